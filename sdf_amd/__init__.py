@@ -1,0 +1,35 @@
+"""sdf_amd -- MI355X-native drop-in for the fogleman/sdf sampling + meshing path.
+
+``from sdf_amd import *`` (or ``from sdf import *`` through the alias package at the repo
+root) exposes the same names as the reference package (reference sdf/__init__.py:1-27):
+the 2-D / 3-D modelling API, the easing module, ``generate / save / sample_slice /
+show_slice`` and ``write_binary_stl``.  Models are lowered to an op tape and sampled and
+meshed by hand-written HIP kernels (sdf_amd/csrc); there is no CPU evaluation path.
+"""
+from . import d2, d3, ease
+
+from .util import *
+
+from .d2 import *
+
+from .d3 import *
+
+from .mesh import Mesh
+
+from .text import (
+    measure_image,
+    measure_text,
+    image,
+    text,
+)
+
+from .core import (
+    generate,
+    save,
+    sample_slice,
+    show_slice,
+)
+
+from .stl import (
+    write_binary_stl,
+)

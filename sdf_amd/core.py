@@ -1,0 +1,197 @@
+"""Sampling + meshing driver: the drop-in for reference sdf/core.py.
+
+Same entry points and keyword arguments as the reference (``generate`` sdf/core.py:84-150,
+``save`` :152-158, ``sample_slice`` :202-232, ``show_slice`` :234-244), but the batch
+loop, the sparse skip test, SDF sampling and marching cubes all run in HIP kernels behind
+the C ABI of include/sdf_hip.h (see sdf_amd/engine.py).  What stays on the host is what
+the reference also does once per call in scalar Python: bounds -> step -> ``np.arange``
+axes (kept in NumPy float64 so the grid is bit-identical to the reference's).
+
+Differences a caller can observe:
+* ``generate`` returns ONE float64 ndarray of shape (3*T, 3) instead of a Python list of
+  3*T tiny arrays (same ``len``, indexing, ``write_binary_stl`` and ``np.unique``
+  behaviour).
+* ``workers`` is accepted and ignored (the device runs every batch concurrently).
+* when ``torch.distributed`` is initialised with world_size > 1 the surviving batches are
+  sharded over the ranks and the triangle buffers all-gathered (sdf_amd/dist.py), so
+  every rank still returns the complete soup in reference order.
+"""
+import multiprocessing
+import time
+
+import numpy as np
+
+from . import stl
+
+WORKERS = multiprocessing.cpu_count()
+SAMPLES = 2 ** 22
+BATCH_SIZE = 32
+
+
+def _cartesian_product(*arrays):
+    """(N, d) points, first axis slowest (reference sdf/core.py:20-26); host helper kept
+    for API compatibility -- the device generates grid points from the axes itself"""
+    grids = np.meshgrid(*arrays, indexing='ij')
+    return np.stack([g.reshape(-1) for g in grids], axis=-1)
+
+
+def _estimate_bounds(sdf):
+    """iterative 16^3 shrink from +-1e9 (reference sdf/core.py:62-82); the 4096 samples of
+    every round are evaluated on the device in float64"""
+    from . import engine
+    eng = engine.get_engine()
+    tape = eng.tape_for(sdf)
+    s = 16
+    x0 = y0 = z0 = -1e9
+    x1 = y1 = z1 = 1e9
+    prev = None
+    for i in range(32):
+        X = np.linspace(x0, x1, s)
+        Y = np.linspace(y0, y1, s)
+        Z = np.linspace(z0, z1, s)
+        d = np.array([X[1] - X[0], Y[1] - Y[0], Z[1] - Z[0]])
+        threshold = np.linalg.norm(d) / 2
+        if threshold == prev:
+            break
+        prev = threshold
+        volume = eng.eval_grid(tape, X, Y, Z)
+        where = np.argwhere(np.abs(volume) <= threshold)
+        x1, y1, z1 = (x0, y0, z0) + where.max(axis=0) * d + d / 2
+        x0, y0, z0 = (x0, y0, z0) + where.min(axis=0) * d - d / 2
+    return ((x0, y0, z0), (x1, y1, z1))
+
+
+def grid_axes(bounds, step=None, samples=SAMPLES):
+    """bounds/step/samples -> (X, Y, Z, (dx, dy, dz)) exactly as reference sdf/core.py:94-112"""
+    (x0, y0, z0), (x1, y1, z1) = bounds
+    if step is None and samples is not None:
+        volume = (x1 - x0) * (y1 - y0) * (z1 - z0)
+        step = (volume / samples) ** (1 / 3)
+    try:
+        dx, dy, dz = step
+    except TypeError:
+        dx = dy = dz = step
+    X = np.arange(x0, x1, dx)
+    Y = np.arange(y0, y1, dy)
+    Z = np.arange(z0, z1, dz)
+    return X, Y, Z, (dx, dy, dz)
+
+
+def generate(
+        sdf,
+        step=None, bounds=None, samples=SAMPLES,
+        workers=WORKERS, batch_size=BATCH_SIZE,
+        verbose=True, sparse=True):
+
+    from . import engine, dist
+    start = time.time()
+    eng = engine.get_engine()
+    tape = eng.tape_for(sdf)
+
+    if bounds is None:
+        bounds = _estimate_bounds(sdf)
+    (x0, y0, z0), (x1, y1, z1) = bounds
+    X, Y, Z, (dx, dy, dz) = grid_axes(bounds, step, samples)
+
+    if verbose:
+        print('min %g, %g, %g' % (x0, y0, z0))
+        print('max %g, %g, %g' % (x1, y1, z1))
+        print('step %g, %g, %g' % (dx, dy, dz))
+
+    s = batch_size
+    num_batches = (-(-len(X) // s)) * (-(-len(Y) // s)) * (-(-len(Z) // s))
+    if verbose:
+        def overlapped(n):       # samples counted with the 1-sample batch overlap (core.py:121-122)
+            return sum(min(s + 1, n - i) for i in range(0, n, s))
+        num_samples = overlapped(len(X)) * overlapped(len(Y)) * overlapped(len(Z))
+        print('%d samples in %d batches with %d workers' % (num_samples, num_batches, workers))
+
+    if dist.world_size() > 1:
+        points, stats = dist.generate_sharded(eng, tape, X, Y, Z, batch_size, sparse)
+    else:
+        mesh = eng.generate(tape, X, Y, Z, batch_size, sparse)
+        try:
+            points = mesh.points()
+            stats = mesh.stats()
+        finally:
+            mesh.close()
+
+    if verbose:
+        print('%d skipped, %d empty, %d nonempty' % (stats['skipped'], stats['empty'], stats['nonempty']))
+        triangles = len(points) // 3
+        seconds = time.time() - start
+        print('%d triangles in %g seconds' % (triangles, seconds))
+
+    generate.last_stats = stats
+    return points
+
+
+generate.last_stats = None
+
+
+def save(path, *args, **kwargs):
+    """reference sdf/core.py:152-158"""
+    points = generate(*args, **kwargs)
+    if path.lower().endswith('.stl'):
+        stl.write_binary_stl(path, points)
+    else:
+        mesh = _mesh(points)
+        mesh.write(path)
+
+
+def _mesh(points):
+    """vertex weld for non-STL formats (reference sdf/core.py:160-164; needs meshio)"""
+    import meshio
+    points, cells = np.unique(points, axis=0, return_inverse=True)
+    cells = [('triangle', cells.reshape((-1, 3)))]
+    return meshio.Mesh(points, cells)
+
+
+def sample_slice(
+        sdf, w=1024, h=1024,
+        x=None, y=None, z=None, bounds=None):
+    """a w x h image of the field on an axis-aligned plane (reference sdf/core.py:202-232)"""
+    from . import engine
+    eng = engine.get_engine()
+    tape = eng.tape_for(sdf)
+
+    if bounds is None:
+        bounds = _estimate_bounds(sdf)
+    (x0, y0, z0), (x1, y1, z1) = bounds
+
+    if x is not None:
+        X = np.array([x])
+        Y = np.linspace(y0, y1, w)
+        Z = np.linspace(z0, z1, h)
+        extent = (Z[0], Z[-1], Y[0], Y[-1])
+        axes = 'ZY'
+    elif y is not None:
+        Y = np.array([y])
+        X = np.linspace(x0, x1, w)
+        Z = np.linspace(z0, z1, h)
+        extent = (Z[0], Z[-1], X[0], X[-1])
+        axes = 'ZX'
+    elif z is not None:
+        Z = np.array([z])
+        X = np.linspace(x0, x1, w)
+        Y = np.linspace(y0, y1, h)
+        extent = (Y[0], Y[-1], X[0], X[-1])
+        axes = 'YX'
+    else:
+        raise Exception('x, y, or z position must be specified')
+
+    return eng.eval_grid(tape, X, Y, Z).reshape((w, h)), extent, axes
+
+
+def show_slice(*args, **kwargs):
+    """matplotlib viewer around sample_slice (reference sdf/core.py:234-244)"""
+    import matplotlib.pyplot as plt
+    show_abs = kwargs.pop('abs', False)
+    a, extent, axes = sample_slice(*args, **kwargs)
+    if show_abs:
+        a = np.abs(a)
+    im = plt.imshow(a, extent=extent, origin='lower')
+    plt.xlabel(axes[0])
+    plt.ylabel(axes[1])
+    plt.colorbar(im)
+    plt.show()

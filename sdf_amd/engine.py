@@ -1,0 +1,286 @@
+"""Host binding of the HIP library (sdf_amd/csrc -> libsdf_hip.so) through its C ABI
+(include/sdf_hip.h).  ctypes only: no torch types cross the boundary; torch is used by
+sdf_amd/dist.py for the RCCL exchange, not here.
+
+There is NO CPU fallback: if the shared library is missing, or no MI355X is visible,
+every entry point raises.  (The CPU checker under oracle/ is test infrastructure and is
+never imported from this package.)
+"""
+import ctypes
+import os
+import threading
+import weakref
+
+import numpy as np
+
+from . import tape as _tape
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsdf_hip.so')
+
+PRECISION_F64 = 0
+PRECISION_F32 = 1
+
+_c_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+_f64p = ctypes.POINTER(ctypes.c_double)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class SdfStats(ctypes.Structure):
+    """mirror of `sdf_stats` in include/sdf_hip.h"""
+    _fields_ = [
+        ('n_batches', _c_i64), ('n_skipped', _c_i64), ('n_empty', _c_i64), ('n_nonempty', _c_i64),
+        ('n_triangles', _c_i64), ('n_grid_voxels', _c_i64), ('n_eval_voxels', _c_i64),
+        ('n_ambiguous_cells', _c_i64), ('n_work_begin', _c_i64), ('n_work_end', _c_i64),
+        ('n_retries', _c_i64),
+        ('ms_prepass', ctypes.c_double), ('ms_mesh', ctypes.c_double), ('ms_emit', ctypes.c_double),
+        ('ms_total', ctypes.c_double),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+ABI = {
+    'sdf_abi_version': (ctypes.c_int, []),
+    'sdf_last_error': (ctypes.c_char_p, []),
+    'sdf_device_count': (ctypes.c_int, []),
+    'sdf_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    'sdf_ctx_destroy': (ctypes.c_int, [_vp]),
+    'sdf_ctx_set_stream': (ctypes.c_int, [_vp, _vp]),
+    'sdf_ctx_synchronize': (ctypes.c_int, [_vp]),
+    'sdf_tape_create': (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _f64p, ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
+    'sdf_tape_destroy': (ctypes.c_int, [_vp]),
+    'sdf_eval_points': (ctypes.c_int, [_vp, _vp, _c_i64, ctypes.c_int, _vp, ctypes.c_int]),
+    'sdf_eval_points_host': (ctypes.c_int, [_vp, _f64p, _c_i64, ctypes.c_int, _f64p, ctypes.c_int]),
+    'sdf_eval_grid_host': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p,
+                                          ctypes.c_int, _f64p, ctypes.c_int]),
+    'sdf_marching_cubes': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp,
+                                          _c_i64, ctypes.POINTER(_c_i64)]),
+    'sdf_marching_cubes_host': (ctypes.c_int, [_vp, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               _f32p, _c_i64, ctypes.POINTER(_c_i64)]),
+    'sdf_generate': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int,
+                                    ctypes.POINTER(_vp)]),
+    'sdf_mesh_stats': (ctypes.c_int, [_vp, ctypes.POINTER(SdfStats)]),
+    'sdf_mesh_triangles': (_c_i64, [_vp]),
+    'sdf_mesh_emit_device': (ctypes.c_int, [_vp, _vp]),
+    'sdf_mesh_emit_host': (ctypes.c_int, [_vp, _f64p]),
+    'sdf_mesh_emit_stl_host': (ctypes.c_int, [_vp, _vp]),
+    'sdf_mesh_kinds': (ctypes.c_int, [_vp, _u8p]),
+    'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
+}
+ABI_VERSION = 1
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class SdfHipError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libsdf_hip.so and attach the prototypes; raises if it was not built"""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise SdfHipError(
+                '%s is missing: build the HIP extension first '
+                '(python -c "import __graft_entry__ as g; g.build()"); sdf_amd has no CPU path' % p)
+        lib = ctypes.CDLL(p)
+        for name, (rt, at) in ABI.items():
+            fn = getattr(lib, name)
+            fn.restype = rt
+            fn.argtypes = at
+        if lib.sdf_abi_version() != ABI_VERSION:
+            raise SdfHipError('libsdf_hip.so ABI %d != binding %d' % (lib.sdf_abi_version(), ABI_VERSION))
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        msg = lib.sdf_last_error()
+        raise SdfHipError(msg.decode() if msg else 'sdf_hip error %d' % rc)
+
+
+def _dp(a, t):
+    return a.ctypes.data_as(t)
+
+
+class DeviceTape:
+    """a lowered model resident on the device (`sdf_tape*`)"""
+
+    def __init__(self, eng, tape):
+        self.engine = eng
+        self.tape = tape
+        self.handle = _vp()
+        lib = eng.lib
+        _check(lib, lib.sdf_tape_create(eng.ctx, _dp(tape.code, _u32p), len(tape.code),
+                                        _dp(tape.consts, _f64p), len(tape.consts),
+                                        tape.n_pslots, tape.n_dslots, ctypes.byref(self.handle)))
+        self._fin = weakref.finalize(self, lib.sdf_tape_destroy, self.handle)
+
+
+class Mesh:
+    """result of one `generate` call (`sdf_mesh*`): triangle soup resident on the device"""
+
+    def __init__(self, eng, handle):
+        self.engine = eng
+        self.handle = handle
+        self._fin = weakref.finalize(self, eng.lib.sdf_mesh_destroy, handle)
+
+    @property
+    def n_triangles(self):
+        return int(self.engine.lib.sdf_mesh_triangles(self.handle))
+
+    def stats(self):
+        st = SdfStats()
+        _check(self.engine.lib, self.engine.lib.sdf_mesh_stats(self.handle, ctypes.byref(st)))
+        d = {k: getattr(st, k) for k, _ in SdfStats._fields_}
+        d.update(skipped=st.n_skipped, empty=st.n_empty, nonempty=st.n_nonempty,
+                 batches=st.n_batches, triangles=st.n_triangles)
+        return d
+
+    def kinds(self):
+        """per-batch classification in reference batch order: 0 skipped / 1 empty / 2 nonempty
+        (3 = outside this rank's shard)"""
+        n = self.stats()['n_batches']
+        out = np.empty(max(n, 1), np.uint8)
+        _check(self.engine.lib, self.engine.lib.sdf_mesh_kinds(self.handle, _dp(out, _u8p)))
+        return out[:n]
+
+    def points(self):
+        """(3T, 3) float64 world-space soup in reference order, copied to the host"""
+        t = self.n_triangles
+        out = np.empty((3 * t, 3), np.float64)
+        if t:
+            _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_host(self.handle, _dp(out, _f64p)))
+        return out
+
+    def emit_device(self, device_ptr):
+        """write the (3T,3) float64 soup into caller-owned device memory (e.g. a torch tensor)"""
+        _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_device(self.handle, _vp(device_ptr)))
+
+    def stl_records(self):
+        """T x 50-byte binary STL records (normals computed on the device)"""
+        t = self.n_triangles
+        out = np.empty(50 * t, np.uint8)
+        if t:
+            _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_stl_host(self.handle, out.ctypes.data_as(_vp)))
+        return out
+
+    def close(self):
+        self._fin()
+
+
+class Engine:
+    """one HIP context (`sdf_ctx*`) on one device"""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        n = self.lib.sdf_device_count()
+        if n <= 0:
+            raise SdfHipError('no HIP device visible (sdf_amd has no CPU path): %s'
+                              % (self.lib.sdf_last_error() or b'').decode())
+        self.device = device
+        self.ctx = _vp()
+        _check(self.lib, self.lib.sdf_ctx_create(device, ctypes.byref(self.ctx)))
+        self._fin = weakref.finalize(self, self.lib.sdf_ctx_destroy, self.ctx)
+        self.precision = PRECISION_F64
+        self._tapes = weakref.WeakValueDictionary()
+
+    def set_stream(self, stream_ptr):
+        _check(self.lib, self.lib.sdf_ctx_set_stream(self.ctx, _vp(stream_ptr)))
+
+    def synchronize(self):
+        _check(self.lib, self.lib.sdf_ctx_synchronize(self.ctx))
+
+    # -- models --
+    def tape_for(self, sdf):
+        """lower `sdf` NOW (boolean smoothing constants are evaluation-time state in the
+        reference, so nothing is cached across calls beyond identical tapes)"""
+        if isinstance(sdf, DeviceTape):
+            return sdf
+        t = sdf if isinstance(sdf, _tape.Tape) else _tape.lower(sdf)
+        key = (t.code.tobytes(), t.consts.tobytes())
+        dt = self._tapes.get(key)
+        if dt is None:
+            dt = DeviceTape(self, t)
+            self._tapes[key] = dt
+        return dt
+
+    # -- f(P) --
+    def eval_points(self, sdf, pts):
+        dt = self.tape_for(sdf)
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        if pts.ndim != 2 or pts.shape[1] not in (2, 3):
+            raise ValueError('points must be (N,2) or (N,3)')
+        out = np.empty(len(pts), np.float64)
+        if len(pts):
+            _check(self.lib, self.lib.sdf_eval_points_host(dt.handle, _dp(pts, _f64p), len(pts), pts.shape[1],
+                                                           _dp(out, _f64p), self.precision))
+        return out
+
+    def eval_grid(self, sdf, X, Y, Z):
+        dt = self.tape_for(sdf)
+        X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
+        out = np.empty((len(X), len(Y), len(Z)), np.float64)
+        if out.size:
+            _check(self.lib, self.lib.sdf_eval_grid_host(dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y),
+                                                         _dp(Z, _f64p), len(Z), _dp(out, _f64p), self.precision))
+        return out
+
+    # -- meshing --
+    def marching_cubes(self, volume):
+        """soup (3T,3) float32 in volume index coordinates of a host volume
+        (drop-in for reference sdf/core.py:16-18 `_marching_cubes`; raises nothing on an empty
+        result, returns a (0,3) array)"""
+        vol = np.ascontiguousarray(volume, dtype=np.float32)
+        if vol.ndim != 3:
+            raise ValueError('Input volume should be a 3D numpy array.')
+        cells = max(1, (max(vol.shape[0], 1) - 1) * (max(vol.shape[1], 1) - 1) * (max(vol.shape[2], 1) - 1))
+        cap = min(5 * cells, max(4096, 2 * cells))
+        while True:
+            out = np.empty((cap, 9), np.float32)
+            nt = _c_i64(0)
+            _check(self.lib, self.lib.sdf_marching_cubes_host(self.ctx, _dp(vol, _f32p), vol.shape[0], vol.shape[1],
+                                                              vol.shape[2], _dp(out, _f32p), cap, ctypes.byref(nt)))
+            if nt.value <= cap:
+                return out[:nt.value].reshape(-1, 3)
+            cap = nt.value
+
+    def generate(self, sdf, X, Y, Z, batch_size=32, sparse=True, shard=(0, 1)):
+        dt = self.tape_for(sdf)
+        X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
+        h = _vp()
+        _check(self.lib, self.lib.sdf_generate(dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y),
+                                               _dp(Z, _f64p), len(Z), int(batch_size), 1 if sparse else 0,
+                                               int(shard[0]), int(shard[1]), self.precision, ctypes.byref(h)))
+        m = Mesh(self, h)
+        m._tape = dt          # keep the device tape alive as long as the mesh
+        return m
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+    if device is None:
+        device = int(os.environ.get('SDF_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    eng = _engines.get(device)
+    if eng is None:
+        eng = _engines[device] = Engine(device)
+    return eng
+
+
+def evaluate(sdf, p):
+    """f(p) on the device -> (N,) float64 (reference sdf/d3.py:24-25 reshapes to (N,1))"""
+    return get_engine().eval_points(sdf, p)

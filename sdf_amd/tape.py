@@ -1,0 +1,343 @@
+"""Lowering of the expression tree to the flat op tape of the HIP interpreter.
+
+The reference evaluates a model by recursive Python closure calls over whole NumPy arrays
+(reference sdf/d3.py:24-25 and SURVEY.md 3.4).  The device evaluates it with a small
+register machine, one lane per sample (csrc/sdf_interp.h):
+
+    p      current point (3 scalars; 2-D nodes use x, y)
+    acc    current distance
+    PS[s]  saved points / per-node scratch triples      (static slot numbers)
+    DS[s]  saved distances / per-node scratch scalars   (static slot numbers)
+
+The tape is a list of fixed-size instructions ``(op, post, a, b, const_off)`` packed in two
+u32 words, plus one float64 constant pool.  Because the tape is straight-line code, every
+stack position is known at lowering time, so instructions name their slots explicitly and
+the kernel never keeps a dynamic stack pointer.
+
+Value-producing instructions (all leaves and COMB) fold their value ``v`` into the
+accumulator through ``post``:
+
+    SET   acc = v                     UNION  acc = min(acc, v)       SUNION  smooth, K
+    DIFF  acc = max(acc, -v)          INTER  acc = max(acc, v)       SDIFF / SINTER / BLEND
+
+which is what removes most stack traffic: ``a | b.translate(t) | c`` lowers to
+``A; SAVE_P; TRANSLATE; B[post=UNION]; LOAD_P; C[post=UNION]`` without touching DS.
+The constant at ``const_off`` is K (always reserved); leaf parameters follow it.
+"""
+import numpy as np
+
+from . import dn
+from .ir import Node, unwrap, resolved_k, NODE_OPS
+
+# ---- machine opcodes (shared with csrc/opcodes.h through tools/gen_headers.py) -----------
+_LEAVES = [
+    'sphere', 'plane', 'box', 'rounded_box', 'wireframe_box', 'torus', 'capsule', 'cylinder',
+    'capped_cylinder', 'rounded_cylinder', 'capped_cone', 'rounded_cone', 'ellipsoid',
+    'pyramid', 'tetrahedron', 'octahedron', 'dodecahedron', 'icosahedron',
+    'circle', 'line', 'rectangle', 'rounded_rectangle', 'equilateral_triangle', 'hexagon',
+    'rounded_x', 'polygon', 'vesica',
+]
+_MACHINE = (
+    ['END'] + ['L_' + n.upper() for n in _LEAVES] + [
+        'COMB',            # v = acc, d1 = DS[a]: acc = post(DS[a], acc)
+        # point ops
+        'TRANSLATE', 'SCALE', 'ROTATE', 'ELONGATE', 'TWIST', 'BEND', 'BEND_LINEAR',
+        'BEND_RADIAL', 'WRAP_AROUND', 'CIRC_PREP', 'CIRC_SET', 'REP_PREP', 'REP_SET',
+        'TRANSLATE2', 'SCALE2', 'ROTATE2', 'ELONGATE2', 'REVOLVE', 'SETZ0',
+        'SAVE_P', 'LOAD_P',
+        # distance ops
+        'PUSH_D', 'NEG', 'ADDC', 'SUBC', 'MULC', 'SHELL', 'ADD_DS',
+        'TRANS_LIN_PRE', 'TRANS_RAD_PRE', 'TRANS_MIX',
+        'EXT_PRE', 'EXT_POST', 'EXTTO_PRE', 'EXTTO_MIX', 'SLICE_POST',
+    ])
+OP = {name: i for i, name in enumerate(_MACHINE)}
+OP_NAMES = _MACHINE
+
+POST = {'SET': 0, 'UNION': 1, 'DIFF': 2, 'INTER': 3, 'SUNION': 4, 'SDIFF': 5, 'SINTER': 6, 'BLEND': 7}
+POST_NAMES = list(POST)
+
+# hard limits of the default kernel build (csrc/sdf_interp.h NP_SLOTS / ND_SLOTS)
+MAX_P_SLOTS = 8
+MAX_D_SLOTS = 8
+
+_PURE_TRANSFORMS = {
+    # node op -> machine op, for transforms that only rewrite p (no post-processing of acc)
+    'translate': 'TRANSLATE', 'rotate': 'ROTATE', 'twist': 'TWIST', 'bend': 'BEND',
+    'bend_linear': 'BEND_LINEAR', 'bend_radial': 'BEND_RADIAL', 'wrap_around': 'WRAP_AROUND',
+    'translate2': 'TRANSLATE2', 'rotate2': 'ROTATE2', 'revolve': 'REVOLVE',
+}
+_BOOL_POST = {
+    'union': ('UNION', 'SUNION'), 'difference': ('DIFF', 'SDIFF'),
+    'intersection': ('INTER', 'SINTER'), 'blend': (None, 'BLEND'),
+}
+
+# rough per-sample arithmetic weights (adds/muls/compares = 1, fma = 2; sqrt/div/trig listed
+# separately) used only for the VALU-side figure bench.py prints
+_FLOPS = {
+    'L_SPHERE': (10, 1), 'L_PLANE': (8, 0), 'L_BOX': (22, 1), 'L_ROUNDED_BOX': (26, 1),
+    'L_WIREFRAME_BOX': (70, 3), 'L_TORUS': (9, 2), 'L_CAPSULE': (22, 2), 'L_CYLINDER': (5, 1),
+    'L_CAPPED_CYLINDER': (40, 3), 'L_ROUNDED_CYLINDER': (16, 2), 'L_CAPPED_CONE': (50, 5),
+    'L_ROUNDED_CONE': (25, 3), 'L_ELLIPSOID': (20, 9), 'L_PYRAMID': (45, 3),
+    'ROTATE': (15, 0), 'TRANSLATE': (3, 0), 'CIRC_PREP': (10, 4), 'CIRC_SET': (6, 2),
+    'BEND_LINEAR': (20, 1), 'REP_PREP': (9, 3), 'REP_SET': (9, 0),
+}
+
+
+class Tape:
+    """a lowered model: ``code`` (uint32, 2 words per instruction), ``consts`` (float64)"""
+
+    def __init__(self, code, consts, n_pslots, n_dslots, dim):
+        self.code = np.ascontiguousarray(code, dtype=np.uint32)
+        self.consts = np.ascontiguousarray(consts, dtype=np.float64)
+        self.n_pslots = n_pslots
+        self.n_dslots = n_dslots
+        self.dim = dim
+
+    @property
+    def n_instr(self):
+        return len(self.code) // 2
+
+    def disassemble(self):
+        out = []
+        for i in range(self.n_instr):
+            w0, w1 = int(self.code[2 * i]), int(self.code[2 * i + 1])
+            out.append('%3d  %-14s post=%-6s a=%d b=%d c@%d' % (
+                i, OP_NAMES[w0 & 255], POST_NAMES[(w0 >> 8) & 255], (w0 >> 16) & 255, w0 >> 24, w1))
+        return '\n'.join(out)
+
+    def flop_estimate(self):
+        """(plain ops, sqrt/div/transcendental ops) per evaluated sample"""
+        plain = special = 0
+        for i in range(self.n_instr):
+            name = OP_NAMES[int(self.code[2 * i]) & 255]
+            a, b = _FLOPS.get(name, (4, 0))
+            plain += a
+            special += b
+            if (int(self.code[2 * i]) >> 8) & 255 >= 4:
+                plain += 12
+                special += 1
+            elif (int(self.code[2 * i]) >> 8) & 255:
+                plain += 1
+        return plain, special
+
+
+class _Lowering:
+    def __init__(self):
+        self.code = []
+        self.consts = []
+        self.pdepth = self.ddepth = 0
+        self.pmax = self.dmax = 0
+
+    # -- emission helpers --
+    def emit(self, op, post='SET', a=0, b=0, consts=(), K=0.0):
+        off = len(self.consts)
+        self.consts.append(float(K))
+        self.consts.extend(float(c) for c in consts)
+        assert 0 <= a < 256 and 0 <= b < 256
+        self.code.append(OP[op] | (POST[post] << 8) | (a << 16) | (b << 24))
+        self.code.append(off)
+
+    def palloc(self):
+        s = self.pdepth
+        self.pdepth += 1
+        self.pmax = max(self.pmax, self.pdepth)
+        if self.pdepth > MAX_P_SLOTS:
+            raise ValueError('model needs more than %d saved-point slots on the device' % MAX_P_SLOTS)
+        return s
+
+    def pfree(self):
+        self.pdepth -= 1
+
+    def dalloc(self):
+        s = self.ddepth
+        self.ddepth += 1
+        self.dmax = max(self.dmax, self.ddepth)
+        if self.ddepth > MAX_D_SLOTS:
+            raise ValueError('model needs more than %d saved-distance slots on the device' % MAX_D_SLOTS)
+        return s
+
+    def dfree(self):
+        self.ddepth -= 1
+
+    # -- analysis --
+    def transparent(self, obj):
+        """True when evaluating obj never needs the accumulator for itself, so its final
+        leaf can fold straight into the caller's accumulator"""
+        n = unwrap(obj)
+        if 'L_' + n.op.upper() in OP:
+            return True
+        if n.op in _PURE_TRANSFORMS:
+            return self.transparent(n.children[0])
+        return False
+
+    # -- lowering --
+    def value(self, obj, dim, post='SET', K=0.0):
+        """emit code that folds obj(p) into acc with `post`; returns True if p is clobbered"""
+        n = unwrap(obj)
+        if post != 'SET' and not self.transparent(n):
+            s = self.dalloc()
+            self.emit('PUSH_D', a=s)
+            dirty = self.value(n, dim, 'SET')
+            self.emit('COMB', post, a=s, K=K)
+            self.dfree()
+            return dirty
+        op = n.op
+        if n.dim and n.dim != dim:
+            raise TypeError('%s is a %d-D node used on %d-D points' % (op, n.dim, dim))
+        leaf = 'L_' + op.upper()
+        if leaf in OP:
+            self.emit(leaf, post, consts=n.params, K=K)
+            return False
+        if op in _PURE_TRANSFORMS:
+            self.emit(_PURE_TRANSFORMS[op], consts=n.params)
+            self.value(n.children[0], 2 if op == 'revolve' else dim, post, K)
+            return True
+        # everything below runs with post == 'SET'
+        if op in _BOOL_POST:
+            return self.boolean(n, dim)
+        if op == 'scale' or op == 'scale2':
+            self.emit('SCALE' if op == 'scale' else 'SCALE2', consts=n.params)
+            self.value(n.children[0], dim)
+            self.emit('MULC', consts=[n.params[-1]])
+            return True
+        if op == 'elongate' or op == 'elongate2':
+            s = self.dalloc()
+            self.emit('ELONGATE' if op == 'elongate' else 'ELONGATE2', a=s, consts=n.params)
+            self.value(n.children[0], dim)
+            self.emit('ADD_DS', a=s)
+            self.dfree()
+            return True
+        if op == 'negate':
+            d = self.value(n.children[0], dim)
+            self.emit('NEG')
+            return d
+        if op in ('dilate', 'erode', 'shell'):
+            d = self.value(n.children[0], dim)
+            self.emit({'dilate': 'SUBC', 'erode': 'ADDC', 'shell': 'SHELL'}[op], consts=n.params)
+            return d
+        if op == 'circular_array':
+            s = self.palloc()
+            self.emit('CIRC_PREP', a=s, consts=n.params)
+            self.emit('CIRC_SET', a=s, consts=[n.params[0]])
+            self.value(n.children[0], dim)
+            self.emit('CIRC_SET', a=s, consts=[0.0])
+            self.value(n.children[0], dim, 'UNION')
+            self.pfree()
+            return True
+        if op == 'repeat':
+            prm = dn.repeat_params(n, dim)
+            nn = int(prm[8])
+            s0 = self.palloc()
+            s1 = self.palloc()
+            self.emit('SAVE_P', a=s0)
+            self.emit('REP_PREP', a=s1, consts=prm[:8])
+            for k in range(nn):
+                self.emit('REP_SET', a=s0, b=s1, consts=list(prm[1:4]) + list(prm[9 + 3 * k: 12 + 3 * k]))
+                self.value(n.children[0], dim, 'SET' if k == 0 else 'UNION')
+            self.pfree()
+            self.pfree()
+            return True
+        if op in ('transition_linear', 'transition_radial'):
+            st = self.dalloc()
+            self.emit('TRANS_LIN_PRE' if op == 'transition_linear' else 'TRANS_RAD_PRE', a=st, consts=n.params)
+            s1 = self.dalloc()
+            dirty = self.pair(n.children[0], n.children[1], dim, s1)
+            self.emit('TRANS_MIX', a=st, b=s1)
+            self.dfree()
+            self.dfree()
+            return dirty
+        if op == 'extrude':
+            s = self.dalloc()
+            self.emit('EXT_PRE', a=s, consts=n.params)
+            self.value(n.children[0], 2)
+            self.emit('EXT_POST', a=s)
+            self.dfree()
+            return True
+        if op == 'extrude_to':
+            s0 = self.dalloc()
+            s1 = self.dalloc()
+            s2 = self.dalloc()
+            self.emit('EXT_PRE', a=s0, consts=[n.params[1]])
+            self.emit('EXTTO_PRE', a=s1, consts=[n.params[0], n.params[2]])
+            self.pair(n.children[0], n.children[1], 2, s2)
+            self.emit('EXTTO_MIX', a=s1, b=s2)
+            self.emit('EXT_POST', a=s0)
+            self.dfree(); self.dfree(); self.dfree()
+            return True
+        if op == 'slice':
+            s = self.dalloc()
+            self.emit('SETZ0')
+            self.pair(n.children[0], n.children[1], 3, s)
+            self.emit('SLICE_POST', a=s)
+            self.dfree()
+            return True
+        raise NotImplementedError(op)
+
+    def pair(self, a, b, dim, dslot):
+        """acc = b(p) with a(p) parked in DS[dslot]; both see the same p"""
+        na = unwrap(a)
+        need_save = self.clobbers(na)
+        sp = None
+        if need_save:
+            sp = self.palloc()
+            self.emit('SAVE_P', a=sp)
+        self.value(na, dim)
+        self.emit('PUSH_D', a=dslot)
+        if need_save:
+            self.emit('LOAD_P', a=sp)
+        dirty = self.value(b, dim)
+        if need_save:
+            self.pfree()
+        return dirty
+
+    def clobbers(self, obj):
+        n = unwrap(obj)
+        if 'L_' + n.op.upper() in OP:
+            return False
+        if n.op in _BOOL_POST or n.op in ('negate', 'dilate', 'erode', 'shell',
+                                          'transition_linear', 'transition_radial'):
+            return any(self.clobbers(c) for c in n.children)
+        return True
+
+    def boolean(self, n, dim):
+        kinds = _BOOL_POST[n.op]
+        Ks = resolved_k(n)
+        kids = n.children
+        dirty_flags = [self.clobbers(c) for c in kids]
+        save = any(dirty_flags[:-1])
+        sp = None
+        dirty = False
+        for i, c in enumerate(kids):
+            if save and sp is None and dirty_flags[i] and i < len(kids) - 1:
+                sp = self.palloc()
+                self.emit('SAVE_P', a=sp)
+            if dirty:
+                self.emit('LOAD_P', a=sp)
+                dirty = False
+            if i == 0:
+                dirty = self.value(c, dim)
+            else:
+                K = Ks[i - 1]
+                if K is None:
+                    if kinds[0] is None:
+                        raise TypeError("unsupported operand type(s) for *: 'NoneType' and 'float'")
+                    dirty = self.value(c, dim, kinds[0])
+                else:
+                    dirty = self.value(c, dim, kinds[1], float(K))
+        if sp is not None:
+            self.pfree()
+        return dirty
+
+
+def lower(obj, dim=None):
+    """lower an SDF2/SDF3/Node to a :class:`Tape`"""
+    root = unwrap(obj)
+    if dim is None:
+        from .d2 import SDF2
+        dim = 2 if isinstance(obj, SDF2) else (root.dim or 3)
+    lw = _Lowering()
+    lw.value(root, dim)
+    lw.emit('END')
+    assert lw.pdepth == 0 and lw.ddepth == 0
+    return Tape(np.array(lw.code, dtype=np.uint32), np.array(lw.consts, dtype=np.float64),
+                lw.pmax, lw.dmax, dim)
