@@ -1,0 +1,115 @@
+/*
+ * sdf_hip.h -- C ABI of libsdf_hip.so, the MI355X (gfx950) sampling + meshing engine.
+ *
+ * The reference (fogleman/sdf) is a single Python process with no FFI boundary; the seams
+ * this ABI replaces are the module-level functions of reference sdf/core.py (cited per entry
+ * point).  The host side that binds these symbols is sdf_amd/engine.py (ctypes); the
+ * maintainer-side binding is shown in INTEGRATION.md.
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a non-zero code on
+ * failure, with a thread-local message available from sdf_last_error(); no C++ exception crosses
+ * the boundary.  Handles are opaque.  A context owns one HIP stream (or adopts the caller's) and
+ * all device scratch; calls on one context must not overlap in time (one caller per context);
+ * different contexts (e.g. one per GPU / per process) are independent.
+ * "host" pointers are ordinary pageable memory, "device" pointers are HIP device memory on the
+ * context's GPU.
+ */
+#ifndef SDF_HIP_H
+#define SDF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDF_ABI_VERSION 1
+
+#define SDF_PRECISION_F64 0 /* parity mode: float64 sampling like the reference's NumPy path */
+#define SDF_PRECISION_F32 1 /* fast mode: float32 sampling */
+
+typedef struct sdf_ctx sdf_ctx;   /* one HIP device + stream + scratch arenas            */
+typedef struct sdf_tape sdf_tape; /* a lowered model (op tape + constants) on the device */
+typedef struct sdf_mesh sdf_mesh; /* the result of one sdf_generate call                 */
+
+/* per-call statistics; the first four are what reference sdf/core.py:144-145 prints */
+typedef struct sdf_stats {
+    int64_t n_batches;
+    int64_t n_skipped;
+    int64_t n_empty;            /* within this call's shard */
+    int64_t n_nonempty;         /* within this call's shard */
+    int64_t n_triangles;        /* within this call's shard */
+    int64_t n_grid_voxels;      /* len(X)*len(Y)*len(Z)                                    */
+    int64_t n_eval_voxels;      /* samples evaluated by the meshing kernel (this shard)    */
+    int64_t n_ambiguous_cells;  /* surface cells with an ambiguous sign configuration      */
+    int64_t n_work_begin;       /* this shard's range in the surviving-batch work list     */
+    int64_t n_work_end;
+    int64_t n_retries;          /* meshing re-runs after a triangle-arena overflow         */
+    double ms_prepass;          /* HIP-event times on the context's stream                 */
+    double ms_mesh;             /* the fused sample+march kernel alone (last run)          */
+    double ms_emit;             /* ordered gather / f64 transform kernel (last emit)       */
+    double ms_total;            /* first launch to last kernel of sdf_generate             */
+} sdf_stats;
+
+int sdf_abi_version(void);
+const char *sdf_last_error(void);
+int sdf_device_count(void); /* <= 0 when no HIP device is usable */
+
+int sdf_ctx_create(int device, sdf_ctx **out);
+int sdf_ctx_destroy(sdf_ctx *ctx);
+/* adopt a caller-owned hipStream_t (e.g. torch's current stream); NULL returns to the own stream */
+int sdf_ctx_set_stream(sdf_ctx *ctx, void *hip_stream);
+int sdf_ctx_synchronize(sdf_ctx *ctx);
+
+/* Upload an op tape produced by sdf_amd/tape.py (2 x uint32 per instruction, float64 constants).
+ * Plays the role of the reference's closure tree (reference sdf/d3.py:48-63). */
+int sdf_tape_create(sdf_ctx *ctx, const uint32_t *code, uint32_t n_words, const double *consts,
+                    uint32_t n_consts, uint32_t n_pslots, uint32_t n_dslots, sdf_tape **out);
+int sdf_tape_destroy(sdf_tape *tape);
+
+/* f(P) for N points of dimension dim (2 or 3): replaces SDF3.__call__ / SDF2.__call__
+ * (reference sdf/d3.py:24-25, sdf/d2.py:23-24).  Output is float64 in both precisions. */
+int sdf_eval_points(sdf_tape *tape, const void *d_points, int64_t n, int dim, void *d_out, int precision);
+int sdf_eval_points_host(sdf_tape *tape, const double *h_points, int64_t n, int dim, double *h_out,
+                         int precision);
+/* f on the cartesian product X x Y x Z, first axis slowest: replaces `_cartesian_product` +
+ * `sdf(P)` (reference sdf/core.py:20-26, :50-52, :78, :232).  h_out has nx*ny*nz elements. */
+int sdf_eval_grid_host(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z,
+                       int nz, double *h_out, int precision);
+
+/* Marching cubes of a C-order float32 volume (n0,n1,n2) at level 0: replaces `_marching_cubes`
+ * (reference sdf/core.py:16-18 -> skimage.measure.marching_cubes(volume, 0)).  Writes up to
+ * cap_tris triangles (9 float32 each: 3 vertices in volume index coordinates, reference soup
+ * order) and always reports the full count in *n_tris (call again with a larger buffer if it
+ * exceeds cap_tris).  A volume with no surface yields *n_tris == 0 (the reference turns the
+ * corresponding skimage exceptions into an empty batch, sdf/core.py:53-56). */
+int sdf_marching_cubes(sdf_ctx *ctx, const void *d_volume, int n0, int n1, int n2, void *d_out_tris,
+                       int64_t cap_tris, int64_t *n_tris);
+int sdf_marching_cubes_host(sdf_ctx *ctx, const float *h_volume, int n0, int n1, int n2, float *h_out_tris,
+                            int64_t cap_tris, int64_t *n_tris);
+
+/* The batch loop of `generate` (reference sdf/core.py:114-141) with `_worker` (:45-60) and
+ * `_skip` (:28-43) inside: X, Y, Z are the float64 `np.arange` axes (host), batch_size the
+ * reference's BATCH_SIZE (<= 32), sparse its `sparse=` flag.  shard_index/shard_count split the
+ * surviving-batch work list into contiguous chunks (1 GPU: 0, 1).  The triangles stay on the
+ * device in the returned mesh until emitted. */
+int sdf_generate(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
+                 int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,
+                 sdf_mesh **out);
+int sdf_mesh_stats(sdf_mesh *mesh, sdf_stats *out);
+int64_t sdf_mesh_triangles(sdf_mesh *mesh);
+/* write the (3T,3) float64 world-space soup (reference order; `points * scale + offset`,
+ * reference sdf/core.py:58-60) into caller-owned device / host memory of 9*T doubles */
+int sdf_mesh_emit_device(sdf_mesh *mesh, void *d_out);
+int sdf_mesh_emit_host(sdf_mesh *mesh, double *h_out);
+/* T binary-STL records of 50 bytes (f32 normal, 3 x f32 vertex, u16 0), i.e. the body that
+ * `write_binary_stl` writes after the 84-byte header (reference sdf/stl.py:4-24) */
+int sdf_mesh_emit_stl_host(sdf_mesh *mesh, void *h_out);
+/* per-batch classification, n_batches bytes: 0 skipped, 1 empty, 2 nonempty, 3 other shard */
+int sdf_mesh_kinds(sdf_mesh *mesh, uint8_t *h_out);
+int sdf_mesh_destroy(sdf_mesh *mesh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDF_HIP_H */

@@ -1,0 +1,946 @@
+// sdf_hip.hip -- kernels + C ABI of libsdf_hip.so (gfx950 only).
+//
+// Kernels
+//   k_eval_points / k_eval_grid   f(P): the tape interpreter alone
+//   k_skip                        the reference's `_skip` predicate for every batch at once
+//                                 (reference sdf/core.py:28-43), 16 lanes per batch
+//   k_compact                     ordered work list of the surviving batches
+//   k_mesh                        THE hot kernel: one persistent workgroup per CU pulls batches
+//                                 from the work list; samples the (<=33)^3 tile through the tape
+//                                 interpreter (float64 -> float32 like skimage's cast) straight
+//                                 into LDS (143,748 B of gfx950's 160 KiB), classifies the cells,
+//                                 block-scans the triangle counts and emits the batch-local
+//                                 float32 soup (reference `_worker`, sdf/core.py:45-56)
+//   k_scan                        exclusive scan of per-batch triangle counts (reference order)
+//   k_gather                      ordered gather + `points * scale + offset` in float64
+//                                 (reference sdf/core.py:58-60, :141)
+//   k_mc_rows / k_mc_emit         marching cubes of a caller-supplied volume (`_marching_cubes`)
+//   k_stl                         50-byte STL records (reference sdf/stl.py:4-24)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sdf_hip.h"
+#include "mc_table.h"
+#include "sdf_interp.h"
+
+using namespace sdfk;
+
+// ============================================================================================
+// device side
+// ============================================================================================
+
+struct McTables {   // copied to __constant__ memory once per process
+    unsigned char ntri[256];
+    unsigned char amb[256];
+    signed char tri[256][16];
+};
+__constant__ McTables c_mc;
+
+struct MeshCounters {   // zeroed before every k_mesh run
+    unsigned long long tri_counter;   // next free triangle slot in the arena
+    unsigned long long n_eval;
+    unsigned int work_counter;
+    unsigned int overflow;
+    unsigned int n_empty, n_nonempty;
+    unsigned long long n_ambiguous;
+    unsigned long long total;         // written by k_scan
+};
+
+struct GridDesc {
+    const double *X, *Y, *Z;   // device copies of the np.arange axes
+    int nx, ny, nz;
+    int bs;                    // batch size (cells per axis), samples per axis = bs + 1
+    int nbx, nby, nbz;         // batches per axis
+};
+
+__device__ __forceinline__ void batch_origin(const GridDesc &g, int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {
+    // itertools.product(Xs, Ys, Zs): Z fastest (reference sdf/core.py:119)
+    const int ibz = b % g.nbz, iby = (b / g.nbz) % g.nby, ibx = b / (g.nbz * g.nby);
+    ox = ibx * g.bs; oy = iby * g.bs; oz = ibz * g.bs;
+    lx = min(g.bs + 1, g.nx - ox); ly = min(g.bs + 1, g.ny - oy); lz = min(g.bs + 1, g.nz - oz);
+}
+
+template <typename T, bool FULL>
+__global__ __launch_bounds__(256) void k_eval_points(const uint32_t *__restrict__ code, const T *__restrict__ consts,
+                                                     const double *__restrict__ pts, long long n, int dim,
+                                                     double *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T x = (T)pts[i * dim], y = (T)pts[i * dim + 1], z = dim > 2 ? (T)pts[i * dim + 2] : T(0);
+    out[i] = (double)run_tape<T, FULL>(code, consts, x, y, z);
+}
+
+template <typename T, bool FULL>
+__global__ __launch_bounds__(256) void k_eval_grid(const uint32_t *__restrict__ code, const T *__restrict__ consts,
+                                                   const double *__restrict__ X, const double *__restrict__ Y,
+                                                   const double *__restrict__ Z, int nx, int ny, int nz,
+                                                   double *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)nx * ny * nz;
+    if (i >= n) return;
+    const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((long long)nz * ny));
+    out[i] = (double)run_tape<T, FULL>(code, consts, (T)X[ix], (T)Y[iy], (T)Z[iz]);
+}
+
+// reference sdf/core.py:28-43.  16 lanes per batch: lane 0 = centre, lanes 1..8 = corners in
+// itertools.product((x0,x1),(y0,y1),(z0,z1)) order.  kinds[b] = 0 (skipped) or 255 (pending).
+template <typename T, bool FULL>
+__global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
+                                              int nbatches, unsigned char *__restrict__ kinds) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gid >> 4, l = gid & 15;
+    const bool live = b < nbatches && l < 9;
+    int ox = 0, oy = 0, oz = 0, lx = 1, ly = 1, lz = 1;
+    if (b < nbatches) batch_origin(g, b, ox, oy, oz, lx, ly, lz);
+    double x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
+    if (b < nbatches) {
+        x0 = g.X[ox]; x1 = g.X[ox + lx - 1]; y0 = g.Y[oy]; y1 = g.Y[oy + ly - 1]; z0 = g.Z[oz]; z1 = g.Z[oz + lz - 1];
+    }
+    const double cx = (x0 + x1) / 2, cy = (y0 + y1) / 2, cz = (z0 + z1) / 2;
+    double px = cx, py = cy, pz = cz;
+    if (l >= 1) { const int k = l - 1; px = (k & 4) ? x1 : x0; py = (k & 2) ? y1 : y0; pz = (k & 1) ? z1 : z0; }
+    T v = T(0);
+    if (live) v = run_tape<T, FULL>(code, consts, (T)px, (T)py, (T)pz);
+    const int lane = threadIdx.x & 63, base = lane & ~15;
+    const T vc = __shfl(v, base, 64);          // centre
+    const T v1 = __shfl(v, base + 1, 64);      // values[0]
+    const bool pos = v1 > T(0);
+    const bool ok = pos ? (v > T(0)) : (v < T(0));
+    const unsigned long long m = __ballot(ok);
+    const bool all_same = ((m >> (base + 1)) & 0xFFull) == 0xFFull;
+    if (b < nbatches && l == 0) {
+        const double r = fabs((double)vc);
+        const double d = __dsqrt_rn(((cx - x0) * (cx - x0) + (cy - y0) * (cy - y0)) + (cz - z0) * (cz - z0));
+        const bool skip = !(r <= d) && all_same;
+        kinds[b] = skip ? 0 : 255;
+    }
+}
+
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wave_sums, int &total) {
+    // wave64 inclusive scan by shuffles, then 16 wave totals through LDS
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_sums[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; w++) { const int s = wave_sums[w]; if (w < wid) base += s; tot += s; }
+    total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ordered compaction of the pending batches into the work list (single workgroup)
+__global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restrict__ kinds, int nbatches,
+                                                  int *__restrict__ worklist, int *__restrict__ nwork) {
+    __shared__ int wave_sums[16];
+    int base = 0;
+    for (int start = 0; start < nbatches; start += 1024) {
+        const int b = start + threadIdx.x;
+        const int f = (b < nbatches && kinds[b] != 0) ? 1 : 0;
+        int tot;
+        const int pos = block_exclusive_scan_1024(f, wave_sums, tot);
+        if (f) worklist[base + pos] = b;
+        base += tot;
+    }
+    if (threadIdx.x == 0) *nwork = base;
+}
+
+// sign bits of the four samples (o0,o1) in {0,1}^2 of one i2-plane, bit (2*o0+o1) set when > 0
+__device__ __forceinline__ unsigned plane_bits(const float *v, int s0, int s1) {
+    return (v[0] > 0.0f ? 1u : 0u) | (v[s1] > 0.0f ? 2u : 0u) | (v[s0] > 0.0f ? 4u : 0u) | (v[s0 + s1] > 0.0f ? 8u : 0u);
+}
+// plane bit j -> configuration bit 2j (o2 = 0) ; shift left by one for o2 = 1
+__device__ __forceinline__ unsigned spread4(unsigned s) { return (s & 1u) | ((s & 2u) << 1) | ((s & 4u) << 2) | ((s & 8u) << 3); }
+
+// One marching-cubes vertex on edge e of the cell at (i0,i1,i2); v points at the cell's corner 0
+// in a volume with strides (s0, s1, 1).  skimage's placement: with w = 1/(eps+|v|),
+// t = w_hi / (w_lo + w_hi), evaluated in float64 on the float32 samples, stored as float32.
+__device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0, int i1, int i2, int e, float *o) {
+    const int axis = e >> 2, oa = (e >> 1) & 1, ob = e & 1;
+    int o0, o1, o2, stride;
+    if (axis == 0) { o0 = 0; o1 = oa; o2 = ob; stride = s0; }
+    else if (axis == 1) { o0 = oa; o1 = 0; o2 = ob; stride = s1; }
+    else { o0 = oa; o1 = ob; o2 = 0; stride = 1; }
+    const int base = o0 * s0 + o1 * s1 + o2;
+    const double vlo = (double)v[base], vhi = (double)v[base + stride];
+    const double eps = 2.220446049250313e-16;
+    const double wlo = 1.0 / (eps + fabs(vlo)), whi = 1.0 / (eps + fabs(vhi));
+    const double t = whi / (wlo + whi);
+    double p0 = (double)(i0 + o0), p1 = (double)(i1 + o1), p2 = (double)(i2 + o2);
+    if (axis == 0) p0 = (double)i0 + t; else if (axis == 1) p1 = (double)i1 + t; else p2 = (double)i2 + t;
+    o[0] = (float)p0; o[1] = (float)p1; o[2] = (float)p2;
+}
+
+struct MeshArgs {
+    GridDesc g;
+    const int *worklist;
+    int work_begin, work_end;      // this shard's slice of the work list
+    unsigned char *kinds;          // per batch
+    unsigned int *batch_count;     // per work item: triangles
+    unsigned long long *batch_base;  // per work item: first triangle slot in the arena
+    float *arena;                  // 9 floats per triangle
+    unsigned long long arena_cap;  // triangles
+    MeshCounters *ctr;
+};
+
+template <typename T, bool FULL>
+__global__ __launch_bounds__(1024) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *wave_sums = reinterpret_cast<int *>(smem);                 // 16 ints
+    int *bcast = wave_sums + 16;                                    // 16 ints of scratch
+    double *axes = reinterpret_cast<double *>(smem + 128);          // 3 * 33 doubles (X, Y, Z of the tile)
+    float *vol = reinterpret_cast<float *>(smem + 128 + 3 * 33 * 8);  // (bs+1)^3 floats
+    const int tid = threadIdx.x;
+    const GridDesc g = a.g;
+
+    for (;;) {
+        if (tid == 0) bcast[0] = a.work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
+        __syncthreads();
+        const int w = bcast[0];
+        if (w >= a.work_end) break;
+        const int b = a.worklist[w];
+        int ox, oy, oz, lx, ly, lz;
+        batch_origin(g, b, ox, oy, oz, lx, ly, lz);
+        if (tid < lx) axes[tid] = g.X[ox + tid];
+        else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
+        else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
+        __syncthreads();
+
+        // ---- sample the tile: volume = sdf(P).reshape(shape), cast to float32 (core.py:50-52) ----
+        const int nvox = lx * ly * lz;
+        const int lyz = ly * lz;
+        for (int i = tid; i < nvox; i += 1024) {
+            const int ix = i / lyz, r = i - ix * lyz, iy = r / lz, iz = r - iy * lz;
+            const T val = run_tape<T, FULL>(code, consts, (T)axes[ix], (T)axes[33 + iy], (T)axes[66 + iz]);
+            vol[i] = (float)val;
+        }
+        __syncthreads();
+
+        // ---- count: thread t owns the i2-row of cells at (i0, i1) ----
+        const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
+        const int nrows = (c0 > 0 && c1 > 0 && c2 > 0) ? c0 * c1 : 0;
+        int my_tris = 0, my_amb = 0;
+        int i0 = 0, i1 = 0;
+        const float *row = vol;
+        if (tid < nrows) {
+            i0 = tid / c1; i1 = tid - i0 * c1;
+            row = vol + i0 * lyz + i1 * lz;
+            unsigned prev = plane_bits(row, lyz, lz);
+            for (int i2 = 0; i2 < c2; i2++) {
+                const unsigned next = plane_bits(row + i2 + 1, lyz, lz);
+                const unsigned cfg = spread4(prev) | (spread4(next) << 1);
+                my_tris += c_mc.ntri[cfg];
+                my_amb += (c_mc.ntri[cfg] ? c_mc.amb[cfg] : 0);
+                prev = next;
+            }
+        }
+        int total;
+        const int my_off = block_exclusive_scan_1024(my_tris, wave_sums, total);
+        if (tid == 0) {
+            unsigned long long base = 0;
+            if (total) {
+                base = atomicAdd(&a.ctr->tri_counter, (unsigned long long)total);
+                if (base + (unsigned long long)total > a.arena_cap) atomicOr(&a.ctr->overflow, 1u);
+                atomicAdd(&a.ctr->n_nonempty, 1u);
+            } else {
+                atomicAdd(&a.ctr->n_empty, 1u);
+            }
+            atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
+            a.batch_count[w] = (unsigned)total;
+            a.batch_base[w] = base;
+            a.kinds[b] = total ? 2 : 1;
+            reinterpret_cast<unsigned long long *>(bcast + 2)[0] = base;
+        }
+        if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
+        __syncthreads();
+        const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
+
+        // ---- emit the batch-local float32 soup in cell order (skimage order) ----
+        if (total && base + (unsigned long long)total <= a.arena_cap && my_tris) {
+            float *dst = a.arena + (base + (unsigned long long)my_off) * 9ull;
+            unsigned prev = plane_bits(row, lyz, lz);
+            for (int i2 = 0; i2 < c2; i2++) {
+                const unsigned next = plane_bits(row + i2 + 1, lyz, lz);
+                const unsigned cfg = spread4(prev) | (spread4(next) << 1);
+                prev = next;
+                const int k = c_mc.ntri[cfg];
+                for (int j = 0; j < 3 * k; j++) {
+                    mc_vertex(row + i2, lyz, lz, i0, i1, i2, c_mc.tri[cfg][j], dst);
+                    dst += 3;
+                }
+            }
+        }
+        __syncthreads();   // vol / bcast are reused by the next batch
+    }
+}
+
+// exclusive scan of batch_count[w0..w1) -> batch_final (triangle index in the ordered soup)
+__global__ __launch_bounds__(1024) void k_scan(const unsigned int *__restrict__ batch_count, int w0, int w1,
+                                               unsigned long long *__restrict__ batch_final, MeshCounters *ctr) {
+    __shared__ int wave_sums[16];
+    unsigned long long base = 0;
+    for (int start = w0; start < w1; start += 1024) {
+        const int w = start + threadIdx.x;
+        const int v = w < w1 ? (int)batch_count[w] : 0;
+        int tot;
+        const int pos = block_exclusive_scan_1024(v, wave_sums, tot);
+        if (w < w1) batch_final[w] = base + (unsigned long long)pos;
+        base += (unsigned long long)tot;
+    }
+    if (threadIdx.x == 0) ctr->total = base;
+}
+
+// ordered gather + float64 world transform: out[final + i] = f64(local) * scale + offset
+// (reference sdf/core.py:58-60).  One workgroup per work item.
+__global__ __launch_bounds__(256) void k_gather(GridDesc g, const int *__restrict__ worklist, int w0,
+                                                const unsigned int *__restrict__ batch_count,
+                                                const unsigned long long *__restrict__ batch_base,
+                                                const unsigned long long *__restrict__ batch_final,
+                                                const float *__restrict__ arena, double *__restrict__ out) {
+    const int w = w0 + blockIdx.x;
+    const unsigned n = batch_count[w];
+    if (!n) return;
+    const int b = worklist[w];
+    int ox, oy, oz, lx, ly, lz;
+    batch_origin(g, b, ox, oy, oz, lx, ly, lz);
+    const double of[3] = {g.X[ox], g.Y[oy], g.Z[oz]};
+    const double sc[3] = {g.X[ox + 1] - g.X[ox], g.Y[oy + 1] - g.Y[oy], g.Z[oz + 1] - g.Z[oz]};
+    const float *src = arena + batch_base[w] * 9ull;
+    double *dst = out + batch_final[w] * 9ull;
+    const unsigned m = n * 9u;
+    for (unsigned i = threadIdx.x; i < m; i += blockDim.x) {
+        const unsigned ax = i % 3u;
+        const double s = ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2]);
+        const double o = ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]);
+        dst[i] = (double)src[i] * s + o;
+    }
+}
+
+// ---- marching cubes of a caller-supplied volume -------------------------------------------
+__global__ __launch_bounds__(256) void k_mc_rows(const float *__restrict__ vol, int n0, int n1, int n2,
+                                                 unsigned int *__restrict__ row_count) {
+    const int c1 = n1 - 1, c2 = n2 - 1;
+    const long long nrows = (long long)(n0 - 1) * c1;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows) return;
+    const int i0 = (int)(t / c1), i1 = (int)(t - (long long)i0 * c1);
+    const int s0 = n1 * n2, s1 = n2;
+    const float *row = vol + (long long)i0 * s0 + (long long)i1 * s1;
+    unsigned prev = plane_bits(row, s0, s1);
+    unsigned cnt = 0;
+    for (int i2 = 0; i2 < c2; i2++) {
+        const unsigned next = plane_bits(row + i2 + 1, s0, s1);
+        cnt += c_mc.ntri[spread4(prev) | (spread4(next) << 1)];
+        prev = next;
+    }
+    row_count[t] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_rows(const unsigned int *__restrict__ cnt, long long n,
+                                                    unsigned long long *__restrict__ off, unsigned long long *total) {
+    __shared__ int wave_sums[16];
+    unsigned long long base = 0;
+    for (long long start = 0; start < n; start += 1024) {
+        const long long i = start + threadIdx.x;
+        const int v = i < n ? (int)cnt[i] : 0;
+        int tot;
+        const int pos = block_exclusive_scan_1024(v, wave_sums, tot);
+        if (i < n) off[i] = base + (unsigned long long)pos;
+        base += (unsigned long long)tot;
+    }
+    if (threadIdx.x == 0) *total = base;
+}
+
+__global__ __launch_bounds__(256) void k_mc_emit(const float *__restrict__ vol, int n0, int n1, int n2,
+                                                 const unsigned long long *__restrict__ row_off, float *__restrict__ out,
+                                                 unsigned long long cap) {
+    const int c1 = n1 - 1, c2 = n2 - 1;
+    const long long nrows = (long long)(n0 - 1) * c1;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows) return;
+    const int i0 = (int)(t / c1), i1 = (int)(t - (long long)i0 * c1);
+    const int s0 = n1 * n2, s1 = n2;
+    const float *row = vol + (long long)i0 * s0 + (long long)i1 * s1;
+    unsigned long long k = row_off[t];
+    unsigned prev = plane_bits(row, s0, s1);
+    for (int i2 = 0; i2 < c2; i2++) {
+        const unsigned next = plane_bits(row + i2 + 1, s0, s1);
+        const unsigned cfg = spread4(prev) | (spread4(next) << 1);
+        prev = next;
+        const int nt = c_mc.ntri[cfg];
+        for (int j = 0; j < nt; j++, k++) {
+            if (k >= cap) return;
+            for (int q = 0; q < 3; q++) mc_vertex(row + i2, s0, s1, i0, i1, i2, c_mc.tri[cfg][3 * j + q], out + k * 9ull + q * 3);
+        }
+    }
+}
+
+// ---- STL records (reference sdf/stl.py:4-24): float32 vertices, normal = normalised cross ----
+__global__ __launch_bounds__(256) void k_stl(const double *__restrict__ pts, long long ntri, unsigned short *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntri) return;
+    float p[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) p[i] = (float)pts[t * 9 + i];
+    const float ax = p[3] - p[0], ay = p[4] - p[1], az = p[5] - p[2];
+    const float bx = p[6] - p[0], by = p[7] - p[1], bz = p[8] - p[2];
+    // np.cross in float32: separate products and one subtraction each
+    float nx = __fsub_rn(__fmul_rn(ay, bz), __fmul_rn(az, by));
+    float ny = __fsub_rn(__fmul_rn(az, bx), __fmul_rn(ax, bz));
+    float nz = __fsub_rn(__fmul_rn(ax, by), __fmul_rn(ay, bx));
+    const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
+    nx = __fdiv_rn(nx, len); ny = __fdiv_rn(ny, len); nz = __fdiv_rn(nz, len);
+    float rec[12] = {nx, ny, nz, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
+    unsigned short *o = out + t * 25;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const unsigned u = __float_as_uint(rec[i]);
+        o[2 * i] = (unsigned short)(u & 0xFFFFu);
+        o[2 * i + 1] = (unsigned short)(u >> 16);
+    }
+    o[24] = 0;
+}
+
+// ============================================================================================
+// host side: the C ABI
+// ============================================================================================
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return 1; }
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        size_t want = std::max(need, (size_t)256);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
+        bytes = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct sdf_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev[6] = {};
+    int n_cu = 256;
+    size_t lds_max = 0;
+    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, counters, nwork, scratch_in, scratch_out, rows, rows_off;
+    std::vector<DevBuf> arena_pool;   // arenas handed back by destroyed meshes
+    unsigned long long last_tris_per_batch = 0;
+};
+
+struct sdf_tape {
+    sdf_ctx *ctx = nullptr;
+    uint32_t *d_code = nullptr;
+    double *d_c64 = nullptr;
+    float *d_c32 = nullptr;
+    uint32_t n_words = 0, n_consts = 0;
+    bool full = false;
+    unsigned long long hint_tris_per_batch = 0;
+};
+
+struct sdf_mesh {
+    sdf_ctx *ctx = nullptr;
+    sdf_stats st = {};
+    GridDesc g = {};
+    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, arena, out;
+    int work_begin = 0, work_end = 0;
+    bool emitted = false;
+};
+
+static bool tape_needs_full(const uint32_t *code, uint32_t n_words, const double *consts) {
+    auto trig_ease = [](int id) {
+        return id == EASE_in_sine || id == EASE_out_sine || id == EASE_in_out_sine || id == EASE_in_expo ||
+               id == EASE_out_expo || id == EASE_in_out_expo || id == EASE_in_elastic || id == EASE_out_elastic ||
+               id == EASE_in_out_elastic;
+    };
+    for (uint32_t i = 0; i + 1 < n_words; i += 2) {
+        const uint32_t op = code[i] & 255u;
+        const double *c = consts + code[i + 1] + 1;
+        switch (op) {
+        case OP_TWIST: case OP_BEND: case OP_BEND_RADIAL: case OP_WRAP_AROUND: case OP_CIRC_PREP: case OP_CIRC_SET:
+        case OP_TRANS_RAD_PRE:
+            return true;
+        case OP_BEND_LINEAR: if (trig_ease((int)c[10])) return true; break;
+        case OP_TRANS_LIN_PRE: if (trig_ease((int)c[7])) return true; break;
+        case OP_EXTTO_PRE: if (trig_ease((int)c[1])) return true; break;
+        default: break;
+        }
+    }
+    return false;
+}
+
+static int validate_tape(const uint32_t *code, uint32_t n_words, uint32_t n_consts, uint32_t n_p, uint32_t n_d) {
+    if (n_words < 2 || (n_words & 1)) return fail("tape: code must be a non-empty list of 2-word instructions");
+    if (n_p > SDF_NP_SLOTS || n_d > SDF_ND_SLOTS) return fail("tape: model needs more register slots than this build provides");
+    if ((code[n_words - 2] & 255u) != OP_END) return fail("tape: missing END");
+    for (uint32_t i = 0; i < n_words; i += 2) {
+        const uint32_t w0 = code[i], op = w0 & 255u, post = (w0 >> 8) & 255u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
+        if (op >= OP_COUNT) return fail("tape: unknown opcode");
+        if (post > POST_BLEND) return fail("tape: unknown post-combine");
+        if (sa >= SDF_NP_SLOTS || sb >= SDF_NP_SLOTS) return fail("tape: slot out of range");
+        if (code[i + 1] >= n_consts) return fail("tape: constant offset out of range");
+        if (op == OP_END && i != n_words - 2) return fail("tape: END before the last instruction");
+    }
+    return 0;
+}
+
+extern "C" {
+
+int sdf_abi_version(void) { return SDF_ABI_VERSION; }
+const char *sdf_last_error(void) { return g_err.c_str(); }
+
+int sdf_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return 0; }
+    return n;
+}
+
+int sdf_ctx_create(int device, sdf_ctx **out) {
+    if (!out) return fail("sdf_ctx_create: out is NULL");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail("sdf_ctx_create: no such device");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(std::string("sdf_ctx_create: this library is built for gfx950 only, device is ") + prop.gcnArchName);
+    sdf_ctx *c = new sdf_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    c->lds_max = prop.sharedMemPerBlock;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    McTables t;
+    memcpy(t.ntri, MC_NTRI, 256);
+    memcpy(t.amb, MC_AMBIGUOUS, 256);
+    memcpy(t.tri, MC_TRI, sizeof(t.tri));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mc), &t, sizeof(t)));
+    *out = c;
+    return 0;
+}
+
+int sdf_ctx_destroy(sdf_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->axes, &c->kinds, &c->worklist, &c->batch_count, &c->batch_base, &c->batch_final, &c->counters,
+                      &c->nwork, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off})
+        b->release();
+    for (auto &b : c->arena_pool) b.release();
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+int sdf_ctx_set_stream(sdf_ctx *c, void *s) {
+    if (!c) return fail("sdf_ctx_set_stream: ctx is NULL");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+int sdf_ctx_synchronize(sdf_ctx *c) {
+    if (!c) return fail("sdf_ctx_synchronize: ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const double *consts, uint32_t n_consts,
+                    uint32_t n_p, uint32_t n_d, sdf_tape **out) {
+    if (!c || !code || !consts || !out) return fail("sdf_tape_create: NULL argument");
+    if (validate_tape(code, n_words, n_consts, n_p, n_d)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    sdf_tape *t = new sdf_tape();
+    t->ctx = c; t->n_words = n_words; t->n_consts = n_consts;
+    t->full = tape_needs_full(code, n_words, consts);
+    std::vector<float> c32(n_consts);
+    for (uint32_t i = 0; i < n_consts; i++) c32[i] = (float)consts[i];
+    HIPCHK(hipMalloc((void **)&t->d_code, n_words * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&t->d_c64, n_consts * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&t->d_c32, n_consts * sizeof(float)));
+    HIPCHK(hipMemcpy(t->d_code, code, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->d_c64, consts, n_consts * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->d_c32, c32.data(), n_consts * sizeof(float), hipMemcpyHostToDevice));
+    *out = t;
+    return 0;
+}
+
+int sdf_tape_destroy(sdf_tape *t) {
+    if (!t) return 0;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    if (t->d_code) (void)hipFree(t->d_code);
+    if (t->d_c64) (void)hipFree(t->d_c64);
+    if (t->d_c32) (void)hipFree(t->d_c32);
+    delete t;
+    return 0;
+}
+
+}  // extern "C"
+
+// dispatch over (precision, FULL)
+#define LAUNCH_TAPE(KERNEL, grid, block, shmem, t, precision, ...)                                              \
+    do {                                                                                                        \
+        if ((precision) == SDF_PRECISION_F64) {                                                                 \
+            if ((t)->full) hipLaunchKernelGGL((KERNEL<double, true>), grid, block, shmem, (t)->ctx->stream, (t)->d_code, (t)->d_c64, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<double, false>), grid, block, shmem, (t)->ctx->stream, (t)->d_code, (t)->d_c64, __VA_ARGS__); \
+        } else {                                                                                                \
+            if ((t)->full) hipLaunchKernelGGL((KERNEL<float, true>), grid, block, shmem, (t)->ctx->stream, (t)->d_code, (t)->d_c32, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<float, false>), grid, block, shmem, (t)->ctx->stream, (t)->d_code, (t)->d_c32, __VA_ARGS__); \
+        }                                                                                                       \
+    } while (0)
+
+extern "C" {
+
+int sdf_eval_points(sdf_tape *t, const void *d_pts, int64_t n, int dim, void *d_out, int precision) {
+    if (!t || !d_pts || !d_out) return fail("sdf_eval_points: NULL argument");
+    if (dim != 2 && dim != 3) return fail("sdf_eval_points: dim must be 2 or 3");
+    if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_points: bad precision");
+    if (n <= 0) return 0;
+    HIPCHK(hipSetDevice(t->ctx->device));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    LAUNCH_TAPE(k_eval_points, dim3(grid), dim3(256), 0, t, precision, (const double *)d_pts, (long long)n, dim, (double *)d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int sdf_eval_points_host(sdf_tape *t, const double *h_pts, int64_t n, int dim, double *h_out, int precision) {
+    if (!t || !h_pts || !h_out) return fail("sdf_eval_points_host: NULL argument");
+    if (n <= 0) return 0;
+    sdf_ctx *c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->scratch_in.ensure((size_t)n * dim * 8) || c->scratch_out.ensure((size_t)n * 8)) return 1;
+    HIPCHK(hipMemcpyAsync(c->scratch_in.p, h_pts, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream));
+    if (sdf_eval_points(t, c->scratch_in.p, n, dim, c->scratch_out.p, precision)) return 1;
+    HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sdf_eval_grid_host(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
+                       double *h_out, int precision) {
+    if (!t || !X || !Y || !Z || !h_out) return fail("sdf_eval_grid_host: NULL argument");
+    if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_grid_host: bad precision");
+    if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+    sdf_ctx *c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)nx * ny * nz;
+    if (c->scratch_in.ensure((size_t)(nx + ny + nz) * 8) || c->scratch_out.ensure(n * 8)) return 1;
+    double *dX = (double *)c->scratch_in.p, *dY = dX + nx, *dZ = dY + ny;
+    HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    LAUNCH_TAPE(k_eval_grid, dim3(grid), dim3(256), 0, t, precision, (const double *)dX, (const double *)dY, (const double *)dZ,
+                nx, ny, nz, (double *)c->scratch_out.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sdf_marching_cubes(sdf_ctx *c, const void *d_volume, int n0, int n1, int n2, void *d_out, int64_t cap, int64_t *n_tris) {
+    if (!c || !n_tris) return fail("sdf_marching_cubes: NULL argument");
+    *n_tris = 0;
+    if (n0 < 2 || n1 < 2 || n2 < 2) return 0;   // skimage: "Input array must be at least 2x2x2" -> empty batch
+    if (!d_volume) return fail("sdf_marching_cubes: volume is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    const long long nrows = (long long)(n0 - 1) * (n1 - 1);
+    if (c->rows.ensure((size_t)nrows * 4) || c->rows_off.ensure((size_t)(nrows + 1) * 8)) return 1;
+    unsigned long long *d_total = (unsigned long long *)c->rows_off.p + nrows;
+    const unsigned grid = (unsigned)((nrows + 255) / 256);
+    hipLaunchKernelGGL(k_mc_rows, dim3(grid), dim3(256), 0, c->stream, (const float *)d_volume, n0, n1, n2, (unsigned *)c->rows.p);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)c->rows.p, nrows,
+                       (unsigned long long *)c->rows_off.p, d_total);
+    HIPCHK(hipGetLastError());
+    unsigned long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *n_tris = (int64_t)total;
+    if (total && d_out && cap > 0) {
+        hipLaunchKernelGGL(k_mc_emit, dim3(grid), dim3(256), 0, c->stream, (const float *)d_volume, n0, n1, n2,
+                           (const unsigned long long *)c->rows_off.p, (float *)d_out, (unsigned long long)cap);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int sdf_marching_cubes_host(sdf_ctx *c, const float *h_vol, int n0, int n1, int n2, float *h_out, int64_t cap, int64_t *n_tris) {
+    if (!c || !n_tris) return fail("sdf_marching_cubes_host: NULL argument");
+    *n_tris = 0;
+    if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
+    if (!h_vol) return fail("sdf_marching_cubes_host: volume is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)n0 * n1 * n2;
+    if (c->scratch_in.ensure(n * 4)) return 1;
+    if (cap > 0 && c->scratch_out.ensure((size_t)cap * 36)) return 1;
+    HIPCHK(hipMemcpyAsync(c->scratch_in.p, h_vol, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (sdf_marching_cubes(c, c->scratch_in.p, n0, n1, n2, cap > 0 ? c->scratch_out.p : nullptr, cap, n_tris)) return 1;
+    const int64_t ncopy = std::min<int64_t>(*n_tris, cap);
+    if (ncopy > 0 && h_out) {
+        HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)ncopy * 36, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+static size_t mesh_lds_bytes(int bs) { return 128 + 3 * 33 * 8 + (size_t)(bs + 1) * (bs + 1) * (bs + 1) * 4; }
+
+template <typename T, bool FULL>
+static int launch_mesh(sdf_tape *t, const T *consts, const MeshArgs &a, int grid, size_t lds) {
+    auto fn = k_mesh<T, FULL>;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(1024), lds, t->ctx->stream, (const uint32_t *)t->d_code, consts, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
+                         int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision) {
+    sdf_ctx *c = t->ctx;
+    GridDesc &g = m->g;
+    g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
+    g.nbx = (nx + bs - 1) / bs; g.nby = (ny + bs - 1) / bs; g.nbz = (nz + bs - 1) / bs;
+    const long long nb64 = (long long)g.nbx * g.nby * g.nbz;
+    if (nb64 > 0x7fffffffLL) return fail("sdf_generate: too many batches");
+    const int nb = (int)nb64;
+    m->st.n_batches = nb;
+    m->st.n_grid_voxels = (int64_t)nx * ny * nz;
+    if (nb == 0) return 0;
+
+    if (m->axes.ensure((size_t)(nx + ny + nz) * 8) || m->kinds.ensure((size_t)nb) || m->worklist.ensure((size_t)nb * 4) ||
+        c->counters.ensure(sizeof(MeshCounters)) || c->nwork.ensure(4))
+        return 1;
+    double *dX = (double *)m->axes.p, *dY = dX + nx, *dZ = dY + ny;
+    g.X = dX; g.Y = dY; g.Z = dZ;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, c->stream));
+
+    // ---- prepass: skip test for every batch, then the ordered work list ----
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    if (sparse) {
+        const unsigned grid = (unsigned)(((long long)nb * 16 + 255) / 256);
+        LAUNCH_TAPE(k_skip, dim3(grid), dim3(256), 0, t, precision, g, nb, (unsigned char *)m->kinds.p);
+    } else {
+        HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
+    }
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
+                       (int *)c->nwork.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    int nwork = 0;
+    HIPCHK(hipMemcpyAsync(&nwork, c->nwork.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    m->st.n_skipped = nb - nwork;
+    m->work_begin = (int)(((long long)nwork * shard_index) / shard_count);
+    m->work_end = (int)(((long long)nwork * (shard_index + 1)) / shard_count);
+    m->st.n_work_begin = m->work_begin; m->st.n_work_end = m->work_end;
+    const int nshard = m->work_end - m->work_begin;
+
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+    m->st.ms_prepass = ms;
+    if (nshard > 0) {
+        if (m->batch_count.ensure((size_t)nwork * 4) || m->batch_base.ensure((size_t)nwork * 8) ||
+            m->batch_final.ensure((size_t)nwork * 8))
+            return 1;
+        HIPCHK(hipMemsetAsync(m->batch_count.p, 0, (size_t)nwork * 4, c->stream));
+        // arena: start from the model's last observed density (or 4096 triangles per batch)
+        unsigned long long per = t->hint_tris_per_batch ? t->hint_tris_per_batch + t->hint_tris_per_batch / 4 + 64 : 4096ull;
+        unsigned long long cap = std::max<unsigned long long>(per * (unsigned long long)nshard, 1ull << 16);
+        const size_t lds = mesh_lds_bytes(bs);
+        if (lds > c->lds_max) return fail("sdf_generate: device LDS too small for this batch size");
+        for (int attempt = 0;; attempt++) {
+            if (!m->arena.p && !c->arena_pool.empty()) { m->arena = c->arena_pool.back(); c->arena_pool.pop_back(); }
+            if (m->arena.ensure((size_t)cap * 36)) return 1;
+            cap = m->arena.bytes / 36;
+            HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(MeshCounters), c->stream));
+            MeshArgs a;
+            a.g = g; a.worklist = (const int *)m->worklist.p; a.work_begin = m->work_begin; a.work_end = m->work_end;
+            a.kinds = (unsigned char *)m->kinds.p; a.batch_count = (unsigned *)m->batch_count.p;
+            a.batch_base = (unsigned long long *)m->batch_base.p; a.arena = (float *)m->arena.p; a.arena_cap = cap;
+            a.ctr = (MeshCounters *)c->counters.p;
+            const int grid = std::min(nshard, c->n_cu);
+            HIPCHK(hipEventRecord(c->ev[3], c->stream));
+            int rc;
+            if (precision == SDF_PRECISION_F64)
+                rc = t->full ? launch_mesh<double, true>(t, t->d_c64, a, grid, lds) : launch_mesh<double, false>(t, t->d_c64, a, grid, lds);
+            else
+                rc = t->full ? launch_mesh<float, true>(t, t->d_c32, a, grid, lds) : launch_mesh<float, false>(t, t->d_c32, a, grid, lds);
+            if (rc) return 1;
+            HIPCHK(hipEventRecord(c->ev[4], c->stream));
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)m->batch_count.p, m->work_begin,
+                               m->work_end, (unsigned long long *)m->batch_final.p, (MeshCounters *)c->counters.p);
+            HIPCHK(hipGetLastError());
+            MeshCounters h;
+            HIPCHK(hipMemcpyAsync(&h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+            m->st.ms_mesh = ms;
+            m->st.n_retries = attempt;
+            if (h.overflow) {
+                if (attempt >= 3) return fail("sdf_generate: triangle arena overflow persists");
+                cap = h.tri_counter + h.tri_counter / 8 + 1024;   // exact need is known now
+                continue;
+            }
+            m->st.n_triangles = (int64_t)h.total;
+            m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
+            m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
+            t->hint_tris_per_batch = (h.total + (unsigned long long)nshard - 1) / (unsigned long long)nshard;
+            break;
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(hipEventSynchronize(c->ev[5]));
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[5]));
+    m->st.ms_total = ms;
+    return 0;
+}
+
+extern "C" {
+
+int sdf_mesh_destroy(sdf_mesh *m);
+
+int sdf_generate(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
+                 int sparse, int64_t shard_index, int64_t shard_count, int precision, sdf_mesh **out) {
+    if (!t || !X || !Y || !Z || !out) return fail("sdf_generate: NULL argument");
+    *out = nullptr;
+    if (bs < 1 || bs > 32) return fail("sdf_generate: batch_size must be in 1..32 (the (batch_size+1)^3 float32 tile lives in LDS)");
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sdf_generate: bad shard");
+    if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_generate: bad precision");
+    if (nx < 0 || ny < 0 || nz < 0) return fail("sdf_generate: negative axis length");
+    sdf_ctx *c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    sdf_mesh *m = new sdf_mesh();
+    m->ctx = c;
+    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision)) {
+        const std::string keep = g_err;
+        sdf_mesh_destroy(m);
+        g_err = keep;
+        return 1;
+    }
+    *out = m;
+    return 0;
+}
+
+int sdf_mesh_stats(sdf_mesh *m, sdf_stats *out) {
+    if (!m || !out) return fail("sdf_mesh_stats: NULL argument");
+    *out = m->st;
+    return 0;
+}
+
+int64_t sdf_mesh_triangles(sdf_mesh *m) { return m ? m->st.n_triangles : 0; }
+
+int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
+    if (!m || !d_out) return fail("sdf_mesh_emit_device: NULL argument");
+    sdf_ctx *c = m->ctx;
+    if (m->st.n_triangles == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    const int nshard = m->work_end - m->work_begin;
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    hipLaunchKernelGGL(k_gather, dim3(nshard), dim3(256), 0, c->stream, m->g, (const int *)m->worklist.p, m->work_begin,
+                       (const unsigned *)m->batch_count.p, (const unsigned long long *)m->batch_base.p,
+                       (const unsigned long long *)m->batch_final.p, (const float *)m->arena.p, (double *)d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[4], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    m->st.ms_emit = ms;
+    return 0;
+}
+
+static int mesh_ensure_out(sdf_mesh *m) {
+    if (m->emitted) return 0;
+    if (m->out.ensure((size_t)m->st.n_triangles * 72)) return 1;
+    if (sdf_mesh_emit_device(m, m->out.p)) return 1;
+    m->emitted = true;
+    return 0;
+}
+
+int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) {
+    if (!m || !h_out) return fail("sdf_mesh_emit_host: NULL argument");
+    if (m->st.n_triangles == 0) return 0;
+    HIPCHK(hipSetDevice(m->ctx->device));
+    if (mesh_ensure_out(m)) return 1;
+    HIPCHK(hipMemcpyAsync(h_out, m->out.p, (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
+int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
+    if (!m || !h_out) return fail("sdf_mesh_emit_stl_host: NULL argument");
+    const long long nt = m->st.n_triangles;
+    if (nt == 0) return 0;
+    sdf_ctx *c = m->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (mesh_ensure_out(m)) return 1;
+    if (c->scratch_out.ensure((size_t)nt * 50)) return 1;
+    hipLaunchKernelGGL(k_stl, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, (const double *)m->out.p, nt,
+                       (unsigned short *)c->scratch_out.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)nt * 50, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sdf_mesh_kinds(sdf_mesh *m, uint8_t *h_out) {
+    if (!m || !h_out) return fail("sdf_mesh_kinds: NULL argument");
+    if (m->st.n_batches == 0) return 0;
+    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(hipMemcpyAsync(h_out, m->kinds.p, (size_t)m->st.n_batches, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    for (int64_t i = 0; i < m->st.n_batches; i++) if (h_out[i] == 255) h_out[i] = 3;
+    return 0;
+}
+
+int sdf_mesh_destroy(sdf_mesh *m) {
+    if (!m) return 0;
+    sdf_ctx *c = m->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (m->arena.p) {   // keep one arena around for the next call
+        if (c->arena_pool.empty()) c->arena_pool.push_back(m->arena);
+        else if (c->arena_pool.back().bytes < m->arena.bytes) { c->arena_pool.back().release(); c->arena_pool.back() = m->arena; }
+        else m->arena.release();
+        m->arena.p = nullptr;
+    }
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->batch_count, &m->batch_base, &m->batch_final, &m->out}) b->release();
+    delete m;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,484 @@
+// sdf_interp.h -- the CDNA4 op-tape interpreter: one lane evaluates one sample.
+//
+// Replaces the reference's recursive NumPy closure calls (reference sdf/d3.py:24-25 and every
+// `def f(p)` in sdf/d3.py, sdf/d2.py, sdf/dn.py, sdf/ease.py).  The tape (sdf_amd/tape.py) is
+// straight-line code that is identical for every lane, so all control flow here is
+// wave-uniform: instruction words and constants are fetched through the scalar cache
+// (s_load), the opcode switch is a scalar branch, and the slot numbers that index the
+// PS / DS register arrays are wave-uniform too.  Machine state per lane:
+//     (x, y, z)  current point         acc      current distance
+//     PS[s]      saved points          DS[s]    saved distances       (static slots)
+//
+// Arithmetic follows the reference's NumPy expression order operation by operation (no
+// contraction: the translation unit is built with -ffp-contract=off; fused multiply-adds appear
+// only where NumPy itself goes through BLAS, see dot3), so that in T = double the values agree
+// with the reference to the last bit for every correctly-rounded operation.  The formulas carry
+// the reference file:line they restate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "opcodes.h"
+
+namespace sdfk {
+
+#define SDF_DEV __device__ __forceinline__
+
+// ---- NumPy scalar semantics (np.minimum/np.maximum/np.clip propagate NaN) ----------------
+template <typename T> SDF_DEV T np_min(T a, T b) { return (a < b || a != a) ? a : b; }
+template <typename T> SDF_DEV T np_max(T a, T b) { return (a >= b || a != a) ? a : b; }
+template <typename T> SDF_DEV T np_clip(T x, T lo, T hi) {
+    T t = (x != x || x > lo) ? x : lo;
+    return (t != t || t < hi) ? t : hi;
+}
+template <typename T> SDF_DEV T np_sign(T x) { return x != x ? x : (x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0))); }
+
+SDF_DEV double m_sqrt(double x) { return __dsqrt_rn(x); }
+SDF_DEV float m_sqrt(float x) { return __fsqrt_rn(x); }
+SDF_DEV double m_fma(double a, double b, double c) { return __fma_rn(a, b, c); }
+SDF_DEV float m_fma(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+SDF_DEV double m_fabs(double x) { return fabs(x); }
+SDF_DEV float m_fabs(float x) { return fabsf(x); }
+SDF_DEV double m_rint(double x) { return rint(x); }
+SDF_DEV float m_rint(float x) { return rintf(x); }
+SDF_DEV double m_sin(double x) { return sin(x); }
+SDF_DEV float m_sin(float x) { return sinf(x); }
+SDF_DEV double m_cos(double x) { return cos(x); }
+SDF_DEV float m_cos(float x) { return cosf(x); }
+SDF_DEV double m_atan2(double y, double x) { return atan2(y, x); }
+SDF_DEV float m_atan2(float y, float x) { return atan2f(y, x); }
+SDF_DEV double m_hypot(double x, double y) { return hypot(x, y); }
+SDF_DEV float m_hypot(float x, float y) { return hypotf(x, y); }
+SDF_DEV double m_fmod(double x, double y) { return fmod(x, y); }
+SDF_DEV float m_fmod(float x, float y) { return fmodf(x, y); }
+SDF_DEV double m_pow2(double x) { return pow(2.0, x); }
+SDF_DEV float m_pow2(float x) { return powf(2.0f, x); }
+SDF_DEV double m_copysign(double x, double y) { return copysign(x, y); }
+SDF_DEV float m_copysign(float x, float y) { return copysignf(x, y); }
+
+// np.linalg.norm(axis=1): sqrt of the left-to-right sum of squares
+template <typename T> SDF_DEV T len2(T x, T y) { return m_sqrt(x * x + y * y); }
+template <typename T> SDF_DEV T len3(T x, T y, T z) { return m_sqrt((x * x + y * y) + z * z); }
+// np.dot((N,3),(3,)) / np.dot((N,3),(3,3)): BLAS kernels accumulate with fused multiply-adds
+template <typename T> SDF_DEV T dot3(T ax, T ay, T az, T bx, T by, T bz) { return m_fma(az, bz, m_fma(ay, by, ax * bx)); }
+template <typename T> SDF_DEV T dot2(T ax, T ay, T bx, T by) { return m_fma(ay, by, ax * bx); }
+// Python / NumPy floored modulo (npy_divmod)
+template <typename T> SDF_DEV T np_mod(T a, T b) {
+    T m = m_fmod(a, b);
+    if (b == T(0)) return m;
+    if (m != T(0)) { if ((b < T(0)) != (m < T(0))) m += b; }
+    else m = m_copysign(T(0), b);
+    return m;
+}
+
+// ---- easing curves: reference sdf/ease.py:3-162 ------------------------------------------
+template <typename T> SDF_DEV T out_bounce(T t) {
+    if (t < T(4.0 / 11)) return (T(121) * t * t) / T(16);
+    if (t < T(8.0 / 11)) return (T(363.0 / 40) * t * t) - (T(99.0 / 10) * t) + T(17.0 / 5);
+    if (t < T(9.0 / 10)) return (T(4356.0 / 361) * t * t) - (T(35442.0 / 1805) * t) + T(16061.0 / 1805);
+    return (T(54.0 / 5) * t * t) - (T(513.0 / 25) * t) + T(268.0 / 25);
+}
+
+template <typename T, bool FULL> SDF_DEV T ease_apply(int id, T t) {
+    const T pi = T(3.141592653589793);
+    T u, v, a, b;
+    switch (id) {   // id is wave-uniform
+    case EASE_linear: return t;
+    case EASE_in_quad: return t * t;
+    case EASE_out_quad: return -t * (t - T(2));
+    case EASE_in_out_quad:
+        u = T(2) * t - T(1); a = T(2) * t * t; b = T(-0.5) * (u * (u - T(2)) - T(1));
+        return t < T(0.5) ? a : b;
+    case EASE_in_cubic: return t * t * t;
+    case EASE_out_cubic: u = t - T(1); return u * u * u + T(1);
+    case EASE_in_out_cubic:
+        u = t * T(2); v = u - T(2);
+        return u < T(1) ? T(0.5) * u * u * u : T(0.5) * (v * v * v + T(2));
+    case EASE_in_quart: return t * t * t * t;
+    case EASE_out_quart: u = t - T(1); return -(u * u * u * u - T(1));
+    case EASE_in_out_quart:
+        u = t * T(2); v = u - T(2);
+        return u < T(1) ? T(0.5) * u * u * u * u : T(-0.5) * (v * v * v * v - T(2));
+    case EASE_in_quint: return t * t * t * t * t;
+    case EASE_out_quint: u = t - T(1); return u * u * u * u * u + T(1);
+    case EASE_in_out_quint:
+        u = t * T(2); v = u - T(2);
+        return u < T(1) ? T(0.5) * u * u * u * u * u : T(0.5) * (v * v * v * v * v + T(2));
+    case EASE_in_circ: return T(-1) * (m_sqrt(T(1) - t * t) - T(1));
+    case EASE_out_circ: u = t - T(1); return m_sqrt(T(1) - u * u);
+    case EASE_in_out_circ:
+        u = t * T(2); v = u - T(2);
+        return u < T(1) ? T(-0.5) * (m_sqrt(T(1) - u * u) - T(1)) : T(0.5) * (m_sqrt(T(1) - v * v) + T(1));
+    case EASE_in_back: { const T k = T(1.70158); return t * t * ((k + T(1)) * t - k); }
+    case EASE_out_back: { const T k = T(1.70158); u = t - T(1); return u * u * ((k + T(1)) * u + k) + T(1); }
+    case EASE_in_out_back: {
+        const T k = T(1.70158 * 1.525); u = t * T(2); v = u - T(2);
+        return u < T(1) ? T(0.5) * (u * u * ((k + T(1)) * u - k)) : T(0.5) * (v * v * ((k + T(1)) * v + k) + T(2)); }
+    case EASE_in_bounce: return T(1) - out_bounce(T(1) - t);
+    case EASE_out_bounce: return out_bounce(t);
+    case EASE_in_out_bounce:
+        return t < T(0.5) ? (T(1) - out_bounce(T(1) - T(2) * t)) * T(0.5) : out_bounce(T(2) * t - T(1)) * T(0.5) + T(0.5);
+    case EASE_in_square: return t < T(1) ? T(0) : T(1);
+    case EASE_out_square: return t > T(0) ? T(1) : T(0);
+    case EASE_in_out_square: return t < T(0.5) ? T(0) : T(1);
+    default: break;
+    }
+    if constexpr (FULL) {   // curves that need sin / cos / 2**x
+        switch (id) {
+        case EASE_in_sine: return -m_cos(t * pi / T(2)) + T(1);
+        case EASE_out_sine: return m_sin(t * pi / T(2));
+        case EASE_in_out_sine: return T(-0.5) * (m_cos(pi * t) - T(1));
+        case EASE_in_expo: return t == T(0) ? T(0) : m_pow2(T(10) * (t - T(1)));
+        case EASE_out_expo: return t == T(1) ? T(1) : T(1) - m_pow2(T(-10) * t);
+        case EASE_in_out_expo:
+            if (t == T(0)) return T(0);
+            if (t == T(1)) return T(1);
+            return t < T(0.5) ? T(0.5) * m_pow2(T(20) * t - T(10)) : T(1) - T(0.5) * m_pow2(T(-20) * t + T(10));
+        case EASE_in_elastic: {
+            const T k = T(0.5); u = t - T(1);
+            return T(-1) * (m_pow2(T(10) * u) * m_sin((u - k / T(4)) * (T(2) * pi) / k)); }
+        case EASE_out_elastic: {
+            const T k = T(0.5);
+            return m_pow2(T(-10) * t) * m_sin((t - k / T(4)) * (T(2) * pi / k)) + T(1); }
+        case EASE_in_out_elastic: {
+            const T k = T(0.5); u = t * T(2); v = u - T(1);
+            a = T(-0.5) * (m_pow2(T(10) * v) * m_sin((v - k / T(4)) * T(2) * pi / k));
+            b = m_pow2(T(-10) * v) * m_sin((v - k / T(4)) * T(2) * pi / k) * T(0.5) + T(1);
+            return u < T(1) ? a : b; }
+        default: break;
+        }
+    }
+    return t - t + __builtin_nan("");   // unknown id
+}
+
+// ---- boolean folds: reference sdf/dn.py:7-58 ----------------------------------------------
+template <typename T> SDF_DEV T post_combine(uint32_t post, T d1, T d2, T K) {
+    T h, m;
+    switch (post) {   // wave-uniform
+    case POST_SET: return d2;
+    case POST_UNION: return np_min(d1, d2);
+    case POST_DIFF: return np_max(d1, -d2);
+    case POST_INTER: return np_max(d1, d2);
+    case POST_SUNION:
+        h = np_clip(T(0.5) + T(0.5) * (d2 - d1) / K, T(0), T(1));
+        m = d2 + (d1 - d2) * h;
+        return m - K * h * (T(1) - h);
+    case POST_SDIFF:
+        h = np_clip(T(0.5) - T(0.5) * (d2 + d1) / K, T(0), T(1));
+        m = d1 + (-d2 - d1) * h;
+        return m + K * h * (T(1) - h);
+    case POST_SINTER:
+        h = np_clip(T(0.5) - T(0.5) * (d2 - d1) / K, T(0), T(1));
+        m = d2 + (d1 - d2) * h;
+        return m + K * h * (T(1) - h);
+    case POST_BLEND: return K * d2 + (T(1) - K) * d1;
+    }
+    return d2;
+}
+
+template <typename T> SDF_DEV T box_like(T qx, T qy, T qz) {
+    // _length(_max(q, 0)) + _min(np.amax(q, axis=1), 0)
+    T mx = np_max(np_max(qx, qy), qz);
+    return len3(np_max(qx, T(0)), np_max(qy, T(0)), np_max(qz, T(0))) + np_min(mx, T(0));
+}
+
+// Run the whole tape for one sample.  FULL=false builds leave out the ops that need
+// sin/cos/atan2/hypot/fmod/pow (their ocml bodies cost registers); the host picks the variant
+// from the opcodes present in the tape.
+template <typename T, bool FULL>
+__device__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ consts, T x, T y, T z) {
+    T acc = T(0);
+    T PSx[SDF_NP_SLOTS], PSy[SDF_NP_SLOTS], PSz[SDF_NP_SLOTS];
+    T DS[SDF_ND_SLOTS];
+#pragma unroll
+    for (int i = 0; i < SDF_NP_SLOTS; i++) { PSx[i] = PSy[i] = PSz[i] = T(0); }
+#pragma unroll
+    for (int i = 0; i < SDF_ND_SLOTS; i++) DS[i] = T(0);
+
+    for (uint32_t pc = 0;; pc += 2) {
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(code[pc]);
+        const uint32_t coff = __builtin_amdgcn_readfirstlane(code[pc + 1]);
+        const T *c = consts + coff + 1;          // c[-1] is K
+        const uint32_t op = w0 & 255u, post = (w0 >> 8) & 255u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
+        T v = T(0), d1 = acc;
+        bool produces = true;
+        switch (op) {
+        case OP_END: return acc;
+        // ---------------- 3-D leaves ----------------
+        case OP_L_SPHERE:   // d3.py:92-96
+            v = len3(x - c[1], y - c[2], z - c[3]) - c[0]; break;
+        case OP_L_PLANE:    // d3.py:98-103
+            v = dot3(c[3] - x, c[4] - y, c[5] - z, c[0], c[1], c[2]); break;
+        case OP_L_BOX:      // d3.py:122-134
+            v = box_like(m_fabs(x - c[0]) - c[3], m_fabs(y - c[1]) - c[4], m_fabs(z - c[2]) - c[5]); break;
+        case OP_L_ROUNDED_BOX:  // d3.py:136-142
+            v = box_like(m_fabs(x) - c[0] + c[3], m_fabs(y) - c[1] + c[3], m_fabs(z) - c[2] + c[3]) - c[3]; break;
+        case OP_L_WIREFRAME_BOX: {  // d3.py:144-155
+            const T t2 = c[3];
+            const T px = m_fabs(x) - c[0] - t2, py = m_fabs(y) - c[1] - t2, pz = m_fabs(z) - c[2] - t2;
+            const T qx = m_fabs(px + t2) - t2, qy = m_fabs(py + t2) - t2, qz = m_fabs(pz + t2) - t2;
+            auto g = [](T a, T b, T cc) {
+                return len3(np_max(a, T(0)), np_max(b, T(0)), np_max(cc, T(0))) + np_min(np_max(a, np_max(b, cc)), T(0));
+            };
+            v = np_min(np_min(g(px, qy, qz), g(qx, py, qz)), g(qx, qy, pz)); break; }
+        case OP_L_TORUS: {  // d3.py:157-165
+            const T a = len2(x, y) - c[0];
+            v = len2(a, z) - c[1]; break; }
+        case OP_L_CAPSULE: {  // d3.py:167-176
+            const T pax = x - c[0], pay = y - c[1], paz = z - c[2];
+            const T h = np_clip(dot3(pax, pay, paz, c[3], c[4], c[5]) / c[6], T(0), T(1));
+            v = len3(pax - c[3] * h, pay - c[4] * h, paz - c[5] * h) - c[7]; break; }
+        case OP_L_CYLINDER:  // d3.py:178-182
+            v = len2(x, y) - c[0]; break;
+        case OP_L_CAPPED_CYLINDER: {  // d3.py:184-204
+            const T bax = c[3], bay = c[4], baz = c[5], baba = c[6];
+            const T pax = x - c[0], pay = y - c[1], paz = z - c[2];
+            const T paba = dot3(pax, pay, paz, bax, bay, baz);
+            const T xx = len3(pax * baba - bax * paba, pay * baba - bay * paba, paz * baba - baz * paba) - c[8];
+            const T yy = m_fabs(paba - c[9]) - c[9];
+            const T x2 = xx * xx, y2 = yy * yy * baba;
+            T d;
+            if (np_max(xx, yy) < T(0)) d = -np_min(x2, y2);
+            else d = (xx > T(0) ? x2 : T(0)) + (yy > T(0) ? y2 : T(0));
+            v = np_sign(d) * m_sqrt(m_fabs(d)) / baba; break; }
+        case OP_L_ROUNDED_CYLINDER: {  // d3.py:206-215
+            const T d0 = len2(x, y) - c[0] + c[1];
+            const T dd1 = m_fabs(z) - c[2] + c[1];
+            v = np_min(np_max(d0, dd1), T(0)) + len2(np_max(d0, T(0)), np_max(dd1, T(0))) - c[1]; break; }
+        case OP_L_CAPPED_CONE: {  // d3.py:217-237
+            const T ra = c[6], rb = c[7], baba = c[8], rba = c[9], k = c[10];
+            const T pax = x - c[0], pay = y - c[1], paz = z - c[2];
+            const T papa = (pax * pax + pay * pay) + paz * paz;
+            const T paba = dot3(pax, pay, paz, c[3], c[4], c[5]) / baba;
+            const T xx = m_sqrt(papa - paba * paba * baba);
+            const T cax = np_max(T(0), xx - (paba < T(0.5) ? ra : rb));
+            const T cay = m_fabs(paba - T(0.5)) - T(0.5);
+            const T f = np_clip((rba * (xx - ra) + paba * baba) / k, T(0), T(1));
+            const T cbx = xx - ra - f * rba;
+            const T cby = paba - f;
+            const T s = (cbx < T(0) && cay < T(0)) ? T(-1) : T(1);
+            v = s * m_sqrt(np_min(cax * cax + cay * cay * baba, cbx * cbx + cby * cby * baba)); break; }
+        case OP_L_ROUNDED_CONE: {  // d3.py:239-250
+            const T r1 = c[0], r2 = c[1], h = c[2], b = c[3], a = c[4], ah = c[5];
+            const T qx = len2(x, y), qy = z;
+            const T k = dot2(qx, qy, -b, a);
+            const T c1 = len2(qx, qy) - r1;
+            const T c2 = len2(qx - T(0), qy - h) - r2;
+            const T c3 = dot2(qx, qy, a, b) - r1;
+            v = k < T(0) ? c1 : (k > ah ? c2 : c3); break; }
+        case OP_L_ELLIPSOID: {  // d3.py:252-259
+            const T k0 = len3(x / c[0], y / c[1], z / c[2]);
+            const T k1 = len3(x / c[3], y / c[4], z / c[5]);
+            v = k0 * (k0 - T(1)) / k1; break; }
+        case OP_L_PYRAMID: {  // d3.py:261-282
+            const T h = c[0], m2 = c[1], m2q = c[2];
+            T a0 = m_fabs(x) - T(0.5), a1 = m_fabs(y) - T(0.5);
+            if (a1 > a0) { const T tmp = a0; a0 = a1; a1 = tmp; }
+            const T px = a0, py = z, pz = a1;
+            const T qx = pz, qy = h * py - T(0.5) * px, qz = h * px + T(0.5) * py;
+            const T s = np_max(-qx, T(0));
+            const T tt = np_clip((qy - T(0.5) * pz) / m2q, T(0), T(1));
+            const T a = m2 * ((qx + s) * (qx + s)) + qy * qy;
+            const T b = m2 * ((qx + T(0.5) * tt) * (qx + T(0.5) * tt)) + (qy - m2 * tt) * (qy - m2 * tt);
+            const T dd2 = np_min(qy, -qx * m2 - qy * T(0.5)) > T(0) ? T(0) : np_min(a, b);
+            v = m_sqrt((dd2 + qz * qz) / m2) * np_sign(np_max(qz, -py)); break; }
+        case OP_L_TETRAHEDRON:  // d3.py:286-293
+            v = (np_max(m_fabs(x + y) - z, m_fabs(x - y) + z) - c[0]) / c[1]; break;
+        case OP_L_OCTAHEDRON:   // d3.py:295-299
+            v = (((m_fabs(x) + m_fabs(y)) + m_fabs(z)) - c[0]) * c[1]; break;
+        case OP_L_DODECAHEDRON: {  // d3.py:301-311
+            const T r = c[0], X = c[1], Y = c[2], Z = c[3];
+            const T ax = m_fabs(x / r), ay = m_fabs(y / r), az = m_fabs(z / r);
+            const T a = dot3(ax, ay, az, X, Y, Z), b = dot3(ax, ay, az, Z, X, Y), cc = dot3(ax, ay, az, Y, Z, X);
+            v = (np_max(np_max(a, b), cc) - X) * r; break; }
+        case OP_L_ICOSAHEDRON: {  // d3.py:313-325
+            const T r = c[0], X = c[1], Y = c[2], Z = c[3], w = c[4];
+            const T ax = m_fabs(x / r), ay = m_fabs(y / r), az = m_fabs(z / r);
+            const T a = dot3(ax, ay, az, X, Y, Z), b = dot3(ax, ay, az, Z, X, Y), cc = dot3(ax, ay, az, Y, Z, X);
+            const T d = dot3(ax, ay, az, w, w, w) - X;
+            v = np_max(np_max(np_max(a, b), cc) - X, d) * r; break; }
+        // ---------------- 2-D leaves: the point is (x, y) ----------------
+        case OP_L_CIRCLE:  // d2.py:76-80
+            v = len2(x - c[1], y - c[2]) - c[0]; break;
+        case OP_L_LINE:    // d2.py:82-87
+            v = dot2(c[2] - x, c[3] - y, c[0], c[1]); break;
+        case OP_L_RECTANGLE: {  // d2.py:102-114
+            const T qx = m_fabs(x - c[0]) - c[2], qy = m_fabs(y - c[1]) - c[3];
+            v = len2(np_max(qx, T(0)), np_max(qy, T(0))) + np_min(np_max(qx, qy), T(0)); break; }
+        case OP_L_ROUNDED_RECTANGLE: {  // d2.py:116-134
+            T r = T(0);
+            if (x > T(0) && y > T(0)) r = c[2];
+            if (x > T(0) && y <= T(0)) r = c[3];
+            if (x <= T(0) && y <= T(0)) r = c[4];
+            if (x <= T(0) && y > T(0)) r = c[5];
+            const T qx = m_fabs(x) - c[0] + r, qy = m_fabs(y) - c[1] + r;
+            v = np_min(np_max(qx, qy), T(0)) + len2(np_max(qx, T(0)), np_max(qy, T(0))) - r; break; }
+        case OP_L_EQUILATERAL_TRIANGLE: {  // d2.py:136-152
+            const T k = c[0];
+            T px = m_fabs(x) - T(1), py = y + c[1];
+            if (px + k * py > T(0)) {
+                const T nx = (px - k * py) / T(2), ny = (-k * px - py) / T(2);
+                px = nx; py = ny;
+            }
+            px = px - np_clip(px, T(-2), T(0));
+            v = -len2(px, py) * np_sign(py); break; }
+        case OP_L_HEXAGON: {  // d2.py:154-165
+            const T r = c[0], k0 = c[1], k1 = c[2];
+            T px = m_fabs(x), py = m_fabs(y);
+            const T m = np_min(k0 * px + k1 * py, T(0));
+            px -= c[4] * m; py -= c[5] * m;
+            px -= np_clip(px, c[6], c[7]); py -= (T(0) + r);
+            v = len2(px, py) * np_sign(py); break; }
+        case OP_L_ROUNDED_X: {  // d2.py:167-173
+            const T px = m_fabs(x), py = m_fabs(y);
+            const T qq = np_min(px + py, c[0]) * T(0.5);
+            v = len2(px - qq, py - qq) - c[1]; break; }
+        case OP_L_POLYGON: {  // d2.py:175-196
+            const int np_ = (int)c[0];
+            const T *pv = c + 1;
+            const T dx = x - pv[0], dy = y - pv[1];
+            T d = dx * dx + dy * dy;
+            T s = T(1);
+            for (int i = 0; i < np_; i++) {
+                const int j = (i + np_ - 1) % np_;
+                const T vix = pv[2 * i], viy = pv[2 * i + 1], vjx = pv[2 * j], vjy = pv[2 * j + 1];
+                const T ex = vjx - vix, ey = vjy - viy;
+                const T wx = x - vix, wy = y - viy;
+                const T ee = dot2(ex, ey, ex, ey);
+                const T cl = np_clip(dot2(wx, wy, ex, ey) / ee, T(0), T(1));
+                const T bx = wx - ex * cl, by = wy - ey * cl;
+                d = np_min(d, bx * bx + by * by);
+                const bool c1 = y >= viy, c2 = y < vjy, c3 = ex * wy > ey * wx;
+                if ((c1 && c2 && c3) || (!c1 && !c2 && !c3)) s = -s;
+            }
+            v = s * m_sqrt(d); break; }
+        case OP_L_VESICA: {  // d2.py:198-207
+            const T r = c[0], d = c[1], b = c[2];
+            const T px = m_fabs(x), py = m_fabs(y);
+            v = ((py - b) * d > px * b) ? len2(px - T(0), py - b) : len2(px - (-d), py - T(0)) - r; break; }
+        // ---------------- fold a parked distance ----------------
+        case OP_COMB: v = acc; d1 = DS[sa]; break;
+        default: produces = false; break;
+        }
+        if (produces) { acc = post_combine(post, d1, v, c[-1]); continue; }
+
+        switch (op) {
+        // ---------------- point ops ----------------
+        case OP_TRANSLATE:  // d3.py:329-333
+            x = x - c[0]; y = y - c[1]; z = z - c[2]; break;
+        case OP_SCALE:      // d3.py:335-345
+            x = x / c[0]; y = y / c[1]; z = z / c[2]; break;
+        case OP_ROTATE: {   // d3.py:347-360: p @ M, M row-major
+            const T nx = dot3(x, y, z, c[0], c[3], c[6]);
+            const T ny = dot3(x, y, z, c[1], c[4], c[7]);
+            const T nz = dot3(x, y, z, c[2], c[5], c[8]);
+            x = nx; y = ny; z = nz; break; }
+        case OP_ELONGATE: {  // d3.py:396-405
+            const T qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1], qz = m_fabs(z) - c[2];
+            DS[sa] = np_min(np_max(qx, np_max(qy, qz)), T(0));
+            x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); break; }
+        case OP_BEND_LINEAR: {  // d3.py:435-445
+            T tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
+            tt = ease_apply<T, FULL>((int)c[10], tt);
+            x = x + tt * c[7]; y = y + tt * c[8]; z = z + tt * c[9]; break; }
+        case OP_REP_PREP: {  // dn.py:80-112: cell index of p
+            const int dim = (int)c[0];
+            T idx[3] = {T(0), T(0), T(0)};
+            const T pp[3] = {x, y, z};
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                if (i < dim) {
+                    const T s = c[1 + i];
+                    const T qq = s != T(0) ? pp[i] / s : T(0);
+                    T r = m_rint(qq);
+                    if (c[4] != T(0)) r = np_clip(r, -c[5 + i], c[5 + i]);
+                    idx[i] = r;
+                }
+            }
+            PSx[sa] = idx[0]; PSy[sa] = idx[1]; PSz[sa] = idx[2]; break; }
+        case OP_REP_SET:   // p = p0 - spacing * (index + n)
+            x = PSx[sa] - c[0] * (PSx[sb] + c[3]);
+            y = PSy[sa] - c[1] * (PSy[sb] + c[4]);
+            z = PSz[sa] - c[2] * (PSz[sb] + c[5]); break;
+        case OP_TRANSLATE2: x = x - c[0]; y = y - c[1]; break;   // d2.py:211-215
+        case OP_SCALE2: x = x / c[0]; y = y / c[1]; break;       // d2.py:217-227
+        case OP_ROTATE2: {  // d2.py:229-240
+            const T nx = dot2(x, y, c[0], c[2]), ny = dot2(x, y, c[1], c[3]);
+            x = nx; y = ny; break; }
+        case OP_ELONGATE2: {  // d2.py:249-257
+            const T qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1];
+            DS[sa] = np_min(np_max(qx, qy), T(0));
+            x = np_max(qx, T(0)); y = np_max(qy, T(0)); break; }
+        case OP_REVOLVE: {  // d2.py:280-286
+            const T nx = len2(x, y) - c[0];
+            y = z; x = nx; z = T(0); break; }
+        case OP_SETZ0: z = T(0); break;                           // d3.py:513
+        case OP_SAVE_P: PSx[sa] = x; PSy[sa] = y; PSz[sa] = z; break;
+        case OP_LOAD_P: x = PSx[sa]; y = PSy[sa]; z = PSz[sa]; break;
+        // ---------------- distance ops ----------------
+        case OP_PUSH_D: DS[sa] = acc; break;
+        case OP_NEG: acc = -acc; break;                            // dn.py:60-63
+        case OP_ADDC: acc = acc + c[0]; break;                     // dn.py:70-73
+        case OP_SUBC: acc = acc - c[0]; break;                     // dn.py:65-68
+        case OP_MULC: acc = acc * c[0]; break;                     // d3.py:344
+        case OP_SHELL: acc = m_fabs(acc) - c[0]; break;            // dn.py:75-78
+        case OP_ADD_DS: acc = acc + DS[sa]; break;                 // d3.py:405
+        case OP_TRANS_LIN_PRE: {  // d3.py:459-470
+            const T tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
+            DS[sa] = ease_apply<T, FULL>((int)c[7], tt); break; }
+        case OP_TRANS_MIX: {  // t * d2 + (1 - t) * d1
+            const T tt = DS[sa];
+            acc = tt * acc + (T(1) - tt) * DS[sb]; break; }
+        case OP_EXT_PRE: DS[sa] = m_fabs(z) - c[0]; break;         // d2.py:264-266
+        case OP_EXT_POST: {  // d2.py:267
+            const T w1 = DS[sa];
+            acc = np_min(np_max(acc, w1), T(0)) + len2(np_max(acc, T(0)), np_max(w1, T(0))); break; }
+        case OP_EXTTO_PRE:   // d2.py:274
+            DS[sa] = ease_apply<T, FULL>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5)); break;
+        case OP_EXTTO_MIX: {  // d2.py:275
+            const T dd1 = DS[sb];
+            acc = dd1 + (acc - dd1) * DS[sa]; break; }
+        case OP_SLICE_POST: {  // d3.py:515-519
+            const T A = DS[sa], B = -acc;
+            acc = A <= T(0) ? B : A; break; }
+        default:
+            if constexpr (FULL) {
+                switch (op) {
+                case OP_TWIST: {  // d3.py:407-419
+                    const T cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
+                    const T nx = cc * x - s * y, ny = s * x + cc * y;
+                    x = nx; y = ny; break; }
+                case OP_BEND: {   // d3.py:421-433
+                    const T cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
+                    const T nx = cc * x - s * y, ny = s * x + cc * y;
+                    x = nx; y = ny; break; }
+                case OP_BEND_RADIAL: {  // d3.py:447-457
+                    const T r = m_hypot(x, y);
+                    const T tt = np_clip((r - c[0]) / c[1], T(0), T(1));
+                    z = z - c[2] * ease_apply<T, FULL>((int)c[3], tt); break; }
+                case OP_WRAP_AROUND: {  // d3.py:483-502
+                    const T pi = T(3.141592653589793);
+                    const T d = m_hypot(x, y) - c[9];
+                    const T a = m_atan2(y, x);
+                    const T tt = ease_apply<T, FULL>((int)c[10], (a + pi) / (T(2) * pi));
+                    x = c[0] + c[3] * tt + c[6] * d;
+                    y = c[1] + c[4] * tt + c[7] * d; break; }
+                case OP_CIRC_PREP: {  // d3.py:379-392: PS[sa] = (d, a, z)
+                    PSx[sa] = m_hypot(x, y);
+                    PSy[sa] = np_mod(m_atan2(y, x), c[0]);
+                    PSz[sa] = z; break; }
+                case OP_CIRC_SET: {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
+                    const T ang = PSy[sa] - c[0], d = PSx[sa];
+                    x = m_cos(ang) * d; y = m_sin(ang) * d; z = PSz[sa]; break; }
+                case OP_TRANS_RAD_PRE: {  // d3.py:472-481
+                    const T r = m_hypot(x, y);
+                    DS[sa] = ease_apply<T, FULL>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1))); break; }
+                default: break;
+                }
+            }
+            break;
+        }
+    }
+}
+
+}  // namespace sdfk

@@ -1,0 +1,259 @@
+"""Parity tests proper: the HIP path (through the C ABI, sdf_amd/engine.py) against the CPU
+oracle on the same inputs and against the committed reference goldens.  All need an MI355X."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import fixtures
+from conftest import GOLDEN, value_tolerance
+from sdf_amd import core
+
+pytestmark = pytest.mark.gpu
+
+# models whose tape contains libm-dependent operations (sin/cos/atan2/hypot/fmod/pow): the device
+# libm (ocml) and glibc agree to ~1 ulp, not bitwise
+TRIG = {'ex_gearlike', 'ex_weave', 'ex_knurling', 'circular_array', 'twist', 'bend', 'bend_radial',
+        'transition_radial', 'wrap_around', 'ease_in_sine', 'ease_out_sine', 'ease_in_out_sine',
+        'ease_in_expo', 'ease_out_expo', 'ease_in_out_expo', 'ease_in_elastic', 'ease_out_elastic',
+        'ease_in_out_elastic'}
+
+
+def test_native_library_is_loaded(eng):
+    from sdf_amd import engine
+    assert os.path.exists(engine.LIB_PATH)
+    maps = open('/proc/self/maps').read()
+    assert 'libsdf_hip.so' in maps
+
+
+@pytest.mark.parametrize('name', sorted(fixtures.FIXTURES))
+def test_values_match_oracle_and_reference(name, ns, golden_values, oracle_lib, eng):
+    P = golden_values['P']
+    f = fixtures.build(name, ns)
+    v = eng.eval_points(f, P)
+    o = oracle_lib.evaluate(f, P)
+    ref = golden_values['v_' + name]
+    assert np.array_equal(np.isnan(v), np.isnan(o))
+    if name in TRIG:
+        ok = ~np.isnan(o)
+        assert np.all(np.abs(v[ok] - o[ok]) <= value_tolerance(o[ok], P[ok]))
+    else:
+        assert np.array_equal(v, o, equal_nan=True)       # bit-exact vs the oracle
+    ok = ~np.isnan(ref)
+    assert np.all(np.abs(v[ok] - ref[ok]) <= value_tolerance(ref[ok], P[ok]))   # vs the reference
+
+
+def test_call_operator_is_drop_in(ns, golden_values):
+    """SDF3.__call__ returns (N,1) float64 like reference sdf/d3.py:24-25"""
+    P = golden_values['P']
+    f = fixtures.build('ex_example', ns)
+    out = f(P)
+    assert out.shape == (len(P), 1) and out.dtype == np.float64
+    assert np.array_equal(out.reshape(-1), golden_values['v_ex_example'])
+    c = ns['circle'](1.2, (0.3, -0.1))
+    out2 = c(P[:, :2].copy())
+    assert out2.shape == (len(P), 1)
+
+
+def test_float32_mode_is_close(ns, golden_values, eng):
+    from sdf_amd import engine
+    P = golden_values['P'][:500]
+    f = fixtures.build('ex_example', ns)
+    eng.precision = engine.PRECISION_F32
+    try:
+        v = eng.eval_points(f, P)
+    finally:
+        eng.precision = engine.PRECISION_F64
+    ref = golden_values['v_ex_example'][:500]
+    assert np.all(np.abs(v - ref) <= 1e-5 * np.maximum(1.0, np.abs(P).max(axis=1)))
+
+
+MC = np.load(os.path.join(GOLDEN, 'mc_volumes.npz'))
+MC_NAMES = sorted(k[4:] for k in MC.files if k.startswith('vol_'))
+
+
+@pytest.mark.parametrize('name', MC_NAMES)
+def test_marching_cubes_matches_oracle(name, oracle_lib, eng):
+    vol = MC['vol_' + name]
+    got = eng.marching_cubes(vol)
+    want, namb = oracle_lib.marching_cubes(vol)
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))      # bit-exact, same order
+    if namb == 0:
+        ref = MC['soup_' + name]                                          # and equal to skimage
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_marching_cubes_random_volumes(oracle_lib, eng):
+    rng = np.random.RandomState(5)
+    for shape in [(2, 2, 2), (3, 7, 5), (17, 4, 9), (40, 33, 21), (64, 64, 64)]:
+        vol = rng.standard_normal(shape) + rng.uniform(-1, 1)
+        got = eng.marching_cubes(vol)
+        want, _ = oracle_lib.marching_cubes(vol)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+GEN = sorted(glob.glob(os.path.join(GOLDEN, 'gen_*.npz')))
+
+
+@pytest.mark.parametrize('path', GEN, ids=[os.path.basename(p)[4:-4] for p in GEN])
+def test_generate_matches_oracle_and_reference(path, ns, oracle_lib, eng):
+    d = np.load(path)
+    name = str(d['fixture'])
+    kw = eval(str(d['kwargs']))
+    f = fixtures.build(name, ns)
+    bounds = tuple(map(tuple, d['bounds']))
+    X, Y, Z, _ = core.grid_axes(bounds, d['step'].tolist())
+    bs, sparse = kw.get('batch_size', 32), kw.get('sparse', True)
+    mesh = eng.generate(f, X, Y, Z, bs, sparse)
+    pts, kinds, st = mesh.points(), mesh.kinds(), mesh.stats()
+    mesh.close()
+    o = oracle_lib.generate(f, X, Y, Z, bs, sparse)
+    assert np.array_equal(kinds, d['kinds'])                    # reference classification
+    assert np.array_equal(kinds, o.kinds)
+    assert (st['skipped'], st['empty'], st['nonempty']) == tuple(int((o.kinds == k).sum()) for k in (0, 1, 2))
+    assert st['n_eval_voxels'] == o.n_eval
+    if name in TRIG:
+        assert pts.shape == o.points.shape
+        extent = np.ptp(np.array(bounds), axis=0).max()
+        assert np.abs(pts - o.points).max() <= 1e-5 * extent     # north-star tolerance
+        assert (pts == o.points).mean() > 0.999
+    else:
+        assert np.array_equal(pts, o.points)                    # bit-exact, reference order
+        if o.n_ambiguous == 0:
+            assert hashlib.sha256(pts.tobytes()).digest() == d['sha256'].tobytes()   # == reference
+
+
+def test_generate_drop_in_api_and_stl(ns, tmp_path, capsys):
+    """f.generate()/f.save() keep the reference signatures, prints and STL bytes"""
+    f = fixtures.build('ex_example', ns)
+    d = np.load(os.path.join(GOLDEN, 'gen_example_s15.npz'))
+    pts = f.generate(samples=2 ** 15, workers=3, batch_size=32, verbose=True, sparse=True)
+    out = capsys.readouterr().out
+    assert 'min -0.84543' in out and 'batches with 3 workers' in out and 'triangles in' in out
+    assert '0 skipped, 0 empty, 1 nonempty' in out
+    assert isinstance(pts, np.ndarray) and pts.shape == d['points'].shape
+    assert np.array_equal(pts, d['points'])                      # bounds estimated on the device too
+    p = str(tmp_path / 'out.stl')
+    f.save(p, samples=2 ** 15, verbose=False)
+    ref = np.load(os.path.join(GOLDEN, 'stl_example_s15.npz'))['stl'].tobytes()
+    assert open(p, 'rb').read() == ref
+
+
+def test_device_stl_records_match_host_writer(ns, eng):
+    f = fixtures.build('ex_example', ns)
+    d = np.load(os.path.join(GOLDEN, 'gen_example_s17.npz'))
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
+    mesh = eng.generate(f, X, Y, Z)
+    rec = mesh.stl_records()
+    from sdf_amd import stl
+    assert rec.tobytes() == stl.stl_records(mesh.points()).tobytes()
+    mesh.close()
+
+
+def test_bounds_estimated_on_device_match_reference(ns):
+    b = np.load(os.path.join(GOLDEN, 'bounds.npz'))
+    for name in ('ex_example', 'ex_blobby', 'ex_pawn', 'torus', 'box2', 'capsule', 'smooth_union', 'slice',
+                 'extrude_to', 'ex_gearlike', 'ex_weave'):
+        got = np.array(core._estimate_bounds(fixtures.build(name, ns)))
+        if name in TRIG:
+            assert np.allclose(got, b[name], rtol=0, atol=1e-9), name
+        else:
+            assert np.array_equal(got, b[name]), name
+
+
+def test_sample_slice(ns, oracle_lib):
+    f = fixtures.build('ex_example', ns)
+    a, extent, axes = core.sample_slice(f, w=64, h=48, z=0.1, bounds=((-1, -1, -1), (1, 1, 1)))
+    assert a.shape == (64, 48) and axes == 'YX'
+    Xs, Ys = np.linspace(-1, 1, 64), np.linspace(-1, 1, 48)
+    P = np.array([(x, y, 0.1) for x in Xs for y in Ys])
+    assert np.array_equal(a.reshape(-1), oracle_lib.evaluate(f, P))
+    with pytest.raises(Exception):
+        core.sample_slice(f, bounds=((-1, -1, -1), (1, 1, 1)))
+
+
+def test_sharded_generate_concatenates_to_single(ns, eng):
+    """the multi-GPU split (contiguous chunks of the surviving work list) reproduces the
+    single-GPU soup when the shards are concatenated in rank order"""
+    f = fixtures.build('ex_example', ns)
+    d = np.load(os.path.join(GOLDEN, 'gen_example_s22.npz'))
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
+    whole = eng.generate(f, X, Y, Z)
+    ref = whole.points()
+    assert hashlib.sha256(ref.tobytes()).digest() == d['sha256'].tobytes()    # BASELINE config 1
+    for world in (2, 3, 8):
+        parts, ne, nn = [], 0, 0
+        for r in range(world):
+            m = eng.generate(f, X, Y, Z, shard=(r, world))
+            parts.append(m.points())
+            st = m.stats(); ne += st['empty']; nn += st['nonempty']
+            k = m.kinds()
+            assert set(np.unique(k)) <= {0, 1, 2, 3}
+            m.close()
+        assert np.array_equal(np.concatenate(parts), ref)
+        assert (ne, nn) == (whole.stats()['empty'], whole.stats()['nonempty'])
+    whole.close()
+
+
+def test_edge_cases(ns, eng, oracle_lib):
+    f = fixtures.build('ex_example', ns)
+    # ragged grids: single-sample trailing slices, non-cubic, tiny
+    for shape_step in [((-0.85, -0.85, -0.85), (0.85, 0.85, 0.85), (0.0531, 0.0531, 0.0531)),   # 33 samples: 2 batches/axis, last has 1 sample
+                       ((-0.9, -0.4, -0.2), (0.9, 0.5, 0.3), (0.013, 0.05, 0.11)),
+                       ((0.0, 0.0, 0.0), (0.05, 0.05, 0.05), (0.1, 0.1, 0.1)),                   # one sample per axis
+                       ((2.0, 2.0, 2.0), (3.0, 3.0, 3.0), (0.1, 0.1, 0.1))]:                     # nothing there
+        lo, hi, step = shape_step
+        X, Y, Z, _ = core.grid_axes((lo, hi), step)
+        for sparse in (True, False):
+            for bs in (32, 7):
+                m = eng.generate(f, X, Y, Z, bs, sparse)
+                o = oracle_lib.generate(f, X, Y, Z, bs, sparse)
+                assert np.array_equal(m.kinds(), o.kinds)
+                assert np.array_equal(m.points(), o.points)
+                m.close()
+    # empty axes
+    m = eng.generate(f, np.zeros(0), np.arange(3.0), np.arange(3.0))
+    assert m.n_triangles == 0 and m.points().shape == (0, 3)
+    # bad arguments fail loudly
+    from sdf_amd import engine
+    with pytest.raises(engine.SdfHipError):
+        eng.generate(f, np.arange(4.0), np.arange(4.0), np.arange(4.0), batch_size=64)
+
+
+@pytest.mark.timeout(900)
+def test_full_size_config2_properties(ns, eng):
+    """BASELINE config 2 (example at 512^3): classification and triangle counts equal the
+    reference's measured run, the soup is a closed 2-manifold (every undirected
+    edge is used by exactly two triangles, with opposite directions), has no degenerate
+    triangle, and is identical across two runs and across precisions' triangle counts"""
+    f = fixtures.build('ex_example', ns)
+    b = np.load(os.path.join(GOLDEN, 'bounds.npz'))['ex_example']
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, b)), samples=2 ** 27)
+    assert (len(X), len(Y), len(Z)) == (512, 512, 512)
+    m = eng.generate(f, X, Y, Z)
+    st = m.stats()
+    assert (st['batches'], st['skipped'], st['empty'], st['nonempty']) == (4096, 2352, 120, 1624)
+    assert st['triangles'] == 2945152
+    pts = m.points()
+    m.close()
+    m2 = eng.generate(f, X, Y, Z)
+    assert np.array_equal(m2.points(), pts)                      # deterministic, order included
+    m2.close()
+    tri = pts.reshape(-1, 3, 3)
+    e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    area2 = np.linalg.norm(np.cross(e1, e2), axis=1)
+    assert area2.min() > 0
+    verts, inv = np.unique(pts, axis=0, return_inverse=True)
+    inv = inv.reshape(-1, 3)
+    a = np.concatenate([inv[:, 0], inv[:, 1], inv[:, 2]])
+    c = np.concatenate([inv[:, 1], inv[:, 2], inv[:, 0]])
+    directed = a.astype(np.int64) * len(verts) + c
+    opposite = c.astype(np.int64) * len(verts) + a
+    assert len(np.unique(directed)) == len(directed)             # no directed edge twice
+    assert np.array_equal(np.sort(directed), np.sort(opposite))  # each edge has its opposite
+    # Euler characteristic of a closed orientable surface is even (genus-5 solid here: 2 - 2*5)
+    V, E, F = len(verts), len(directed) // 2, len(tri)
+    assert V - E + F == 2 - 2 * 5

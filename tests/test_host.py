@@ -1,0 +1,157 @@
+"""Host-side logic that needs no GPU: the drop-in API surface, tape lowering, header sync,
+the C ABI symbol table and the STL writer."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import fixtures
+from conftest import ROOT, GOLDEN
+
+
+def test_public_names_cover_reference_surface(ns):
+    # the names `from sdf import *` gives in the reference (reference sdf/__init__.py:1-27;
+    # SURVEY.md section 8b), minus imported helper modules
+    expected = '''
+    ORIGIN X Y Z UP pi degrees radians d2 d3 ease
+    SDF2 SDF3 sdf2 sdf3 op2 op3 op23 op32
+    sphere plane slab box rounded_box wireframe_box torus capsule cylinder capped_cylinder
+    rounded_cylinder capped_cone rounded_cone ellipsoid pyramid tetrahedron octahedron
+    dodecahedron icosahedron
+    translate scale rotate rotate_to orient circular_array elongate twist bend bend_linear
+    bend_radial transition_linear transition_radial wrap_around slice
+    union difference intersection blend negate dilate erode shell repeat
+    circle line rectangle rounded_rectangle equilateral_triangle hexagon rounded_x polygon vesica
+    extrude extrude_to revolve
+    Mesh measure_image measure_text image text
+    generate save sample_slice show_slice write_binary_stl
+    '''.split()
+    missing = [n for n in expected if n not in ns]
+    assert not missing, missing
+
+
+def test_alias_package_is_drop_in():
+    import sdf
+    import sdf_amd
+    assert sdf.sphere is sdf_amd.sphere and sdf.d3 is sdf_amd.d3 and sdf.ease is sdf_amd.ease
+    assert sdf.X.tolist() == [1, 0, 0] and sdf.UP is sdf.Z      # d3 names shadow d2's
+
+
+def test_k_quirks(ns):
+    """reference quirks listed in SURVEY.md A.3"""
+    cyl, Xv, Zv = ns['cylinder'], ns['X'], ns['Z']
+    c = cyl(0.5)
+    assert c.k(0.1) is c and c._k == 0.1                         # .k() mutates and returns self
+    assert cyl(.5).k(.1).orient(Zv)._k == 0.1                    # parallel -> child itself, _k visible
+    assert getattr(cyl(.5).k(.1).orient(Xv), '_k', None) is None
+    assert getattr(ns['circle'](1), '_k', None) is None          # SDF2 has no fall-through
+
+
+def test_smoothing_constant_is_resolved_at_evaluation_time(ns):
+    from sdf_amd import tape
+    a, b = ns['sphere'](1), ns['box'](1.5)
+    f = a | b
+    assert 'SUNION' not in tape.lower(f).disassemble()
+    b.k(0.25)                                                    # after building the union
+    assert 'SUNION' in tape.lower(f).disassemble()
+
+
+@pytest.mark.parametrize('name', sorted(fixtures.FIXTURES))
+def test_every_fixture_lowers(name, ns):
+    from sdf_amd import tape
+    t = tape.lower(fixtures.build(name, ns))
+    assert t.n_instr >= 2 and t.code.dtype == np.uint32 and t.consts.dtype == np.float64
+    assert (t.code[-2] & 255) == tape.OP['END']
+    assert t.n_pslots <= tape.MAX_P_SLOTS and t.n_dslots <= tape.MAX_D_SLOTS
+
+
+def test_opaque_closure_is_rejected(ns):
+    from sdf_amd import tape, ir
+
+    @ns['sdf3']
+    def custom():
+        def f(p):
+            return np.linalg.norm(p, axis=1) - 1
+        return f
+    with pytest.raises(ir.OpaqueSDFError):
+        tape.lower(custom() | ns['sphere'](1))
+
+
+def test_generated_headers_are_in_sync():
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import gen_headers
+    for rel, text in gen_headers.render().items():
+        assert open(os.path.join(ROOT, rel)).read() == text, rel + ' is stale: run tools/gen_headers.py'
+    a = open(os.path.join(ROOT, 'oracle', 'mc_table.h')).read()
+    b = open(os.path.join(ROOT, 'sdf_amd', 'csrc', 'mc_table.h')).read()
+    assert a == b
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libsdf_hip.so loads without a GPU and exports exactly what include/sdf_hip.h declares"""
+    from sdf_amd import engine
+    hdr = open(os.path.join(ROOT, 'include', 'sdf_hip.h')).read()
+    declared = set(re.findall(r'\b(sdf_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(engine.ABI), declared ^ set(engine.ABI)
+    lib = engine.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sdf_abi_version() == engine.ABI_VERSION
+    # struct layout of sdf_stats: 11 int64 + 4 double
+    assert ctypes.sizeof(engine.SdfStats) == 15 * 8
+
+
+def test_no_cpu_fallback_without_device(ns):
+    """on a box without a GPU every compute entry point raises instead of silently
+    computing on the host"""
+    from sdf_amd import engine
+    lib = engine.load_library()
+    if lib.sdf_device_count() > 0:
+        pytest.skip('a GPU is visible here')
+    with pytest.raises(engine.SdfHipError):
+        ns['sphere'](1)(np.zeros((1, 3)))
+    with pytest.raises(engine.SdfHipError):
+        ns['sphere'](1).generate(samples=2 ** 12, verbose=False)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'sdf_amd')):
+        for fn in files:
+            if fn.endswith(('.py', '.h', '.hip', '.cpp')):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle\b', src, re.M), fn
+                assert 'libsdf_oracle' not in src, fn
+
+
+def test_stl_writer_bytes_match_reference(tmp_path):
+    from sdf_amd import stl
+    pts = np.load(os.path.join(GOLDEN, 'gen_example_s15.npz'))['points']
+    ref = np.load(os.path.join(GOLDEN, 'stl_example_s15.npz'))['stl'].tobytes()
+    p = str(tmp_path / 'a.stl')
+    stl.write_binary_stl(p, pts)
+    assert open(p, 'rb').read() == ref
+    stl.write_binary_stl(p, list(pts))           # the reference passes a list of points
+    assert open(p, 'rb').read() == ref
+
+
+def test_grid_axes_follow_reference_rule():
+    from sdf_amd import core
+    b = ((-0.845430, -0.845430, -0.845430), (0.845431, 0.845431, 0.845431))
+    X, Y, Z, (dx, dy, dz) = core.grid_axes(b, samples=2 ** 22)
+    assert len(X) == len(Y) == len(Z) == 162 and dx == dy == dz      # BASELINE config 1: 162^3
+    X, Y, Z, _ = core.grid_axes(b, step=(0.1, 0.2, 0.4))
+    assert (len(X), len(Y), len(Z)) == (17, 9, 5)
+
+
+def test_shard_bounds_partition_the_work_list():
+    from sdf_amd import dist
+    for n in (0, 1, 7, 1744, 33856):
+        for world in (1, 2, 3, 8):
+            cuts = [dist.shard_bounds(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1

@@ -1,0 +1,92 @@
+"""The CPU checker (oracle/) against the golden vectors produced by RUNNING the unmodified
+reference (tools/make_golden.py).  This is what pins the oracle; everything else compares
+the HIP path with the oracle."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import fixtures
+from conftest import GOLDEN, value_tolerance
+from sdf_amd import core
+
+
+@pytest.mark.parametrize('name', sorted(fixtures.FIXTURES))
+def test_values_match_reference(name, ns, golden_values, oracle_lib):
+    P = golden_values['P']
+    ref = golden_values['v_' + name]
+    f = fixtures.build(name, ns)
+    v = oracle_lib.evaluate(f, P)
+    assert np.array_equal(np.isnan(v), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.all(np.abs(v[ok] - ref[ok]) <= value_tolerance(ref[ok], P[ok]))
+
+
+def test_values_bit_exact_where_numpy_is_deterministic(ns, golden_values, oracle_lib):
+    """fixtures that use only correctly-rounded elementwise NumPy ops must agree bit for bit"""
+    P = golden_values['P']
+    for name in ('ex_example', 'ex_blobby', 'ex_pawn', 'sphere', 'box2', 'rounded_box', 'wireframe_box',
+                 'torus', 'capsule', 'capped_cylinder', 'rounded_cylinder', 'capped_cone', 'ellipsoid',
+                 'pyramid', 'tetrahedron', 'smooth_union', 'smooth_difference', 'smooth_intersection',
+                 'blend_k', 'elongate', 'rotate', 'orient', 'scale', 'slab_k', 'rectangle',
+                 'rounded_rectangle', 'equilateral_triangle', 'rounded_x', 'vesica', 'slice', 'extrude_to',
+                 'ease_in_out_quad', 'ease_out_bounce', 'ease_in_out_back', 'ease_in_out_circ'):
+        v = oracle_lib.evaluate(fixtures.build(name, ns), P)
+        ref = golden_values['v_' + name]
+        assert np.array_equal(v, ref, equal_nan=True), name
+
+
+def test_bounds_match_reference(ns, oracle_lib):
+    b = np.load(os.path.join(GOLDEN, 'bounds.npz'))
+    for name in b.files:
+        got = np.array(oracle_lib.estimate_bounds(fixtures.build(name, ns)))
+        assert np.array_equal(got, b[name]), name
+
+
+MC = np.load(os.path.join(GOLDEN, 'mc_volumes.npz'))
+MC_NAMES = sorted(k[4:] for k in MC.files if k.startswith('vol_'))
+
+
+@pytest.mark.parametrize('name', MC_NAMES)
+def test_marching_cubes_matches_skimage(name, oracle_lib):
+    soup, namb = oracle_lib.marching_cubes(MC['vol_' + name])
+    ref = MC['soup_' + name]
+    if namb == 0:
+        # no ambiguous cell: bit-identical soup, same order
+        assert soup.shape == ref.shape
+        assert np.array_equal(soup.view(np.uint32), ref.view(np.uint32))
+    else:
+        # ambiguous cells: skimage's Lewiner tiling may differ (documented limit); our vertex
+        # set is still a subset of skimage's (it only adds centre vertices in some tilings)
+        mine = {tuple(r) for r in soup.view(np.uint32).reshape(-1, 3).tolist()}
+        theirs = {tuple(r) for r in ref.view(np.uint32).reshape(-1, 3).tolist()}
+        assert mine <= theirs
+
+
+GEN = sorted(glob.glob(os.path.join(GOLDEN, 'gen_*.npz')))
+
+
+@pytest.mark.parametrize('path', GEN, ids=[os.path.basename(p)[4:-4] for p in GEN])
+def test_generate_matches_reference(path, ns, oracle_lib):
+    d = np.load(path)
+    kw = eval(str(d['kwargs']))
+    f = fixtures.build(str(d['fixture']), ns)
+    bounds = tuple(map(tuple, d['bounds']))
+    X, Y, Z, _ = core.grid_axes(bounds, d['step'].tolist())
+    r = oracle_lib.generate(f, X, Y, Z, kw.get('batch_size', 32), kw.get('sparse', True))
+    assert np.array_equal(r.kinds, d['kinds'])          # skipped / empty / nonempty per batch
+    if r.n_ambiguous == 0:
+        assert len(r.points) // 3 == int(d['ntri'])
+        assert hashlib.sha256(r.points.tobytes()).digest() == d['sha256'].tobytes()
+        if 'points' in d.files:
+            assert np.array_equal(r.points, d['points'])
+    else:
+        # Lewiner may tile ambiguous cells differently (documented limit): the
+        # triangle count may differ there, but every vertex we emit is one skimage emits too
+        assert abs(len(r.points) // 3 - int(d['ntri'])) <= 4 * r.n_ambiguous
+        if 'points' in d.files:
+            mine = {tuple(v) for v in r.points.tolist()}
+            theirs = {tuple(v) for v in d['points'].tolist()}
+            assert mine <= theirs
