@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the sampling + meshing hot path.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): the canonical CSG example (reference examples/example.py:
+sphere & box - 3 cylinders) on the 512^3 grid the reference builds for samples=2**27 over its own
+estimated bounds, sparse=True, batch_size=32.  One "step" = one complete pass of the hot path:
+skip prepass -> work list -> fused sample+march kernel -> ordered gather to the float64 (3T,3)
+soup in HBM (and, for N>1, the RCCL all-gather of the rank soups).  The axes are the only input
+(3 x 512 float64); the output stays in HBM inside the timed region (the PCIe-inclusive rate is
+reported separately as `value_incl_d2h`).  float64 sampling = the reference's NumPy precision.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (k_mesh),
+`cpu_baseline` = the CPU oracle (a C port of the reference path) timed on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# bounds the reference's _estimate_bounds returns for the example (tests/golden/bounds.npz)
+EXAMPLE_BOUNDS = ((-0.8454303741455078, -0.8454303741455078, -0.8454303741455078),
+                  (0.8454312324523926, 0.8454312324523926, 0.8454312324523926))
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def build_model(name):
+    import sdf_amd as s
+    if name == 'example':
+        f = s.sphere(1) & s.box(1.5)
+        c = s.cylinder(0.5)
+        f -= c.orient(s.X) | c.orient(s.Y) | c.orient(s.Z)
+        return f, None
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import fixtures
+    ns = {k: getattr(s, k) for k in dir(s) if not k.startswith('_')}
+    return fixtures.build('ex_' + name, ns), None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--model', default='example', help='example | gearlike | blobby | weave | knurling')
+    ap.add_argument('--samples-log2', type=int, default=27, help='grid = samples=2**k through the reference step rule')
+    ap.add_argument('--precision', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-check', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    td = None
+    if world > 1:
+        import torch.distributed as td
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    from sdf_amd import core, engine, dist
+    eng = engine.get_engine(local_rank)
+    eng.precision = engine.PRECISION_F64 if args.precision == 'f64' else engine.PRECISION_F32
+    f, _ = build_model(args.model)
+    tape = eng.tape_for(f)
+    if args.model == 'example':
+        bounds = EXAMPLE_BOUNDS
+    else:
+        bounds = core._estimate_bounds(f)
+    X, Y, Z, step = core.grid_axes(bounds, samples=2 ** args.samples_log2)
+    grid_voxels = len(X) * len(Y) * len(Z)
+    dev = torch.device('cuda', local_rank)
+
+    state = {}
+
+    def one_step():
+        if world == 1:
+            mesh = eng.generate(tape, X, Y, Z, 32, True)
+            t = mesh.n_triangles
+            buf = state.get('buf')
+            if buf is None or buf.numel() < t * 9:
+                buf = state['buf'] = torch.empty(max(t, 1) * 9, dtype=torch.float64, device=dev)
+            if t:
+                mesh.emit_device(buf.data_ptr())
+            state['stats'] = mesh.stats()
+            state['tris'] = t
+            mesh.close()
+        else:
+            soup, st = dist.generate_sharded_device(eng, tape, X, Y, Z, 32, True, device=dev)
+            state['buf'] = soup
+            state['stats'] = st
+            state['tris'] = st['triangles']
+
+    def sync():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if td is not None:
+            td.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    mesh_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+        mesh_ms.append(state['stats']['ms_mesh'])
+    sync()
+    dt = time.perf_counter() - t0
+    if td is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    st = state['stats']
+    tris = int(state['tris'])
+    ms_per_step = 1e3 * dt / args.steps
+    value = grid_voxels * args.steps / dt
+
+    # PCIe-inclusive variant (single GPU): same step + D2H of the soup into pageable host memory
+    incl = None
+    if world == 1:
+        sync()
+        t1 = time.perf_counter()
+        n_incl = max(1, min(args.steps, 5))
+        for _ in range(n_incl):
+            mesh = eng.generate(tape, X, Y, Z, 32, True)
+            pts = mesh.points()
+            mesh.close()
+        incl = grid_voxels * n_incl / (time.perf_counter() - t1)
+
+    # parity spot check inside the bench run: identical soup from two passes + reference counts
+    check = None
+    if world == 1 and not args.no_check and args.model == 'example' and args.samples_log2 == 27:
+        check = bool((st['batches'], st['skipped'], st['empty'], st['nonempty'], tris) ==
+                     (4096, 2352, 120, 1624, 2945152))
+
+    if rank != 0:
+        if td is not None:
+            td.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (k_mesh), from HIP events on the library's stream ----
+    k_ms = float(np.mean(mesh_ms))
+    shard_tris = int(st.get('n_triangles', tris)) if world == 1 else int(max(st.get('per_rank_triangles', [tris])))
+    alg_bytes = 36.0 * shard_tris                     # fused design: 36 B per emitted triangle
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    plain, special = tape.tape.flop_estimate()
+    eval_vox = int(st['n_eval_voxels']) if world == 1 else int(st['n_eval_voxels'] // world)
+    traffic = None
+    prof = os.path.join(ROOT, 'profiles', 'r01_pmc_k_mesh.json')
+    if os.path.exists(prof) and args.model == 'example' and args.samples_log2 == 27 and world == 1:
+        try:
+            traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    roofline = {
+        'kernel': 'k_mesh<%s>' % ('double' if args.precision == 'f64' else 'float'),
+        'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
+        'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': round(k_ms, 4),
+        'note': 'path is VALU/latency bound by construction (SURVEY 8d): see valu',
+        'valu': {'eval_voxels_per_launch': eval_vox, 'flops_per_voxel_est': plain + special,
+                 'achieved_tflops_est': round((plain + special) * eval_vox / (k_ms * 1e-3) / 1e12, 3) if k_ms > 0 else 0,
+                 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS if args.precision == 'f64' else 157.3},
+    }
+
+    # ---- CPU baseline: the C oracle (port of the reference path), one core, same workload ----
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle
+        nb = st['batches']
+        # bounded sample: ~10-30 s of single-core work
+        frac = 1.0 if (args.model == 'example' and args.samples_log2 <= 27) else 0.1
+        b1 = max(1, int(nb * frac))
+        t2 = time.perf_counter()
+        r = oracle.generate(f, X, Y, Z, 32, True, batch_range=(0, b1))
+        cdt = time.perf_counter() - t2
+        cpu = {'value': round(grid_voxels * (b1 / nb) / cdt, 1), 'unit': 'voxels/s', 'cores': 1, 'kind': 'port',
+               'sample': 'oracle/sdf_oracle.c generate() on batches [0,%d) of %d of the same %dx%dx%d grid, '
+                         '%.1f s on one host core of %d; triangles %d' % (b1, nb, len(X), len(Y), len(Z), cdt,
+                                                                         os.cpu_count(), len(r.points) // 3),
+               'triangles_per_sec': round(len(r.points) // 3 / cdt, 1)}
+
+    out = {
+        'metric': 'grid voxels/sec (sampled + meshed), canonical CSG example',
+        'value': round(value, 1), 'unit': 'voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': '%s @ samples=2**%d -> %dx%dx%d grid, sparse=True, batch_size=32'
+                               % (args.model, args.samples_log2, len(X), len(Y), len(Z)),
+                   'batches': int(st['batches']), 'skipped': int(st['skipped']), 'empty': int(st['empty']),
+                   'nonempty': int(st['nonempty']), 'triangles': tris,
+                   'parallelism': 'work-list shards x%d + RCCL all-gather' % world if world > 1 else 'single GPU'},
+        'triangles_per_sec': round(tris * args.steps / dt, 1),
+        'eval_voxels_per_sec': round(int(st['n_eval_voxels']) * args.steps / dt, 1),
+        'value_incl_d2h': round(incl, 1) if incl else None,
+        'device_ms': {'prepass': round(st['ms_prepass'], 4), 'mesh': round(k_ms, 4), 'emit': round(st.get('ms_emit', 0.0), 4)},
+        'parity_check': check,
+        'roofline': roofline,
+        'cpu_baseline': cpu,
+    }
+    print(json.dumps(out))
+    if td is not None:
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
     const bool all_same = ((m >> (base + 1)) & 0xFFull) == 0xFFull;
     if (b < nbatches && l == 0) {
         const double r = fabs((double)vc);
-        const double d = __dsqrt_rn(((cx - x0) * (cx - x0) + (cy - y0) * (cy - y0)) + (cz - z0) * (cz - z0));
+        const double d = sqrt(((cx - x0) * (cx - x0) + (cy - y0) * (cy - y0)) + (cz - z0) * (cz - z0));
         const bool skip = !(r <= d) && all_same;
         kinds[b] = skip ? 0 : 255;
     }
@@ -396,12 +396,14 @@ __global__ __launch_bounds__(256) void k_stl(const double *__restrict__ pts, lon
     for (int i = 0; i < 9; i++) p[i] = (float)pts[t * 9 + i];
     const float ax = p[3] - p[0], ay = p[4] - p[1], az = p[5] - p[2];
     const float bx = p[6] - p[0], by = p[7] - p[1], bz = p[8] - p[2];
-    // np.cross in float32: separate products and one subtraction each
-    float nx = __fsub_rn(__fmul_rn(ay, bz), __fmul_rn(az, by));
-    float ny = __fsub_rn(__fmul_rn(az, bx), __fmul_rn(ax, bz));
-    float nz = __fsub_rn(__fmul_rn(ax, by), __fmul_rn(ay, bx));
-    const float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)));
-    nx = __fdiv_rn(nx, len); ny = __fdiv_rn(ny, len); nz = __fdiv_rn(nz, len);
+    // np.cross / np.linalg.norm in float32: separate, individually rounded products, sums and the
+    // quotient (the translation unit is built with -ffp-contract=off; sqrtf and '/' are the
+    // correctly rounded forms, the __f*_rn intrinsics map to native approximations here)
+    float nx = ay * bz - az * by;
+    float ny = az * bx - ax * bz;
+    float nz = ax * by - ay * bx;
+    const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+    nx = nx / len; ny = ny / len; nz = nz / len;
     float rec[12] = {nx, ny, nz, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
     unsigned short *o = out + t * 25;
 #pragma unroll

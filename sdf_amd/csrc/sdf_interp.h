@@ -33,10 +33,12 @@ template <typename T> SDF_DEV T np_clip(T x, T lo, T hi) {
 }
 template <typename T> SDF_DEV T np_sign(T x) { return x != x ? x : (x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0))); }
 
-SDF_DEV double m_sqrt(double x) { return __dsqrt_rn(x); }
-SDF_DEV float m_sqrt(float x) { return __fsqrt_rn(x); }
-SDF_DEV double m_fma(double a, double b, double c) { return __fma_rn(a, b, c); }
-SDF_DEV float m_fma(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+// sqrt() / sqrtf() are the correctly rounded ocml forms (the __*sqrt_rn intrinsics may map to the
+// native approximation)
+SDF_DEV double m_sqrt(double x) { return sqrt(x); }
+SDF_DEV float m_sqrt(float x) { return sqrtf(x); }
+SDF_DEV double m_fma(double a, double b, double c) { return fma(a, b, c); }
+SDF_DEV float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
 SDF_DEV double m_fabs(double x) { return fabs(x); }
 SDF_DEV float m_fabs(float x) { return fabsf(x); }
 SDF_DEV double m_rint(double x) { return rint(x); }
@@ -176,6 +178,27 @@ template <typename T> SDF_DEV T post_combine(uint32_t post, T d1, T d2, T K) {
     return d2;
 }
 
+// A small per-lane register file addressed by a WAVE-UNIFORM slot number.  A plain array indexed
+// by a run-time value would be placed in scratch memory by the compiler; the explicit switch keeps
+// the eight values in VGPRs and costs one scalar branch per access.
+template <typename T> struct RegFile8 {
+    T r0, r1, r2, r3, r4, r5, r6, r7;
+    SDF_DEV void clear() { r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = T(0); }
+    SDF_DEV T get(uint32_t s) const {
+        switch (s) {
+        case 0: return r0; case 1: return r1; case 2: return r2; case 3: return r3;
+        case 4: return r4; case 5: return r5; case 6: return r6; default: return r7;
+        }
+    }
+    SDF_DEV void set(uint32_t s, T v) {
+        switch (s) {
+        case 0: r0 = v; break; case 1: r1 = v; break; case 2: r2 = v; break; case 3: r3 = v; break;
+        case 4: r4 = v; break; case 5: r5 = v; break; case 6: r6 = v; break; default: r7 = v; break;
+        }
+    }
+};
+static_assert(SDF_NP_SLOTS == 8 && SDF_ND_SLOTS == 8, "RegFile8 holds eight slots");
+
 template <typename T> SDF_DEV T box_like(T qx, T qy, T qz) {
     // _length(_max(q, 0)) + _min(np.amax(q, axis=1), 0)
     T mx = np_max(np_max(qx, qy), qz);
@@ -186,14 +209,10 @@ template <typename T> SDF_DEV T box_like(T qx, T qy, T qz) {
 // sin/cos/atan2/hypot/fmod/pow (their ocml bodies cost registers); the host picks the variant
 // from the opcodes present in the tape.
 template <typename T, bool FULL>
-__device__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ consts, T x, T y, T z) {
+__device__ __forceinline__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ consts, T x, T y, T z) {
     T acc = T(0);
-    T PSx[SDF_NP_SLOTS], PSy[SDF_NP_SLOTS], PSz[SDF_NP_SLOTS];
-    T DS[SDF_ND_SLOTS];
-#pragma unroll
-    for (int i = 0; i < SDF_NP_SLOTS; i++) { PSx[i] = PSy[i] = PSz[i] = T(0); }
-#pragma unroll
-    for (int i = 0; i < SDF_ND_SLOTS; i++) DS[i] = T(0);
+    RegFile8<T> PSx, PSy, PSz, DS;
+    PSx.clear(); PSy.clear(); PSz.clear(); DS.clear();
 
     for (uint32_t pc = 0;; pc += 2) {
         const uint32_t w0 = __builtin_amdgcn_readfirstlane(code[pc]);
@@ -357,7 +376,7 @@ __device__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ c
             const T px = m_fabs(x), py = m_fabs(y);
             v = ((py - b) * d > px * b) ? len2(px - T(0), py - b) : len2(px - (-d), py - T(0)) - r; break; }
         // ---------------- fold a parked distance ----------------
-        case OP_COMB: v = acc; d1 = DS[sa]; break;
+        case OP_COMB: v = acc; d1 = DS.get(sa); break;
         default: produces = false; break;
         }
         if (produces) { acc = post_combine(post, d1, v, c[-1]); continue; }
@@ -375,7 +394,7 @@ __device__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ c
             x = nx; y = ny; z = nz; break; }
         case OP_ELONGATE: {  // d3.py:396-405
             const T qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1], qz = m_fabs(z) - c[2];
-            DS[sa] = np_min(np_max(qx, np_max(qy, qz)), T(0));
+            DS.set(sa, np_min(np_max(qx, np_max(qy, qz)), T(0)));
             x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); break; }
         case OP_BEND_LINEAR: {  // d3.py:435-445
             T tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
@@ -395,11 +414,11 @@ __device__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ c
                     idx[i] = r;
                 }
             }
-            PSx[sa] = idx[0]; PSy[sa] = idx[1]; PSz[sa] = idx[2]; break; }
+            PSx.set(sa, idx[0]); PSy.set(sa, idx[1]); PSz.set(sa, idx[2]); break; }
         case OP_REP_SET:   // p = p0 - spacing * (index + n)
-            x = PSx[sa] - c[0] * (PSx[sb] + c[3]);
-            y = PSy[sa] - c[1] * (PSy[sb] + c[4]);
-            z = PSz[sa] - c[2] * (PSz[sb] + c[5]); break;
+            x = PSx.get(sa) - c[0] * (PSx.get(sb) + c[3]);
+            y = PSy.get(sa) - c[1] * (PSy.get(sb) + c[4]);
+            z = PSz.get(sa) - c[2] * (PSz.get(sb) + c[5]); break;
         case OP_TRANSLATE2: x = x - c[0]; y = y - c[1]; break;   // d2.py:211-215
         case OP_SCALE2: x = x / c[0]; y = y / c[1]; break;       // d2.py:217-227
         case OP_ROTATE2: {  // d2.py:229-240
@@ -407,39 +426,39 @@ __device__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ c
             x = nx; y = ny; break; }
         case OP_ELONGATE2: {  // d2.py:249-257
             const T qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1];
-            DS[sa] = np_min(np_max(qx, qy), T(0));
+            DS.set(sa, np_min(np_max(qx, qy), T(0)));
             x = np_max(qx, T(0)); y = np_max(qy, T(0)); break; }
         case OP_REVOLVE: {  // d2.py:280-286
             const T nx = len2(x, y) - c[0];
             y = z; x = nx; z = T(0); break; }
         case OP_SETZ0: z = T(0); break;                           // d3.py:513
-        case OP_SAVE_P: PSx[sa] = x; PSy[sa] = y; PSz[sa] = z; break;
-        case OP_LOAD_P: x = PSx[sa]; y = PSy[sa]; z = PSz[sa]; break;
+        case OP_SAVE_P: PSx.set(sa, x); PSy.set(sa, y); PSz.set(sa, z); break;
+        case OP_LOAD_P: x = PSx.get(sa); y = PSy.get(sa); z = PSz.get(sa); break;
         // ---------------- distance ops ----------------
-        case OP_PUSH_D: DS[sa] = acc; break;
+        case OP_PUSH_D: DS.set(sa, acc); break;
         case OP_NEG: acc = -acc; break;                            // dn.py:60-63
         case OP_ADDC: acc = acc + c[0]; break;                     // dn.py:70-73
         case OP_SUBC: acc = acc - c[0]; break;                     // dn.py:65-68
         case OP_MULC: acc = acc * c[0]; break;                     // d3.py:344
         case OP_SHELL: acc = m_fabs(acc) - c[0]; break;            // dn.py:75-78
-        case OP_ADD_DS: acc = acc + DS[sa]; break;                 // d3.py:405
+        case OP_ADD_DS: acc = acc + DS.get(sa); break;                 // d3.py:405
         case OP_TRANS_LIN_PRE: {  // d3.py:459-470
             const T tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
-            DS[sa] = ease_apply<T, FULL>((int)c[7], tt); break; }
+            DS.set(sa, ease_apply<T, FULL>((int)c[7], tt)); break; }
         case OP_TRANS_MIX: {  // t * d2 + (1 - t) * d1
-            const T tt = DS[sa];
-            acc = tt * acc + (T(1) - tt) * DS[sb]; break; }
-        case OP_EXT_PRE: DS[sa] = m_fabs(z) - c[0]; break;         // d2.py:264-266
+            const T tt = DS.get(sa);
+            acc = tt * acc + (T(1) - tt) * DS.get(sb); break; }
+        case OP_EXT_PRE: DS.set(sa, m_fabs(z) - c[0]); break;         // d2.py:264-266
         case OP_EXT_POST: {  // d2.py:267
-            const T w1 = DS[sa];
+            const T w1 = DS.get(sa);
             acc = np_min(np_max(acc, w1), T(0)) + len2(np_max(acc, T(0)), np_max(w1, T(0))); break; }
         case OP_EXTTO_PRE:   // d2.py:274
-            DS[sa] = ease_apply<T, FULL>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5)); break;
+            DS.set(sa, ease_apply<T, FULL>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5))); break;
         case OP_EXTTO_MIX: {  // d2.py:275
-            const T dd1 = DS[sb];
-            acc = dd1 + (acc - dd1) * DS[sa]; break; }
+            const T dd1 = DS.get(sb);
+            acc = dd1 + (acc - dd1) * DS.get(sa); break; }
         case OP_SLICE_POST: {  // d3.py:515-519
-            const T A = DS[sa], B = -acc;
+            const T A = DS.get(sa), B = -acc;
             acc = A <= T(0) ? B : A; break; }
         default:
             if constexpr (FULL) {
@@ -464,15 +483,15 @@ __device__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ c
                     x = c[0] + c[3] * tt + c[6] * d;
                     y = c[1] + c[4] * tt + c[7] * d; break; }
                 case OP_CIRC_PREP: {  // d3.py:379-392: PS[sa] = (d, a, z)
-                    PSx[sa] = m_hypot(x, y);
-                    PSy[sa] = np_mod(m_atan2(y, x), c[0]);
-                    PSz[sa] = z; break; }
+                    PSx.set(sa, m_hypot(x, y));
+                    PSy.set(sa, np_mod(m_atan2(y, x), c[0]));
+                    PSz.set(sa, z); break; }
                 case OP_CIRC_SET: {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
-                    const T ang = PSy[sa] - c[0], d = PSx[sa];
-                    x = m_cos(ang) * d; y = m_sin(ang) * d; z = PSz[sa]; break; }
+                    const T ang = PSy.get(sa) - c[0], d = PSx.get(sa);
+                    x = m_cos(ang) * d; y = m_sin(ang) * d; z = PSz.get(sa); break; }
                 case OP_TRANS_RAD_PRE: {  // d3.py:472-481
                     const T r = m_hypot(x, y);
-                    DS[sa] = ease_apply<T, FULL>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1))); break; }
+                    DS.set(sa, ease_apply<T, FULL>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); break; }
                 default: break;
                 }
             }

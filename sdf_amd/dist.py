@@ -54,8 +54,9 @@ def _local_tensor(mesh, t_pad, device):
     return buf
 
 
-def generate_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=None):
-    """every rank returns (points (3T,3) float64 ndarray, merged stats dict)"""
+def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=None):
+    """every rank returns (soup: flat float64 torch tensor of 9*T values on `device`, in
+    reference order; merged stats dict).  The soup never leaves the device."""
     import torch
     td = _dist()
     if td is None:
@@ -79,17 +80,19 @@ def generate_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=
         counts = allc[:, 0]
         t_pad = int(counts.max())
 
-        # 2) the exchange step: padded all-gather of the triangle buffers
+        # 2) the exchange step: padded all-gather of the triangle buffers, then compaction
         if t_pad:
             local = _local_tensor(mesh, t_pad, device)
             gathered = torch.empty(world * t_pad * 9, dtype=torch.float64, device=device)
             td.all_gather_into_tensor(gathered, local, group=group)
             gathered = gathered.view(world, t_pad * 9)
-            parts = [gathered[i, :int(counts[i]) * 9] for i in range(world) if counts[i]]
-            soup = torch.cat(parts) if parts else gathered[0, :0]
-            points = soup.cpu().numpy().reshape(-1, 3)
+            if all(int(c) == t_pad for c in counts):
+                soup = gathered.reshape(-1)
+            else:
+                parts = [gathered[i, :int(counts[i]) * 9] for i in range(world) if counts[i]]
+                soup = torch.cat(parts) if parts else gathered[0, :0]
         else:
-            points = np.empty((0, 3), np.float64)
+            soup = torch.empty(0, dtype=torch.float64, device=device)
     finally:
         mesh.close()
 
@@ -100,4 +103,10 @@ def generate_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=
     merged['n_ambiguous_cells'] = int(allc[:, 4].sum())
     merged['triangles'] = merged['n_triangles'] = int(counts.sum())
     merged['per_rank_triangles'] = [int(c) for c in counts]
-    return points, merged
+    return soup, merged
+
+
+def generate_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=None):
+    """every rank returns (points (3T,3) float64 ndarray, merged stats dict)"""
+    soup, merged = generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device, group)
+    return soup.cpu().numpy().reshape(-1, 3), merged
