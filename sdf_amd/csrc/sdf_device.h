@@ -1,0 +1,276 @@
+// sdf_device.h -- device-side structures and the fused sample+march kernel template (gfx950).
+//
+//   k_mesh   THE hot kernel: persistent workgroups (one per CU: the tile owns most of the CU's
+//            160 KiB LDS) pull surviving batches from the ordered work list.  Per batch:
+//              1. sample   the (<=33)^3 tile through the tape interpreter (NS samples per lane,
+//                          float64 or float32), cast to float32 like skimage's volume cast, and
+//                          store it in LDS -- the field never touches HBM
+//                          (reference `_worker`, sdf/core.py:50-52)
+//              2. count    one thread per (i0, i1) row of cells walks i2, builds the 8-bit sign
+//                          configuration from LDS and sums triangles per row; a block-wide
+//                          wave-shuffle prefix scan turns the row counts into offsets
+//              3. compact  surface cells expand into a per-triangle work list in LDS
+//                          (cell, configuration, triangle-in-cell), in skimage's emission order
+//              4. emit     one lane per TRIANGLE: three edge interpolations from the LDS tile,
+//                          36 contiguous bytes per lane into the float32 arena (coalesced)
+//            (reference `_marching_cubes`, sdf/core.py:16-18, 54)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sdf_interp.h"
+
+namespace sdfk {
+
+struct McTables {   // uploaded once per context
+    unsigned char ntri[256];   // triangles per sign configuration
+    unsigned char amb[256];    // 1 when the configuration is ambiguous (classic table vs Lewiner)
+    signed char tri[256][16];  // edge ids, 3 per triangle
+};
+
+struct MeshCounters {   // zeroed before every k_mesh run
+    unsigned long long tri_counter;   // next free triangle slot in the arena
+    unsigned long long n_eval;
+    unsigned int work_counter;
+    unsigned int overflow;
+    unsigned int n_empty, n_nonempty;
+    unsigned long long n_ambiguous;
+    unsigned long long total;         // written by k_scan
+};
+
+struct GridDesc {
+    const double *X, *Y, *Z;   // device copies of the np.arange axes
+    int nx, ny, nz;
+    int bs;                    // batch size (cells per axis), samples per axis = bs + 1
+    int nbx, nby, nbz;         // batches per axis
+};
+
+struct MeshArgs {
+    GridDesc g;
+    const McTables *mc;
+    const int *worklist;
+    int work_begin, work_end;      // this shard's slice of the work list
+    unsigned char *kinds;          // per batch
+    unsigned int *batch_count;     // per work item: triangles
+    unsigned long long *batch_base;  // per work item: first triangle slot in the arena
+    float *arena;                  // 9 floats per triangle
+    unsigned long long arena_cap;  // triangles
+    MeshCounters *ctr;
+    int list_off;                  // byte offset of the triangle work list in dynamic LDS
+    int list_cap;                  // its capacity in entries
+};
+
+// dynamic LDS layout of k_mesh
+enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_VOL = 1184 };
+
+__device__ __forceinline__ void batch_origin(const GridDesc &g, int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {
+    // itertools.product(Xs, Ys, Zs): Z fastest (reference sdf/core.py:119)
+    const int ibz = b % g.nbz, iby = (b / g.nbz) % g.nby, ibx = b / (g.nbz * g.nby);
+    ox = ibx * g.bs; oy = iby * g.bs; oz = ibz * g.bs;
+    lx = min(g.bs + 1, g.nx - ox); ly = min(g.bs + 1, g.ny - oy); lz = min(g.bs + 1, g.nz - oz);
+}
+
+// i / d for 0 <= i < 2^16, d >= 1, through the float pipe (exact: (i + 0.5) / d is never closer
+// than 0.5 / d to an integer, far above the float rounding error of the product)
+__device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
+
+template <int BLOCK>
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wave_sums, int &total) {
+    // wave64 inclusive scan by shuffles, then the wave totals through LDS
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_sums[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) { const int s = wave_sums[w]; if (w < wid) base += s; tot += s; }
+    total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// sign bits of the four samples (o0,o1) in {0,1}^2 of one i2-plane, bit (2*o0+o1) set when > 0
+__device__ __forceinline__ unsigned plane_bits(const float *v, int s0, int s1) {
+    return (v[0] > 0.0f ? 1u : 0u) | (v[s1] > 0.0f ? 2u : 0u) | (v[s0] > 0.0f ? 4u : 0u) | (v[s0 + s1] > 0.0f ? 8u : 0u);
+}
+// plane bit j -> configuration bit 2j (o2 = 0) ; shift left by one for o2 = 1
+__device__ __forceinline__ unsigned spread4(unsigned s) { return (s & 1u) | ((s & 2u) << 1) | ((s & 4u) << 2) | ((s & 8u) << 3); }
+
+// One marching-cubes vertex on edge e of the cell at (i0,i1,i2); v points at the cell's corner 0
+// in a volume with strides (s0, s1, 1).  skimage's placement: with w = 1/(eps+|v|),
+// t = w_hi / (w_lo + w_hi), evaluated in float64 on the float32 samples, stored as float32.
+__device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0, int i1, int i2, int e, float *o) {
+    const int axis = e >> 2, oa = (e >> 1) & 1, ob = e & 1;
+    int o0, o1, o2, stride;
+    if (axis == 0) { o0 = 0; o1 = oa; o2 = ob; stride = s0; }
+    else if (axis == 1) { o0 = oa; o1 = 0; o2 = ob; stride = s1; }
+    else { o0 = oa; o1 = ob; o2 = 0; stride = 1; }
+    const int base = o0 * s0 + o1 * s1 + o2;
+    const double vlo = (double)v[base], vhi = (double)v[base + stride];
+    const double eps = 2.220446049250313e-16;
+    const double wlo = 1.0 / (eps + fabs(vlo)), whi = 1.0 / (eps + fabs(vhi));
+    const double t = whi / (wlo + whi);
+    double p0 = (double)(i0 + o0), p1 = (double)(i1 + o1), p2 = (double)(i2 + o2);
+    if (axis == 0) p0 = (double)i0 + t; else if (axis == 1) p1 = (double)i1 + t; else p2 = (double)i2 + t;
+    o[0] = (float)p0; o[1] = (float)p1; o[2] = (float)p2;
+}
+
+template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
+    typedef Vec<T, NS> V;
+    constexpr int RPT = 1024 / BLOCK;   // (i0, i1) rows of cells per thread (a tile has <= 32 x 32 rows)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *wave_sums = reinterpret_cast<int *>(smem);                 // 16 ints
+    int *bcast = wave_sums + 16;                                    // 16 ints of scratch
+    unsigned char *ntri_lds = smem + MESH_LDS_NTRI;                 // 256 B: ntri | ambiguous << 7
+    double *axes = reinterpret_cast<double *>(smem + MESH_LDS_AXES);  // 3 * 33 doubles (X, Y, Z of the tile)
+    float *vol = reinterpret_cast<float *>(smem + MESH_LDS_VOL);    // (bs+1)^3 floats
+    unsigned *list = reinterpret_cast<unsigned *>(smem + a.list_off);
+    const int tid = threadIdx.x;
+    const GridDesc g = a.g;
+    const signed char *tri_tab = &a.mc->tri[0][0];
+
+    if (tid < 256) ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
+
+    for (;;) {
+        if (tid == 0) bcast[0] = a.work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
+        __syncthreads();
+        const int w = bcast[0];
+        if (w >= a.work_end) break;
+        const int b = a.worklist[w];
+        int ox, oy, oz, lx, ly, lz;
+        batch_origin(g, b, ox, oy, oz, lx, ly, lz);
+        if (tid < lx) axes[tid] = g.X[ox + tid];
+        else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
+        else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
+        __syncthreads();
+
+        // ---- 1. sample: volume = sdf(P).reshape(shape), cast to float32 (core.py:50-52) ----
+        const int nvox = lx * ly * lz;
+        const int lyz = ly * lz;
+        const float inv_lyz = 1.0f / (float)lyz, inv_lz = 1.0f / (float)lz;
+        for (int i0 = 0; i0 < nvox; i0 += BLOCK * NS) {
+            V px, py, pz;
+            SDF_UNROLL
+            for (int k = 0; k < NS; k++) {
+                const int i = min(i0 + k * BLOCK + tid, nvox - 1);
+                const int ix = fast_div(i, inv_lyz), r = i - ix * lyz, iy = fast_div(r, inv_lz), iz = r - iy * lz;
+                px.v[k] = (T)axes[ix]; py.v[k] = (T)axes[33 + iy]; pz.v[k] = (T)axes[66 + iz];
+            }
+            const V val = run_tape<T, FULL, NP, ND, NS>(code, consts, px, py, pz);
+            SDF_UNROLL
+            for (int k = 0; k < NS; k++) {
+                const int i = i0 + k * BLOCK + tid;
+                if (i < nvox) vol[i] = (float)val.v[k];
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. count: a thread owns the i2-rows of cells (i0, i1) = row tid + k * BLOCK ----
+        const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
+        const int nrows = (c0 > 0 && c1 > 0 && c2 > 0) ? c0 * c1 : 0;
+        const float inv_c1 = 1.0f / (float)max(c1, 1);
+        int row_tris[RPT], row_off[RPT];
+        unsigned row_mask[RPT];
+        int total = 0, my_amb = 0;
+        SDF_UNROLL
+        for (int k = 0; k < RPT; k++) {
+            const int r = tid + k * BLOCK;
+            int n = 0;
+            unsigned mask = 0;
+            if (r < nrows) {
+                const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
+                const float *row = vol + i0 * lyz + i1 * lz;
+                unsigned prev = plane_bits(row, lyz, lz);
+                for (int i2 = 0; i2 < c2; i2++) {
+                    const unsigned next = plane_bits(row + i2 + 1, lyz, lz);
+                    const unsigned e = ntri_lds[spread4(prev) | (spread4(next) << 1)];
+                    n += (int)(e & 7u);
+                    if (e) { mask |= 1u << i2; my_amb += (int)(e >> 7); }
+                    prev = next;
+                }
+            }
+            row_tris[k] = n; row_mask[k] = mask;
+            int tot;
+            row_off[k] = total + block_exclusive_scan<BLOCK>(n, wave_sums, tot);
+            total += tot;
+        }
+        if (tid == 0) {
+            unsigned long long base = 0;
+            if (total) {
+                base = atomicAdd(&a.ctr->tri_counter, (unsigned long long)total);
+                if (base + (unsigned long long)total > a.arena_cap) atomicOr(&a.ctr->overflow, 1u);
+                atomicAdd(&a.ctr->n_nonempty, 1u);
+            } else {
+                atomicAdd(&a.ctr->n_empty, 1u);
+            }
+            atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
+            a.batch_count[w] = (unsigned)total;
+            a.batch_base[w] = base;
+            a.kinds[b] = total ? 2 : 1;
+            reinterpret_cast<unsigned long long *>(bcast + 2)[0] = base;
+        }
+        if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
+        __syncthreads();
+        const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
+        const bool fits = base + (unsigned long long)total <= a.arena_cap;
+
+        // ---- 3 + 4. per-triangle work list in LDS, then one lane per triangle ----
+        for (int lo = 0; fits && lo < total; lo += a.list_cap) {
+            const int cn = min(a.list_cap, total - lo);
+            SDF_UNROLL
+            for (int k = 0; k < RPT; k++) {
+                if (row_tris[k] == 0 || row_off[k] >= lo + cn || row_off[k] + row_tris[k] <= lo) continue;
+                const int r = tid + k * BLOCK;
+                const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
+                const float *row = vol + i0 * lyz + i1 * lz;
+                int pos = row_off[k] - lo;
+                unsigned m = row_mask[k];
+                while (m) {
+                    const int i2 = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const unsigned cfg = spread4(plane_bits(row + i2, lyz, lz)) | (spread4(plane_bits(row + i2 + 1, lyz, lz)) << 1);
+                    const int n = (int)(ntri_lds[cfg] & 7u);
+                    const unsigned e = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 11) | (cfg << 3);
+                    for (int j = 0; j < n; j++, pos++)
+                        if (pos >= 0 && pos < cn) list[pos] = e | (unsigned)j;
+                }
+            }
+            __syncthreads();
+            float *dst0 = a.arena + (base + (unsigned long long)lo) * 9ull;
+            for (int t = tid; t < cn; t += BLOCK) {
+                const unsigned e = list[t];
+                const int j = (int)(e & 7u), cfg = (int)((e >> 3) & 255u), cell = (int)(e >> 11);
+                const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
+                const float *corner = vol + i0 * lyz + i1 * lz + i2;
+                const signed char *tt = tri_tab + cfg * 16 + 3 * j;
+                float o[9];
+                mc_vertex(corner, lyz, lz, i0, i1, i2, tt[0], o);
+                mc_vertex(corner, lyz, lz, i0, i1, i2, tt[1], o + 3);
+                mc_vertex(corner, lyz, lz, i0, i1, i2, tt[2], o + 6);
+                float *dst = dst0 + (size_t)t * 9;
+                SDF_UNROLL
+                for (int q = 0; q < 9; q++) dst[q] = o[q];
+            }
+            __syncthreads();   // list / vol are reused
+        }
+        __syncthreads();   // vol / bcast are reused by the next batch
+    }
+}
+
+// host-side launcher of one (T, FULL) family, defined in sdf_mesh_inst.hip (one translation
+// unit per family so the variants compile in parallel).  slots: 0 = (2,2), 1 = (4,4), 2 = (8,8)
+// register files; shape: 0 = 1024 threads x 1 sample, 1 = 512 x 2, 2 = 256 x 4.
+#define SDF_DECLARE_MESH_LAUNCH(NAME, T) \
+    int NAME(int slots, int shape, int grid, size_t lds, hipStream_t stream, const uint32_t *code, const T *consts, const MeshArgs &a)
+SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f64, double);
+SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f64_full, double);
+SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f32, float);
+SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f32_full, float);
+
+}  // namespace sdfk

@@ -21,50 +21,20 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/sdf_hip.h"
 #include "mc_table.h"
-#include "sdf_interp.h"
+#include "sdf_device.h"
 
 using namespace sdfk;
 
 // ============================================================================================
-// device side
+// device side (the fused sample+march kernel k_mesh lives in sdf_device.h)
 // ============================================================================================
-
-struct McTables {   // copied to __constant__ memory once per process
-    unsigned char ntri[256];
-    unsigned char amb[256];
-    signed char tri[256][16];
-};
-__constant__ McTables c_mc;
-
-struct MeshCounters {   // zeroed before every k_mesh run
-    unsigned long long tri_counter;   // next free triangle slot in the arena
-    unsigned long long n_eval;
-    unsigned int work_counter;
-    unsigned int overflow;
-    unsigned int n_empty, n_nonempty;
-    unsigned long long n_ambiguous;
-    unsigned long long total;         // written by k_scan
-};
-
-struct GridDesc {
-    const double *X, *Y, *Z;   // device copies of the np.arange axes
-    int nx, ny, nz;
-    int bs;                    // batch size (cells per axis), samples per axis = bs + 1
-    int nbx, nby, nbz;         // batches per axis
-};
-
-__device__ __forceinline__ void batch_origin(const GridDesc &g, int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {
-    // itertools.product(Xs, Ys, Zs): Z fastest (reference sdf/core.py:119)
-    const int ibz = b % g.nbz, iby = (b / g.nbz) % g.nby, ibx = b / (g.nbz * g.nby);
-    ox = ibx * g.bs; oy = iby * g.bs; oz = ibz * g.bs;
-    lx = min(g.bs + 1, g.nx - ox); ly = min(g.bs + 1, g.ny - oy); lz = min(g.bs + 1, g.nz - oz);
-}
 
 template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void k_eval_points(const uint32_t *__restrict__ code, const T *__restrict__ consts,
@@ -73,7 +43,7 @@ __global__ __launch_bounds__(256) void k_eval_points(const uint32_t *__restrict_
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const T x = (T)pts[i * dim], y = (T)pts[i * dim + 1], z = dim > 2 ? (T)pts[i * dim + 2] : T(0);
-    out[i] = (double)run_tape<T, FULL>(code, consts, x, y, z);
+    out[i] = (double)run_tape1<T, FULL>(code, consts, x, y, z);
 }
 
 template <typename T, bool FULL>
@@ -85,7 +55,7 @@ __global__ __launch_bounds__(256) void k_eval_grid(const uint32_t *__restrict__ 
     const long long n = (long long)nx * ny * nz;
     if (i >= n) return;
     const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((long long)nz * ny));
-    out[i] = (double)run_tape<T, FULL>(code, consts, (T)X[ix], (T)Y[iy], (T)Z[iz]);
+    out[i] = (double)run_tape1<T, FULL>(code, consts, (T)X[ix], (T)Y[iy], (T)Z[iz]);
 }
 
 // reference sdf/core.py:28-43.  16 lanes per batch: lane 0 = centre, lanes 1..8 = corners in
@@ -106,7 +76,7 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
     double px = cx, py = cy, pz = cz;
     if (l >= 1) { const int k = l - 1; px = (k & 4) ? x1 : x0; py = (k & 2) ? y1 : y0; pz = (k & 1) ? z1 : z0; }
     T v = T(0);
-    if (live) v = run_tape<T, FULL>(code, consts, (T)px, (T)py, (T)pz);
+    if (live) v = run_tape1<T, FULL>(code, consts, (T)px, (T)py, (T)pz);
     const int lane = threadIdx.x & 63, base = lane & ~15;
     const T vc = __shfl(v, base, 64);          // centre
     const T v1 = __shfl(v, base + 1, 64);      // values[0]
@@ -122,25 +92,6 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
     }
 }
 
-__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wave_sums, int &total) {
-    // wave64 inclusive scan by shuffles, then 16 wave totals through LDS
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) wave_sums[wid] = inc;
-    __syncthreads();
-    int base = 0, tot = 0;
-    const int nw = blockDim.x >> 6;
-    for (int w = 0; w < nw; w++) { const int s = wave_sums[w]; if (w < wid) base += s; tot += s; }
-    total = tot;
-    __syncthreads();
-    return base + inc - v;
-}
-
 // ordered compaction of the pending batches into the work list (single workgroup)
 __global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restrict__ kinds, int nbatches,
                                                   int *__restrict__ worklist, int *__restrict__ nwork) {
@@ -150,140 +101,11 @@ __global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restric
         const int b = start + threadIdx.x;
         const int f = (b < nbatches && kinds[b] != 0) ? 1 : 0;
         int tot;
-        const int pos = block_exclusive_scan_1024(f, wave_sums, tot);
+        const int pos = block_exclusive_scan<1024>(f, wave_sums, tot);
         if (f) worklist[base + pos] = b;
         base += tot;
     }
     if (threadIdx.x == 0) *nwork = base;
-}
-
-// sign bits of the four samples (o0,o1) in {0,1}^2 of one i2-plane, bit (2*o0+o1) set when > 0
-__device__ __forceinline__ unsigned plane_bits(const float *v, int s0, int s1) {
-    return (v[0] > 0.0f ? 1u : 0u) | (v[s1] > 0.0f ? 2u : 0u) | (v[s0] > 0.0f ? 4u : 0u) | (v[s0 + s1] > 0.0f ? 8u : 0u);
-}
-// plane bit j -> configuration bit 2j (o2 = 0) ; shift left by one for o2 = 1
-__device__ __forceinline__ unsigned spread4(unsigned s) { return (s & 1u) | ((s & 2u) << 1) | ((s & 4u) << 2) | ((s & 8u) << 3); }
-
-// One marching-cubes vertex on edge e of the cell at (i0,i1,i2); v points at the cell's corner 0
-// in a volume with strides (s0, s1, 1).  skimage's placement: with w = 1/(eps+|v|),
-// t = w_hi / (w_lo + w_hi), evaluated in float64 on the float32 samples, stored as float32.
-__device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0, int i1, int i2, int e, float *o) {
-    const int axis = e >> 2, oa = (e >> 1) & 1, ob = e & 1;
-    int o0, o1, o2, stride;
-    if (axis == 0) { o0 = 0; o1 = oa; o2 = ob; stride = s0; }
-    else if (axis == 1) { o0 = oa; o1 = 0; o2 = ob; stride = s1; }
-    else { o0 = oa; o1 = ob; o2 = 0; stride = 1; }
-    const int base = o0 * s0 + o1 * s1 + o2;
-    const double vlo = (double)v[base], vhi = (double)v[base + stride];
-    const double eps = 2.220446049250313e-16;
-    const double wlo = 1.0 / (eps + fabs(vlo)), whi = 1.0 / (eps + fabs(vhi));
-    const double t = whi / (wlo + whi);
-    double p0 = (double)(i0 + o0), p1 = (double)(i1 + o1), p2 = (double)(i2 + o2);
-    if (axis == 0) p0 = (double)i0 + t; else if (axis == 1) p1 = (double)i1 + t; else p2 = (double)i2 + t;
-    o[0] = (float)p0; o[1] = (float)p1; o[2] = (float)p2;
-}
-
-struct MeshArgs {
-    GridDesc g;
-    const int *worklist;
-    int work_begin, work_end;      // this shard's slice of the work list
-    unsigned char *kinds;          // per batch
-    unsigned int *batch_count;     // per work item: triangles
-    unsigned long long *batch_base;  // per work item: first triangle slot in the arena
-    float *arena;                  // 9 floats per triangle
-    unsigned long long arena_cap;  // triangles
-    MeshCounters *ctr;
-};
-
-template <typename T, bool FULL>
-__global__ __launch_bounds__(1024) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *wave_sums = reinterpret_cast<int *>(smem);                 // 16 ints
-    int *bcast = wave_sums + 16;                                    // 16 ints of scratch
-    double *axes = reinterpret_cast<double *>(smem + 128);          // 3 * 33 doubles (X, Y, Z of the tile)
-    float *vol = reinterpret_cast<float *>(smem + 128 + 3 * 33 * 8);  // (bs+1)^3 floats
-    const int tid = threadIdx.x;
-    const GridDesc g = a.g;
-
-    for (;;) {
-        if (tid == 0) bcast[0] = a.work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
-        __syncthreads();
-        const int w = bcast[0];
-        if (w >= a.work_end) break;
-        const int b = a.worklist[w];
-        int ox, oy, oz, lx, ly, lz;
-        batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-        if (tid < lx) axes[tid] = g.X[ox + tid];
-        else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
-        else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
-        __syncthreads();
-
-        // ---- sample the tile: volume = sdf(P).reshape(shape), cast to float32 (core.py:50-52) ----
-        const int nvox = lx * ly * lz;
-        const int lyz = ly * lz;
-        for (int i = tid; i < nvox; i += 1024) {
-            const int ix = i / lyz, r = i - ix * lyz, iy = r / lz, iz = r - iy * lz;
-            const T val = run_tape<T, FULL>(code, consts, (T)axes[ix], (T)axes[33 + iy], (T)axes[66 + iz]);
-            vol[i] = (float)val;
-        }
-        __syncthreads();
-
-        // ---- count: thread t owns the i2-row of cells at (i0, i1) ----
-        const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
-        const int nrows = (c0 > 0 && c1 > 0 && c2 > 0) ? c0 * c1 : 0;
-        int my_tris = 0, my_amb = 0;
-        int i0 = 0, i1 = 0;
-        const float *row = vol;
-        if (tid < nrows) {
-            i0 = tid / c1; i1 = tid - i0 * c1;
-            row = vol + i0 * lyz + i1 * lz;
-            unsigned prev = plane_bits(row, lyz, lz);
-            for (int i2 = 0; i2 < c2; i2++) {
-                const unsigned next = plane_bits(row + i2 + 1, lyz, lz);
-                const unsigned cfg = spread4(prev) | (spread4(next) << 1);
-                my_tris += c_mc.ntri[cfg];
-                my_amb += (c_mc.ntri[cfg] ? c_mc.amb[cfg] : 0);
-                prev = next;
-            }
-        }
-        int total;
-        const int my_off = block_exclusive_scan_1024(my_tris, wave_sums, total);
-        if (tid == 0) {
-            unsigned long long base = 0;
-            if (total) {
-                base = atomicAdd(&a.ctr->tri_counter, (unsigned long long)total);
-                if (base + (unsigned long long)total > a.arena_cap) atomicOr(&a.ctr->overflow, 1u);
-                atomicAdd(&a.ctr->n_nonempty, 1u);
-            } else {
-                atomicAdd(&a.ctr->n_empty, 1u);
-            }
-            atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
-            a.batch_count[w] = (unsigned)total;
-            a.batch_base[w] = base;
-            a.kinds[b] = total ? 2 : 1;
-            reinterpret_cast<unsigned long long *>(bcast + 2)[0] = base;
-        }
-        if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
-        __syncthreads();
-        const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
-
-        // ---- emit the batch-local float32 soup in cell order (skimage order) ----
-        if (total && base + (unsigned long long)total <= a.arena_cap && my_tris) {
-            float *dst = a.arena + (base + (unsigned long long)my_off) * 9ull;
-            unsigned prev = plane_bits(row, lyz, lz);
-            for (int i2 = 0; i2 < c2; i2++) {
-                const unsigned next = plane_bits(row + i2 + 1, lyz, lz);
-                const unsigned cfg = spread4(prev) | (spread4(next) << 1);
-                prev = next;
-                const int k = c_mc.ntri[cfg];
-                for (int j = 0; j < 3 * k; j++) {
-                    mc_vertex(row + i2, lyz, lz, i0, i1, i2, c_mc.tri[cfg][j], dst);
-                    dst += 3;
-                }
-            }
-        }
-        __syncthreads();   // vol / bcast are reused by the next batch
-    }
 }
 
 // exclusive scan of batch_count[w0..w1) -> batch_final (triangle index in the ordered soup)
@@ -295,7 +117,7 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned int *__restrict__ 
         const int w = start + threadIdx.x;
         const int v = w < w1 ? (int)batch_count[w] : 0;
         int tot;
-        const int pos = block_exclusive_scan_1024(v, wave_sums, tot);
+        const int pos = block_exclusive_scan<1024>(v, wave_sums, tot);
         if (w < w1) batch_final[w] = base + (unsigned long long)pos;
         base += (unsigned long long)tot;
     }
@@ -329,7 +151,7 @@ __global__ __launch_bounds__(256) void k_gather(GridDesc g, const int *__restric
 }
 
 // ---- marching cubes of a caller-supplied volume -------------------------------------------
-__global__ __launch_bounds__(256) void k_mc_rows(const float *__restrict__ vol, int n0, int n1, int n2,
+__global__ __launch_bounds__(256) void k_mc_rows(const McTables *__restrict__ mc, const float *__restrict__ vol, int n0, int n1, int n2,
                                                  unsigned int *__restrict__ row_count) {
     const int c1 = n1 - 1, c2 = n2 - 1;
     const long long nrows = (long long)(n0 - 1) * c1;
@@ -342,7 +164,7 @@ __global__ __launch_bounds__(256) void k_mc_rows(const float *__restrict__ vol, 
     unsigned cnt = 0;
     for (int i2 = 0; i2 < c2; i2++) {
         const unsigned next = plane_bits(row + i2 + 1, s0, s1);
-        cnt += c_mc.ntri[spread4(prev) | (spread4(next) << 1)];
+        cnt += mc->ntri[spread4(prev) | (spread4(next) << 1)];
         prev = next;
     }
     row_count[t] = cnt;
@@ -356,14 +178,14 @@ __global__ __launch_bounds__(1024) void k_scan_rows(const unsigned int *__restri
         const long long i = start + threadIdx.x;
         const int v = i < n ? (int)cnt[i] : 0;
         int tot;
-        const int pos = block_exclusive_scan_1024(v, wave_sums, tot);
+        const int pos = block_exclusive_scan<1024>(v, wave_sums, tot);
         if (i < n) off[i] = base + (unsigned long long)pos;
         base += (unsigned long long)tot;
     }
     if (threadIdx.x == 0) *total = base;
 }
 
-__global__ __launch_bounds__(256) void k_mc_emit(const float *__restrict__ vol, int n0, int n1, int n2,
+__global__ __launch_bounds__(256) void k_mc_emit(const McTables *__restrict__ mc, const float *__restrict__ vol, int n0, int n1, int n2,
                                                  const unsigned long long *__restrict__ row_off, float *__restrict__ out,
                                                  unsigned long long cap) {
     const int c1 = n1 - 1, c2 = n2 - 1;
@@ -379,10 +201,10 @@ __global__ __launch_bounds__(256) void k_mc_emit(const float *__restrict__ vol, 
         const unsigned next = plane_bits(row + i2 + 1, s0, s1);
         const unsigned cfg = spread4(prev) | (spread4(next) << 1);
         prev = next;
-        const int nt = c_mc.ntri[cfg];
+        const int nt = mc->ntri[cfg];
         for (int j = 0; j < nt; j++, k++) {
             if (k >= cap) return;
-            for (int q = 0; q < 3; q++) mc_vertex(row + i2, s0, s1, i0, i1, i2, c_mc.tri[cfg][3 * j + q], out + k * 9ull + q * 3);
+            for (int q = 0; q < 3; q++) mc_vertex(row + i2, s0, s1, i0, i1, i2, mc->tri[cfg][3 * j + q], out + k * 9ull + q * 3);
         }
     }
 }
@@ -449,7 +271,9 @@ struct sdf_ctx {
     hipEvent_t ev[6] = {};
     int n_cu = 256;
     size_t lds_max = 0;
-    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, counters, nwork, scratch_in, scratch_out, rows, rows_off;
+    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, counters, nwork, scratch_in, scratch_out, rows, rows_off, mc;
+    int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
+    int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
     std::vector<DevBuf> arena_pool;   // arenas handed back by destroyed meshes
     unsigned long long last_tris_per_batch = 0;
 };
@@ -461,6 +285,7 @@ struct sdf_tape {
     float *d_c32 = nullptr;
     uint32_t n_words = 0, n_consts = 0;
     bool full = false;
+    uint32_t n_p = 0, n_d = 0;
     unsigned long long hint_tris_per_batch = 0;
 };
 
@@ -543,7 +368,10 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     memcpy(t.ntri, MC_NTRI, 256);
     memcpy(t.amb, MC_AMBIGUOUS, 256);
     memcpy(t.tri, MC_TRI, sizeof(t.tri));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mc), &t, sizeof(t)));
+    if (c->mc.ensure(sizeof(t))) return 1;
+    HIPCHK(hipMemcpy(c->mc.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    if (const char *e = getenv("SDF_MESH_SHAPE")) c->mesh_shape = atoi(e);
+    if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
     *out = c;
     return 0;
 }
@@ -553,7 +381,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->axes, &c->kinds, &c->worklist, &c->batch_count, &c->batch_base, &c->batch_final, &c->counters,
-                      &c->nwork, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off})
+                      &c->nwork, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc})
         b->release();
     for (auto &b : c->arena_pool) b.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -583,6 +411,7 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     sdf_tape *t = new sdf_tape();
     t->ctx = c; t->n_words = n_words; t->n_consts = n_consts;
     t->full = tape_needs_full(code, n_words, consts);
+    t->n_p = n_p; t->n_d = n_d;
     std::vector<float> c32(n_consts);
     for (uint32_t i = 0; i < n_consts; i++) c32[i] = (float)consts[i];
     HIPCHK(hipMalloc((void **)&t->d_code, n_words * sizeof(uint32_t)));
@@ -679,7 +508,7 @@ int sdf_marching_cubes(sdf_ctx *c, const void *d_volume, int n0, int n1, int n2,
     if (c->rows.ensure((size_t)nrows * 4) || c->rows_off.ensure((size_t)(nrows + 1) * 8)) return 1;
     unsigned long long *d_total = (unsigned long long *)c->rows_off.p + nrows;
     const unsigned grid = (unsigned)((nrows + 255) / 256);
-    hipLaunchKernelGGL(k_mc_rows, dim3(grid), dim3(256), 0, c->stream, (const float *)d_volume, n0, n1, n2, (unsigned *)c->rows.p);
+    hipLaunchKernelGGL(k_mc_rows, dim3(grid), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)d_volume, n0, n1, n2, (unsigned *)c->rows.p);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)c->rows.p, nrows,
                        (unsigned long long *)c->rows_off.p, d_total);
     HIPCHK(hipGetLastError());
@@ -688,7 +517,7 @@ int sdf_marching_cubes(sdf_ctx *c, const void *d_volume, int n0, int n1, int n2,
     HIPCHK(hipStreamSynchronize(c->stream));
     *n_tris = (int64_t)total;
     if (total && d_out && cap > 0) {
-        hipLaunchKernelGGL(k_mc_emit, dim3(grid), dim3(256), 0, c->stream, (const float *)d_volume, n0, n1, n2,
+        hipLaunchKernelGGL(k_mc_emit, dim3(grid), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)d_volume, n0, n1, n2,
                            (const unsigned long long *)c->rows_off.p, (float *)d_out, (unsigned long long)cap);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -717,14 +546,29 @@ int sdf_marching_cubes_host(sdf_ctx *c, const float *h_vol, int n0, int n1, int 
 
 }  // extern "C"
 
-static size_t mesh_lds_bytes(int bs) { return 128 + 3 * 33 * 8 + (size_t)(bs + 1) * (bs + 1) * (bs + 1) * 4; }
-
-template <typename T, bool FULL>
-static int launch_mesh(sdf_tape *t, const T *consts, const MeshArgs &a, int grid, size_t lds) {
-    auto fn = k_mesh<T, FULL>;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(1024), lds, t->ctx->stream, (const uint32_t *)t->d_code, consts, a);
-    HIPCHK(hipGetLastError());
+// k_mesh launch: the register-file variant is the smallest that holds the tape's slots, the
+// shape (threads x samples per lane) a per-precision default found by measurement
+static int launch_mesh(sdf_tape *t, int precision, MeshArgs &a, int grid, int bs) {
+    sdf_ctx *c = t->ctx;
+    const size_t tile = (size_t)(bs + 1) * (bs + 1) * (bs + 1) * 4;
+    const size_t list_off = (MESH_LDS_VOL + tile + 15) & ~(size_t)15;
+    if (list_off + 4096 > c->lds_max) return fail("sdf_generate: device LDS too small for this batch size");
+    const size_t list_cap = std::min<size_t>((c->lds_max - list_off) / 4, 16384);
+    a.list_off = (int)list_off; a.list_cap = (int)list_cap;
+    const size_t lds = list_off + list_cap * 4;
+    const uint32_t need = std::max(t->n_p, t->n_d);
+    int slots = need <= 2 ? 0 : (need <= 4 ? 1 : 2);
+    if (c->mesh_slots >= 0) slots = std::max(slots, std::min(c->mesh_slots, 2));
+    int shape = 1;
+    if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 2);
+    int rc;
+    if (precision == SDF_PRECISION_F64)
+        rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, grid, lds, c->stream, t->d_code, t->d_c64, a)
+                     : sdf_launch_mesh_f64(slots, shape, grid, lds, c->stream, t->d_code, t->d_c64, a);
+    else
+        rc = t->full ? sdf_launch_mesh_f32_full(slots, shape, grid, lds, c->stream, t->d_code, t->d_c32, a)
+                     : sdf_launch_mesh_f32(slots, shape, grid, lds, c->stream, t->d_code, t->d_c32, a);
+    if (rc) return fail(std::string("k_mesh launch: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
 
@@ -783,8 +627,6 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         // arena: start from the model's last observed density (or 4096 triangles per batch)
         unsigned long long per = t->hint_tris_per_batch ? t->hint_tris_per_batch + t->hint_tris_per_batch / 4 + 64 : 4096ull;
         unsigned long long cap = std::max<unsigned long long>(per * (unsigned long long)nshard, 1ull << 16);
-        const size_t lds = mesh_lds_bytes(bs);
-        if (lds > c->lds_max) return fail("sdf_generate: device LDS too small for this batch size");
         for (int attempt = 0;; attempt++) {
             if (!m->arena.p && !c->arena_pool.empty()) { m->arena = c->arena_pool.back(); c->arena_pool.pop_back(); }
             if (m->arena.ensure((size_t)cap * 36)) return 1;
@@ -797,12 +639,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             a.ctr = (MeshCounters *)c->counters.p;
             const int grid = std::min(nshard, c->n_cu);
             HIPCHK(hipEventRecord(c->ev[3], c->stream));
-            int rc;
-            if (precision == SDF_PRECISION_F64)
-                rc = t->full ? launch_mesh<double, true>(t, t->d_c64, a, grid, lds) : launch_mesh<double, false>(t, t->d_c64, a, grid, lds);
-            else
-                rc = t->full ? launch_mesh<float, true>(t, t->d_c32, a, grid, lds) : launch_mesh<float, false>(t, t->d_c32, a, grid, lds);
-            if (rc) return 1;
+            a.mc = (const McTables *)c->mc.p;
+            if (launch_mesh(t, precision, a, grid, bs)) return 1;
             HIPCHK(hipEventRecord(c->ev[4], c->stream));
             hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)m->batch_count.p, m->work_begin,
                                m->work_end, (unsigned long long *)m->batch_final.p, (MeshCounters *)c->counters.p);

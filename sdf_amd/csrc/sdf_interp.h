@@ -1,16 +1,19 @@
-// sdf_interp.h -- the CDNA4 op-tape interpreter: one lane evaluates one sample.
+// sdf_interp.h -- the CDNA4 op-tape interpreter: one lane evaluates NS samples.
 //
 // Replaces the reference's recursive NumPy closure calls (reference sdf/d3.py:24-25 and every
 // `def f(p)` in sdf/d3.py, sdf/d2.py, sdf/dn.py, sdf/ease.py).  The tape (sdf_amd/tape.py) is
 // straight-line code that is identical for every lane, so all control flow here is
 // wave-uniform: instruction words and constants are fetched through the scalar cache
-// (s_load), the opcode switch is a scalar branch, and the slot numbers that index the
-// PS / DS register arrays are wave-uniform too.  Machine state per lane:
+// (s_load), the opcode switch is a scalar branch tree, and the slot numbers that index the
+// PS / DS register files are wave-uniform too.  Data-dependent choices inside an op are
+// selects (v_cndmask), never branches.  Machine state per sample:
 //     (x, y, z)  current point         acc      current distance
 //     PS[s]      saved points          DS[s]    saved distances       (static slots)
+// Every lane carries NS samples (Vec<T, NS>, sdf_vec.h): the decode cost of an instruction is
+// paid once per NS * 64 samples and the NS dependency chains interleave in the VALU.
 //
 // Arithmetic follows the reference's NumPy expression order operation by operation (no
-// contraction: the translation unit is built with -ffp-contract=off; fused multiply-adds appear
+// contraction: the translation units are built with -ffp-contract=off; fused multiply-adds appear
 // only where NumPy itself goes through BLAS, see dot3), so that in T = double the values agree
 // with the reference to the last bit for every correctly-rounded operation.  The formulas carry
 // the reference file:line they restate.
@@ -19,20 +22,11 @@
 #include <stdint.h>
 
 #include "opcodes.h"
+#include "sdf_vec.h"
 
 namespace sdfk {
 
-#define SDF_DEV __device__ __forceinline__
-
-// ---- NumPy scalar semantics (np.minimum/np.maximum/np.clip propagate NaN) ----------------
-template <typename T> SDF_DEV T np_min(T a, T b) { return (a < b || a != a) ? a : b; }
-template <typename T> SDF_DEV T np_max(T a, T b) { return (a >= b || a != a) ? a : b; }
-template <typename T> SDF_DEV T np_clip(T x, T lo, T hi) {
-    T t = (x != x || x > lo) ? x : lo;
-    return (t != t || t < hi) ? t : hi;
-}
-template <typename T> SDF_DEV T np_sign(T x) { return x != x ? x : (x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0))); }
-
+// ---- scalar primitives -------------------------------------------------------------------
 // sqrt() / sqrtf() are the correctly rounded ocml forms (the __*sqrt_rn intrinsics may map to the
 // native approximation)
 SDF_DEV double m_sqrt(double x) { return sqrt(x); }
@@ -58,14 +52,16 @@ SDF_DEV float m_pow2(float x) { return powf(2.0f, x); }
 SDF_DEV double m_copysign(double x, double y) { return copysign(x, y); }
 SDF_DEV float m_copysign(float x, float y) { return copysignf(x, y); }
 
-// np.linalg.norm(axis=1): sqrt of the left-to-right sum of squares
-template <typename T> SDF_DEV T len2(T x, T y) { return m_sqrt(x * x + y * y); }
-template <typename T> SDF_DEV T len3(T x, T y, T z) { return m_sqrt((x * x + y * y) + z * z); }
-// np.dot((N,3),(3,)) / np.dot((N,3),(3,3)): BLAS kernels accumulate with fused multiply-adds
-template <typename T> SDF_DEV T dot3(T ax, T ay, T az, T bx, T by, T bz) { return m_fma(az, bz, m_fma(ay, by, ax * bx)); }
-template <typename T> SDF_DEV T dot2(T ax, T ay, T bx, T by) { return m_fma(ay, by, ax * bx); }
+// NumPy scalar semantics: np.minimum / np.maximum / np.clip propagate NaN
+template <typename T> SDF_DEV T s_min(T a, T b) { return (a < b || a != a) ? a : b; }
+template <typename T> SDF_DEV T s_max(T a, T b) { return (a >= b || a != a) ? a : b; }
+template <typename T> SDF_DEV T s_clip(T x, T lo, T hi) {
+    T t = (x != x || x > lo) ? x : lo;
+    return (t != t || t < hi) ? t : hi;
+}
+template <typename T> SDF_DEV T s_sign(T x) { return x != x ? x : (x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0))); }
 // Python / NumPy floored modulo (npy_divmod)
-template <typename T> SDF_DEV T np_mod(T a, T b) {
+template <typename T> SDF_DEV T s_mod(T a, T b) {
     T m = m_fmod(a, b);
     if (b == T(0)) return m;
     if (m != T(0)) { if ((b < T(0)) != (m < T(0))) m += b; }
@@ -73,56 +69,91 @@ template <typename T> SDF_DEV T np_mod(T a, T b) {
     return m;
 }
 
-// ---- easing curves: reference sdf/ease.py:3-162 ------------------------------------------
-template <typename T> SDF_DEV T out_bounce(T t) {
-    if (t < T(4.0 / 11)) return (T(121) * t * t) / T(16);
-    if (t < T(8.0 / 11)) return (T(363.0 / 40) * t * t) - (T(99.0 / 10) * t) + T(17.0 / 5);
-    if (t < T(9.0 / 10)) return (T(4356.0 / 361) * t * t) - (T(35442.0 / 1805) * t) + T(16061.0 / 1805);
-    return (T(54.0 / 5) * t * t) - (T(513.0 / 25) * t) + T(268.0 / 25);
+// ---- the same, element-wise over Vec ------------------------------------------------------
+SDF_VEC_MAP1(m_sqrt, m_sqrt(x))
+SDF_VEC_MAP1(m_fabs, m_fabs(x))
+SDF_VEC_MAP1(m_rint, m_rint(x))
+SDF_VEC_MAP1(m_sin, m_sin(x))
+SDF_VEC_MAP1(m_cos, m_cos(x))
+SDF_VEC_MAP1(m_pow2, m_pow2(x))
+SDF_VEC_MAP1(np_sign, s_sign(x))
+SDF_VEC_MAP2(m_atan2, m_atan2(x, y))
+SDF_VEC_MAP2(m_hypot, m_hypot(x, y))
+SDF_VEC_MAP2(np_min, s_min(x, y))
+SDF_VEC_MAP2(np_max, s_max(x, y))
+SDF_VEC_MAP2(np_mod, s_mod(x, y))
+template <typename T, int N> SDF_DEV Vec<T, N> np_clip(const Vec<T, N> &a, T lo, T hi) {
+    Vec<T, N> r; SDF_UNROLL for (int i = 0; i < N; i++) r.v[i] = s_clip(a.v[i], lo, hi); return r;
+}
+template <typename T, int N> SDF_DEV Vec<T, N> np_clip(const Vec<T, N> &a, const Vec<T, N> &lo, const Vec<T, N> &hi) {
+    Vec<T, N> r; SDF_UNROLL for (int i = 0; i < N; i++) r.v[i] = s_clip(a.v[i], lo.v[i], hi.v[i]); return r;
 }
 
-template <typename T, bool FULL> SDF_DEV T ease_apply(int id, T t) {
+// np.linalg.norm(axis=1): sqrt of the left-to-right sum of squares
+template <typename V> SDF_DEV V len2(const V &x, const V &y) { return m_sqrt(x * x + y * y); }
+template <typename V> SDF_DEV V len3(const V &x, const V &y, const V &z) { return m_sqrt((x * x + y * y) + z * z); }
+// np.dot((N,3),(3,)) / np.dot((N,3),(3,3)): BLAS kernels accumulate with fused multiply-adds
+template <typename T, int N>
+SDF_DEV Vec<T, N> dot3(const Vec<T, N> &ax, const Vec<T, N> &ay, const Vec<T, N> &az, T bx, T by, T bz) {
+    Vec<T, N> r; SDF_UNROLL for (int i = 0; i < N; i++) r.v[i] = m_fma(az.v[i], bz, m_fma(ay.v[i], by, ax.v[i] * bx)); return r;
+}
+template <typename T, int N> SDF_DEV Vec<T, N> dot2(const Vec<T, N> &ax, const Vec<T, N> &ay, T bx, T by) {
+    Vec<T, N> r; SDF_UNROLL for (int i = 0; i < N; i++) r.v[i] = m_fma(ay.v[i], by, ax.v[i] * bx); return r;
+}
+template <typename T> SDF_DEV T dot2s(T ax, T ay, T bx, T by) { return m_fma(ay, by, ax * bx); }
+
+// ---- easing curves: reference sdf/ease.py:3-162 ------------------------------------------
+template <typename T, int N> SDF_DEV Vec<T, N> out_bounce(const Vec<T, N> &t) {
+    const Vec<T, N> a = (T(121) * t * t) / T(16);
+    const Vec<T, N> b = (T(363.0 / 40) * t * t) - (T(99.0 / 10) * t) + T(17.0 / 5);
+    const Vec<T, N> c = (T(4356.0 / 361) * t * t) - (T(35442.0 / 1805) * t) + T(16061.0 / 1805);
+    const Vec<T, N> d = (T(54.0 / 5) * t * t) - (T(513.0 / 25) * t) + T(268.0 / 25);
+    return vsel(t < T(4.0 / 11), a, vsel(t < T(8.0 / 11), b, vsel(t < T(9.0 / 10), c, d)));
+}
+
+template <typename T, bool FULL, int N> SDF_DEV Vec<T, N> ease_apply(int id, const Vec<T, N> &t) {
+    typedef Vec<T, N> V;
     const T pi = T(3.141592653589793);
-    T u, v, a, b;
+    V u, v, a, b;
     switch (id) {   // id is wave-uniform
     case EASE_linear: return t;
     case EASE_in_quad: return t * t;
     case EASE_out_quad: return -t * (t - T(2));
     case EASE_in_out_quad:
         u = T(2) * t - T(1); a = T(2) * t * t; b = T(-0.5) * (u * (u - T(2)) - T(1));
-        return t < T(0.5) ? a : b;
+        return vsel(t < T(0.5), a, b);
     case EASE_in_cubic: return t * t * t;
     case EASE_out_cubic: u = t - T(1); return u * u * u + T(1);
     case EASE_in_out_cubic:
         u = t * T(2); v = u - T(2);
-        return u < T(1) ? T(0.5) * u * u * u : T(0.5) * (v * v * v + T(2));
+        return vsel(u < T(1), T(0.5) * u * u * u, T(0.5) * (v * v * v + T(2)));
     case EASE_in_quart: return t * t * t * t;
     case EASE_out_quart: u = t - T(1); return -(u * u * u * u - T(1));
     case EASE_in_out_quart:
         u = t * T(2); v = u - T(2);
-        return u < T(1) ? T(0.5) * u * u * u * u : T(-0.5) * (v * v * v * v - T(2));
+        return vsel(u < T(1), T(0.5) * u * u * u * u, T(-0.5) * (v * v * v * v - T(2)));
     case EASE_in_quint: return t * t * t * t * t;
     case EASE_out_quint: u = t - T(1); return u * u * u * u * u + T(1);
     case EASE_in_out_quint:
         u = t * T(2); v = u - T(2);
-        return u < T(1) ? T(0.5) * u * u * u * u * u : T(0.5) * (v * v * v * v * v + T(2));
+        return vsel(u < T(1), T(0.5) * u * u * u * u * u, T(0.5) * (v * v * v * v * v + T(2)));
     case EASE_in_circ: return T(-1) * (m_sqrt(T(1) - t * t) - T(1));
     case EASE_out_circ: u = t - T(1); return m_sqrt(T(1) - u * u);
     case EASE_in_out_circ:
         u = t * T(2); v = u - T(2);
-        return u < T(1) ? T(-0.5) * (m_sqrt(T(1) - u * u) - T(1)) : T(0.5) * (m_sqrt(T(1) - v * v) + T(1));
+        return vsel(u < T(1), T(-0.5) * (m_sqrt(T(1) - u * u) - T(1)), T(0.5) * (m_sqrt(T(1) - v * v) + T(1)));
     case EASE_in_back: { const T k = T(1.70158); return t * t * ((k + T(1)) * t - k); }
     case EASE_out_back: { const T k = T(1.70158); u = t - T(1); return u * u * ((k + T(1)) * u + k) + T(1); }
     case EASE_in_out_back: {
         const T k = T(1.70158 * 1.525); u = t * T(2); v = u - T(2);
-        return u < T(1) ? T(0.5) * (u * u * ((k + T(1)) * u - k)) : T(0.5) * (v * v * ((k + T(1)) * v + k) + T(2)); }
+        return vsel(u < T(1), T(0.5) * (u * u * ((k + T(1)) * u - k)), T(0.5) * (v * v * ((k + T(1)) * v + k) + T(2))); }
     case EASE_in_bounce: return T(1) - out_bounce(T(1) - t);
     case EASE_out_bounce: return out_bounce(t);
     case EASE_in_out_bounce:
-        return t < T(0.5) ? (T(1) - out_bounce(T(1) - T(2) * t)) * T(0.5) : out_bounce(T(2) * t - T(1)) * T(0.5) + T(0.5);
-    case EASE_in_square: return t < T(1) ? T(0) : T(1);
-    case EASE_out_square: return t > T(0) ? T(1) : T(0);
-    case EASE_in_out_square: return t < T(0.5) ? T(0) : T(1);
+        return vsel(t < T(0.5), (T(1) - out_bounce(T(1) - T(2) * t)) * T(0.5), out_bounce(T(2) * t - T(1)) * T(0.5) + T(0.5));
+    case EASE_in_square: return vsel_s(t < T(1), T(0), T(1));
+    case EASE_out_square: return vsel_s(t > T(0), T(1), T(0));
+    case EASE_in_out_square: return vsel_s(t < T(0.5), T(0), T(1));
     default: break;
     }
     if constexpr (FULL) {   // curves that need sin / cos / 2**x
@@ -130,12 +161,11 @@ template <typename T, bool FULL> SDF_DEV T ease_apply(int id, T t) {
         case EASE_in_sine: return -m_cos(t * pi / T(2)) + T(1);
         case EASE_out_sine: return m_sin(t * pi / T(2));
         case EASE_in_out_sine: return T(-0.5) * (m_cos(pi * t) - T(1));
-        case EASE_in_expo: return t == T(0) ? T(0) : m_pow2(T(10) * (t - T(1)));
-        case EASE_out_expo: return t == T(1) ? T(1) : T(1) - m_pow2(T(-10) * t);
+        case EASE_in_expo: return vsel(t == T(0), T(0), m_pow2(T(10) * (t - T(1))));
+        case EASE_out_expo: return vsel(t == T(1), T(1), T(1) - m_pow2(T(-10) * t));
         case EASE_in_out_expo:
-            if (t == T(0)) return T(0);
-            if (t == T(1)) return T(1);
-            return t < T(0.5) ? T(0.5) * m_pow2(T(20) * t - T(10)) : T(1) - T(0.5) * m_pow2(T(-20) * t + T(10));
+            a = vsel(t < T(0.5), T(0.5) * m_pow2(T(20) * t - T(10)), T(1) - T(0.5) * m_pow2(T(-20) * t + T(10)));
+            return vsel(t == T(0), T(0), vsel(t == T(1), T(1), a));
         case EASE_in_elastic: {
             const T k = T(0.5); u = t - T(1);
             return T(-1) * (m_pow2(T(10) * u) * m_sin((u - k / T(4)) * (T(2) * pi) / k)); }
@@ -146,16 +176,16 @@ template <typename T, bool FULL> SDF_DEV T ease_apply(int id, T t) {
             const T k = T(0.5); u = t * T(2); v = u - T(1);
             a = T(-0.5) * (m_pow2(T(10) * v) * m_sin((v - k / T(4)) * T(2) * pi / k));
             b = m_pow2(T(-10) * v) * m_sin((v - k / T(4)) * T(2) * pi / k) * T(0.5) + T(1);
-            return u < T(1) ? a : b; }
+            return vsel(u < T(1), a, b); }
         default: break;
         }
     }
-    return t - t + __builtin_nan("");   // unknown id
+    return t - t + T(__builtin_nan(""));   // unknown id
 }
 
 // ---- boolean folds: reference sdf/dn.py:7-58 ----------------------------------------------
-template <typename T> SDF_DEV T post_combine(uint32_t post, T d1, T d2, T K) {
-    T h, m;
+template <typename T, int N> SDF_DEV Vec<T, N> post_combine(uint32_t post, const Vec<T, N> &d1, const Vec<T, N> &d2, T K) {
+    Vec<T, N> h, m;
     switch (post) {   // wave-uniform
     case POST_SET: return d2;
     case POST_UNION: return np_min(d1, d2);
@@ -179,50 +209,81 @@ template <typename T> SDF_DEV T post_combine(uint32_t post, T d1, T d2, T K) {
 }
 
 // A small per-lane register file addressed by a WAVE-UNIFORM slot number.  A plain array indexed
-// by a run-time value would be placed in scratch memory by the compiler; the explicit switch keeps
-// the eight values in VGPRs and costs one scalar branch per access.
-template <typename T> struct RegFile8 {
-    T r0, r1, r2, r3, r4, r5, r6, r7;
-    SDF_DEV void clear() { r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = T(0); }
-    SDF_DEV T get(uint32_t s) const {
-        switch (s) {
-        case 0: return r0; case 1: return r1; case 2: return r2; case 3: return r3;
-        case 4: return r4; case 5: return r5; case 6: return r6; default: return r7;
-        }
-    }
-    SDF_DEV void set(uint32_t s, T v) {
-        switch (s) {
-        case 0: r0 = v; break; case 1: r1 = v; break; case 2: r2 = v; break; case 3: r3 = v; break;
-        case 4: r4 = v; break; case 5: r5 = v; break; case 6: r6 = v; break; default: r7 = v; break;
-        }
-    }
+// by a run-time value would be placed in scratch memory by the compiler (and so would a struct
+// whose members are picked by a switch: the optimiser merges the arms into one load through a phi
+// of member addresses).  Slots are therefore passed around BY VALUE and picked by a chain of
+// wave-uniform branches; the empty asm statements keep the arms from being merged back into
+// selects or pointer phis.  S is the number of slots the kernel variant provides (the host picks
+// the smallest variant that fits the tape: fewer slots = fewer VGPRs).
+template <typename V, int S> struct RegFile {
+    V r0, r1, r2, r3, r4, r5, r6, r7;
 };
-static_assert(SDF_NP_SLOTS == 8 && SDF_ND_SLOTS == 8, "RegFile8 holds eight slots");
+#define SDF_RF_ARM(K) asm volatile("; slot " #K)
+template <typename V, int S> SDF_DEV void rf_clear(RegFile<V, S> &f, const V &z) {
+    f.r0 = z;
+    if constexpr (S > 1) f.r1 = z;
+    if constexpr (S > 2) f.r2 = z;
+    if constexpr (S > 3) f.r3 = z;
+    if constexpr (S > 4) f.r4 = z;
+    if constexpr (S > 5) f.r5 = z;
+    if constexpr (S > 6) f.r6 = z;
+    if constexpr (S > 7) f.r7 = z;
+}
+// run STMT(rK) for the member rK selected by the wave-uniform slot number s
+#define SDF_RF_PICK(S_, s, STMT)                                              \
+    do {                                                                      \
+        if (S_ > 1 && (s) == 1) { SDF_RF_ARM(1); STMT(r1); SDF_RF_ARM(1); }       \
+        else if (S_ > 2 && (s) == 2) { SDF_RF_ARM(2); STMT(r2); SDF_RF_ARM(2); }  \
+        else if (S_ > 3 && (s) == 3) { SDF_RF_ARM(3); STMT(r3); SDF_RF_ARM(3); }  \
+        else if (S_ > 4 && (s) == 4) { SDF_RF_ARM(4); STMT(r4); SDF_RF_ARM(4); }  \
+        else if (S_ > 5 && (s) == 5) { SDF_RF_ARM(5); STMT(r5); SDF_RF_ARM(5); }  \
+        else if (S_ > 6 && (s) == 6) { SDF_RF_ARM(6); STMT(r6); SDF_RF_ARM(6); }  \
+        else if (S_ > 7 && (s) == 7) { SDF_RF_ARM(7); STMT(r7); SDF_RF_ARM(7); }  \
+        else { SDF_RF_ARM(0); STMT(r0); SDF_RF_ARM(0); }                          \
+    } while (0)
+static_assert(SDF_NP_SLOTS == 8 && SDF_ND_SLOTS == 8, "RegFile holds at most eight slots");
 
-template <typename T> SDF_DEV T box_like(T qx, T qy, T qz) {
+template <typename V> SDF_DEV V box_like(const V &qx, const V &qy, const V &qz) {
     // _length(_max(q, 0)) + _min(np.amax(q, axis=1), 0)
-    T mx = np_max(np_max(qx, qy), qz);
+    typedef decltype(qx.v[0] + qx.v[0]) T;
+    const V mx = np_max(np_max(qx, qy), qz);
     return len3(np_max(qx, T(0)), np_max(qy, T(0)), np_max(qz, T(0))) + np_min(mx, T(0));
 }
 
-// Run the whole tape for one sample.  FULL=false builds leave out the ops that need
-// sin/cos/atan2/hypot/fmod/pow (their ocml bodies cost registers); the host picks the variant
-// from the opcodes present in the tape.
-template <typename T, bool FULL>
-__device__ __forceinline__ T run_tape(const uint32_t *__restrict__ code, const T *__restrict__ consts, T x, T y, T z) {
-    T acc = T(0);
-    RegFile8<T> PSx, PSy, PSz, DS;
-    PSx.clear(); PSy.clear(); PSz.clear(); DS.clear();
+// Run the whole tape for NS samples per lane.  FULL=false builds leave out the ops that need
+// sin/cos/atan2/hypot/fmod/pow (their ocml bodies cost registers); NP / ND are the register-file
+// sizes; the host picks the variant from the opcodes and slot counts of the tape.
+template <typename T, bool FULL, int NP, int ND, int NS>
+__device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code, const T *__restrict__ consts,
+                                               Vec<T, NS> x, Vec<T, NS> y, Vec<T, NS> z) {
+    typedef Vec<T, NS> V;
+    V acc(T(0));
+    RegFile<V, NP> PSx, PSy, PSz;
+    RegFile<V, ND> DS;
+    rf_clear(PSx, V(T(0))); rf_clear(PSy, V(T(0))); rf_clear(PSz, V(T(0))); rf_clear(DS, V(T(0)));
 
-    for (uint32_t pc = 0;; pc += 2) {
-        const uint32_t w0 = __builtin_amdgcn_readfirstlane(code[pc]);
-        const uint32_t coff = __builtin_amdgcn_readfirstlane(code[pc + 1]);
-        const T *c = consts + coff + 1;          // c[-1] is K
+#define SDF_DGET_(R) _dst = DS.R
+#define SDF_DSET_(R) DS.R = _val
+#define SDF_PGET_(R) _px = PSx.R; _py = PSy.R; _pz = PSz.R
+#define SDF_PSET_(R) PSx.R = _px; PSy.R = _py; PSz.R = _pz
+#define DGET(OUT, s) do { V _dst; SDF_RF_PICK(ND, s, SDF_DGET_); OUT = _dst; } while (0)
+#define DSET(s, ...) do { const V _val = (__VA_ARGS__); SDF_RF_PICK(ND, s, SDF_DSET_); } while (0)
+#define PGET(s, X, Y, Z) do { V _px, _py, _pz; SDF_RF_PICK(NP, s, SDF_PGET_); X = _px; Y = _py; Z = _pz; } while (0)
+#define PSET(s, X, Y, Z) do { const V _px = (X), _py = (Y), _pz = (Z); SDF_RF_PICK(NP, s, SDF_PSET_); } while (0)
+
+    // the next instruction's words are requested before the current one executes, so their
+    // scalar-cache latency overlaps the constant loads and the arithmetic of this instruction
+    uint32_t w0 = __builtin_amdgcn_readfirstlane(code[0]);
+    uint32_t coff = __builtin_amdgcn_readfirstlane(code[1]);
+    for (uint32_t pc = 2;; pc += 2) {
         const uint32_t op = w0 & 255u, post = (w0 >> 8) & 255u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
-        T v = T(0), d1 = acc;
+        if (op == OP_END) return acc;
+        const T *c = consts + coff + 1;          // c[-1] is K
+        w0 = __builtin_amdgcn_readfirstlane(code[pc]);       // prefetch (the tape always ends in END)
+        coff = __builtin_amdgcn_readfirstlane(code[pc + 1]);
+        V v(T(0)), d1 = acc;
         bool produces = true;
         switch (op) {
-        case OP_END: return acc;
         // ---------------- 3-D leaves ----------------
         case OP_L_SPHERE:   // d3.py:92-96
             v = len3(x - c[1], y - c[2], z - c[3]) - c[0]; break;
@@ -234,72 +295,73 @@ __device__ __forceinline__ T run_tape(const uint32_t *__restrict__ code, const T
             v = box_like(m_fabs(x) - c[0] + c[3], m_fabs(y) - c[1] + c[3], m_fabs(z) - c[2] + c[3]) - c[3]; break;
         case OP_L_WIREFRAME_BOX: {  // d3.py:144-155
             const T t2 = c[3];
-            const T px = m_fabs(x) - c[0] - t2, py = m_fabs(y) - c[1] - t2, pz = m_fabs(z) - c[2] - t2;
-            const T qx = m_fabs(px + t2) - t2, qy = m_fabs(py + t2) - t2, qz = m_fabs(pz + t2) - t2;
-            auto g = [](T a, T b, T cc) {
+            const V px = m_fabs(x) - c[0] - t2, py = m_fabs(y) - c[1] - t2, pz = m_fabs(z) - c[2] - t2;
+            const V qx = m_fabs(px + t2) - t2, qy = m_fabs(py + t2) - t2, qz = m_fabs(pz + t2) - t2;
+            auto g = [](const V &a, const V &b, const V &cc) {
                 return len3(np_max(a, T(0)), np_max(b, T(0)), np_max(cc, T(0))) + np_min(np_max(a, np_max(b, cc)), T(0));
             };
             v = np_min(np_min(g(px, qy, qz), g(qx, py, qz)), g(qx, qy, pz)); break; }
         case OP_L_TORUS: {  // d3.py:157-165
-            const T a = len2(x, y) - c[0];
+            const V a = len2(x, y) - c[0];
             v = len2(a, z) - c[1]; break; }
         case OP_L_CAPSULE: {  // d3.py:167-176
-            const T pax = x - c[0], pay = y - c[1], paz = z - c[2];
-            const T h = np_clip(dot3(pax, pay, paz, c[3], c[4], c[5]) / c[6], T(0), T(1));
+            const V pax = x - c[0], pay = y - c[1], paz = z - c[2];
+            const V h = np_clip(dot3(pax, pay, paz, c[3], c[4], c[5]) / c[6], T(0), T(1));
             v = len3(pax - c[3] * h, pay - c[4] * h, paz - c[5] * h) - c[7]; break; }
         case OP_L_CYLINDER:  // d3.py:178-182
             v = len2(x, y) - c[0]; break;
         case OP_L_CAPPED_CYLINDER: {  // d3.py:184-204
             const T bax = c[3], bay = c[4], baz = c[5], baba = c[6];
-            const T pax = x - c[0], pay = y - c[1], paz = z - c[2];
-            const T paba = dot3(pax, pay, paz, bax, bay, baz);
-            const T xx = len3(pax * baba - bax * paba, pay * baba - bay * paba, paz * baba - baz * paba) - c[8];
-            const T yy = m_fabs(paba - c[9]) - c[9];
-            const T x2 = xx * xx, y2 = yy * yy * baba;
-            T d;
-            if (np_max(xx, yy) < T(0)) d = -np_min(x2, y2);
-            else d = (xx > T(0) ? x2 : T(0)) + (yy > T(0) ? y2 : T(0));
+            const V pax = x - c[0], pay = y - c[1], paz = z - c[2];
+            const V paba = dot3(pax, pay, paz, bax, bay, baz);
+            const V xx = len3(pax * baba - bax * paba, pay * baba - bay * paba, paz * baba - baz * paba) - c[8];
+            const V yy = m_fabs(paba - c[9]) - c[9];
+            const V x2 = xx * xx, y2 = yy * yy * baba;
+            const V din = -np_min(x2, y2);
+            const V dout = vsel(xx > T(0), x2, T(0)) + vsel(yy > T(0), y2, T(0));
+            const V d = vsel(np_max(xx, yy) < T(0), din, dout);
             v = np_sign(d) * m_sqrt(m_fabs(d)) / baba; break; }
         case OP_L_ROUNDED_CYLINDER: {  // d3.py:206-215
-            const T d0 = len2(x, y) - c[0] + c[1];
-            const T dd1 = m_fabs(z) - c[2] + c[1];
+            const V d0 = len2(x, y) - c[0] + c[1];
+            const V dd1 = m_fabs(z) - c[2] + c[1];
             v = np_min(np_max(d0, dd1), T(0)) + len2(np_max(d0, T(0)), np_max(dd1, T(0))) - c[1]; break; }
         case OP_L_CAPPED_CONE: {  // d3.py:217-237
             const T ra = c[6], rb = c[7], baba = c[8], rba = c[9], k = c[10];
-            const T pax = x - c[0], pay = y - c[1], paz = z - c[2];
-            const T papa = (pax * pax + pay * pay) + paz * paz;
-            const T paba = dot3(pax, pay, paz, c[3], c[4], c[5]) / baba;
-            const T xx = m_sqrt(papa - paba * paba * baba);
-            const T cax = np_max(T(0), xx - (paba < T(0.5) ? ra : rb));
-            const T cay = m_fabs(paba - T(0.5)) - T(0.5);
-            const T f = np_clip((rba * (xx - ra) + paba * baba) / k, T(0), T(1));
-            const T cbx = xx - ra - f * rba;
-            const T cby = paba - f;
-            const T s = (cbx < T(0) && cay < T(0)) ? T(-1) : T(1);
+            const V pax = x - c[0], pay = y - c[1], paz = z - c[2];
+            const V papa = (pax * pax + pay * pay) + paz * paz;
+            const V paba = dot3(pax, pay, paz, c[3], c[4], c[5]) / baba;
+            const V xx = m_sqrt(papa - paba * paba * baba);
+            const V cax = np_max(T(0), xx - vsel_s(paba < T(0.5), ra, rb));
+            const V cay = m_fabs(paba - T(0.5)) - T(0.5);
+            const V f = np_clip((rba * (xx - ra) + paba * baba) / k, T(0), T(1));
+            const V cbx = xx - ra - f * rba;
+            const V cby = paba - f;
+            const V s = vsel_s((cbx < T(0)) & (cay < T(0)), T(-1), T(1));
             v = s * m_sqrt(np_min(cax * cax + cay * cay * baba, cbx * cbx + cby * cby * baba)); break; }
         case OP_L_ROUNDED_CONE: {  // d3.py:239-250
             const T r1 = c[0], r2 = c[1], h = c[2], b = c[3], a = c[4], ah = c[5];
-            const T qx = len2(x, y), qy = z;
-            const T k = dot2(qx, qy, -b, a);
-            const T c1 = len2(qx, qy) - r1;
-            const T c2 = len2(qx - T(0), qy - h) - r2;
-            const T c3 = dot2(qx, qy, a, b) - r1;
-            v = k < T(0) ? c1 : (k > ah ? c2 : c3); break; }
+            const V qx = len2(x, y), qy = z;
+            const V k = dot2(qx, qy, -b, a);
+            const V c1 = len2(qx, qy) - r1;
+            const V c2 = len2(qx - T(0), qy - h) - r2;
+            const V c3 = dot2(qx, qy, a, b) - r1;
+            v = vsel(k < T(0), c1, vsel(k > ah, c2, c3)); break; }
         case OP_L_ELLIPSOID: {  // d3.py:252-259
-            const T k0 = len3(x / c[0], y / c[1], z / c[2]);
-            const T k1 = len3(x / c[3], y / c[4], z / c[5]);
+            const V k0 = len3(x / c[0], y / c[1], z / c[2]);
+            const V k1 = len3(x / c[3], y / c[4], z / c[5]);
             v = k0 * (k0 - T(1)) / k1; break; }
         case OP_L_PYRAMID: {  // d3.py:261-282
             const T h = c[0], m2 = c[1], m2q = c[2];
-            T a0 = m_fabs(x) - T(0.5), a1 = m_fabs(y) - T(0.5);
-            if (a1 > a0) { const T tmp = a0; a0 = a1; a1 = tmp; }
-            const T px = a0, py = z, pz = a1;
-            const T qx = pz, qy = h * py - T(0.5) * px, qz = h * px + T(0.5) * py;
-            const T s = np_max(-qx, T(0));
-            const T tt = np_clip((qy - T(0.5) * pz) / m2q, T(0), T(1));
-            const T a = m2 * ((qx + s) * (qx + s)) + qy * qy;
-            const T b = m2 * ((qx + T(0.5) * tt) * (qx + T(0.5) * tt)) + (qy - m2 * tt) * (qy - m2 * tt);
-            const T dd2 = np_min(qy, -qx * m2 - qy * T(0.5)) > T(0) ? T(0) : np_min(a, b);
+            const V b0 = m_fabs(x) - T(0.5), b1 = m_fabs(y) - T(0.5);
+            const Mask<NS> sw = b1 > b0;
+            const V a0 = vsel(sw, b1, b0), a1 = vsel(sw, b0, b1);
+            const V px = a0, py = z, pz = a1;
+            const V qx = pz, qy = h * py - T(0.5) * px, qz = h * px + T(0.5) * py;
+            const V s = np_max(-qx, T(0));
+            const V tt = np_clip((qy - T(0.5) * pz) / m2q, T(0), T(1));
+            const V a = m2 * ((qx + s) * (qx + s)) + qy * qy;
+            const V b = m2 * ((qx + T(0.5) * tt) * (qx + T(0.5) * tt)) + (qy - m2 * tt) * (qy - m2 * tt);
+            const V dd2 = vsel(np_min(qy, -qx * m2 - qy * T(0.5)) > T(0), T(0), np_min(a, b));
             v = m_sqrt((dd2 + qz * qz) / m2) * np_sign(np_max(qz, -py)); break; }
         case OP_L_TETRAHEDRON:  // d3.py:286-293
             v = (np_max(m_fabs(x + y) - z, m_fabs(x - y) + z) - c[0]) / c[1]; break;
@@ -307,14 +369,14 @@ __device__ __forceinline__ T run_tape(const uint32_t *__restrict__ code, const T
             v = (((m_fabs(x) + m_fabs(y)) + m_fabs(z)) - c[0]) * c[1]; break;
         case OP_L_DODECAHEDRON: {  // d3.py:301-311
             const T r = c[0], X = c[1], Y = c[2], Z = c[3];
-            const T ax = m_fabs(x / r), ay = m_fabs(y / r), az = m_fabs(z / r);
-            const T a = dot3(ax, ay, az, X, Y, Z), b = dot3(ax, ay, az, Z, X, Y), cc = dot3(ax, ay, az, Y, Z, X);
+            const V ax = m_fabs(x / r), ay = m_fabs(y / r), az = m_fabs(z / r);
+            const V a = dot3(ax, ay, az, X, Y, Z), b = dot3(ax, ay, az, Z, X, Y), cc = dot3(ax, ay, az, Y, Z, X);
             v = (np_max(np_max(a, b), cc) - X) * r; break; }
         case OP_L_ICOSAHEDRON: {  // d3.py:313-325
             const T r = c[0], X = c[1], Y = c[2], Z = c[3], w = c[4];
-            const T ax = m_fabs(x / r), ay = m_fabs(y / r), az = m_fabs(z / r);
-            const T a = dot3(ax, ay, az, X, Y, Z), b = dot3(ax, ay, az, Z, X, Y), cc = dot3(ax, ay, az, Y, Z, X);
-            const T d = dot3(ax, ay, az, w, w, w) - X;
+            const V ax = m_fabs(x / r), ay = m_fabs(y / r), az = m_fabs(z / r);
+            const V a = dot3(ax, ay, az, X, Y, Z), b = dot3(ax, ay, az, Z, X, Y), cc = dot3(ax, ay, az, Y, Z, X);
+            const V d = dot3(ax, ay, az, w, w, w) - X;
             v = np_max(np_max(np_max(a, b), cc) - X, d) * r; break; }
         // ---------------- 2-D leaves: the point is (x, y) ----------------
         case OP_L_CIRCLE:  // d2.py:76-80
@@ -322,61 +384,61 @@ __device__ __forceinline__ T run_tape(const uint32_t *__restrict__ code, const T
         case OP_L_LINE:    // d2.py:82-87
             v = dot2(c[2] - x, c[3] - y, c[0], c[1]); break;
         case OP_L_RECTANGLE: {  // d2.py:102-114
-            const T qx = m_fabs(x - c[0]) - c[2], qy = m_fabs(y - c[1]) - c[3];
+            const V qx = m_fabs(x - c[0]) - c[2], qy = m_fabs(y - c[1]) - c[3];
             v = len2(np_max(qx, T(0)), np_max(qy, T(0))) + np_min(np_max(qx, qy), T(0)); break; }
-        case OP_L_ROUNDED_RECTANGLE: {  // d2.py:116-134
-            T r = T(0);
-            if (x > T(0) && y > T(0)) r = c[2];
-            if (x > T(0) && y <= T(0)) r = c[3];
-            if (x <= T(0) && y <= T(0)) r = c[4];
-            if (x <= T(0) && y > T(0)) r = c[5];
-            const T qx = m_fabs(x) - c[0] + r, qy = m_fabs(y) - c[1] + r;
+        case OP_L_ROUNDED_RECTANGLE: {  // d2.py:116-134 (later assignments win, as in the reference)
+            const Mask<NS> xp = x > T(0), yp = y > T(0);
+            V r(T(0));
+            r = vsel(xp & yp, c[2], r);
+            r = vsel(xp & !yp, c[3], r);
+            r = vsel(!xp & !yp, c[4], r);
+            r = vsel(!xp & yp, c[5], r);
+            const V qx = m_fabs(x) - c[0] + r, qy = m_fabs(y) - c[1] + r;
             v = np_min(np_max(qx, qy), T(0)) + len2(np_max(qx, T(0)), np_max(qy, T(0))) - r; break; }
         case OP_L_EQUILATERAL_TRIANGLE: {  // d2.py:136-152
             const T k = c[0];
-            T px = m_fabs(x) - T(1), py = y + c[1];
-            if (px + k * py > T(0)) {
-                const T nx = (px - k * py) / T(2), ny = (-k * px - py) / T(2);
-                px = nx; py = ny;
-            }
+            V px = m_fabs(x) - T(1), py = y + c[1];
+            const Mask<NS> w = px + k * py > T(0);
+            const V nx = (px - k * py) / T(2), ny = (-k * px - py) / T(2);
+            px = vsel(w, nx, px); py = vsel(w, ny, py);
             px = px - np_clip(px, T(-2), T(0));
             v = -len2(px, py) * np_sign(py); break; }
         case OP_L_HEXAGON: {  // d2.py:154-165
             const T r = c[0], k0 = c[1], k1 = c[2];
-            T px = m_fabs(x), py = m_fabs(y);
-            const T m = np_min(k0 * px + k1 * py, T(0));
-            px -= c[4] * m; py -= c[5] * m;
-            px -= np_clip(px, c[6], c[7]); py -= (T(0) + r);
+            V px = m_fabs(x), py = m_fabs(y);
+            const V m = np_min(k0 * px + k1 * py, T(0));
+            px = px - c[4] * m; py = py - c[5] * m;
+            px = px - np_clip(px, c[6], c[7]); py = py - (T(0) + r);
             v = len2(px, py) * np_sign(py); break; }
         case OP_L_ROUNDED_X: {  // d2.py:167-173
-            const T px = m_fabs(x), py = m_fabs(y);
-            const T qq = np_min(px + py, c[0]) * T(0.5);
+            const V px = m_fabs(x), py = m_fabs(y);
+            const V qq = np_min(px + py, c[0]) * T(0.5);
             v = len2(px - qq, py - qq) - c[1]; break; }
         case OP_L_POLYGON: {  // d2.py:175-196
             const int np_ = (int)c[0];
             const T *pv = c + 1;
-            const T dx = x - pv[0], dy = y - pv[1];
-            T d = dx * dx + dy * dy;
-            T s = T(1);
+            const V dx = x - pv[0], dy = y - pv[1];
+            V d = dx * dx + dy * dy;
+            V s(T(1));
             for (int i = 0; i < np_; i++) {
                 const int j = (i + np_ - 1) % np_;
                 const T vix = pv[2 * i], viy = pv[2 * i + 1], vjx = pv[2 * j], vjy = pv[2 * j + 1];
                 const T ex = vjx - vix, ey = vjy - viy;
-                const T wx = x - vix, wy = y - viy;
-                const T ee = dot2(ex, ey, ex, ey);
-                const T cl = np_clip(dot2(wx, wy, ex, ey) / ee, T(0), T(1));
-                const T bx = wx - ex * cl, by = wy - ey * cl;
+                const V wx = x - vix, wy = y - viy;
+                const T ee = dot2s(ex, ey, ex, ey);
+                const V cl = np_clip(dot2(wx, wy, ex, ey) / ee, T(0), T(1));
+                const V bx = wx - ex * cl, by = wy - ey * cl;
                 d = np_min(d, bx * bx + by * by);
-                const bool c1 = y >= viy, c2 = y < vjy, c3 = ex * wy > ey * wx;
-                if ((c1 && c2 && c3) || (!c1 && !c2 && !c3)) s = -s;
+                const Mask<NS> c1 = y >= viy, c2 = y < vjy, c3 = ex * wy > ey * wx;
+                s = vsel((c1 & c2 & c3) | (!c1 & !c2 & !c3), -s, s);
             }
             v = s * m_sqrt(d); break; }
         case OP_L_VESICA: {  // d2.py:198-207
             const T r = c[0], d = c[1], b = c[2];
-            const T px = m_fabs(x), py = m_fabs(y);
-            v = ((py - b) * d > px * b) ? len2(px - T(0), py - b) : len2(px - (-d), py - T(0)) - r; break; }
+            const V px = m_fabs(x), py = m_fabs(y);
+            v = vsel((py - b) * d > px * b, len2(px - T(0), py - b), len2(px - (-d), py - T(0)) - r); break; }
         // ---------------- fold a parked distance ----------------
-        case OP_COMB: v = acc; d1 = DS.get(sa); break;
+        case OP_COMB: v = acc; DGET(d1, sa); break;
         default: produces = false; break;
         }
         if (produces) { acc = post_combine(post, d1, v, c[-1]); continue; }
@@ -388,116 +450,127 @@ __device__ __forceinline__ T run_tape(const uint32_t *__restrict__ code, const T
         case OP_SCALE:      // d3.py:335-345
             x = x / c[0]; y = y / c[1]; z = z / c[2]; break;
         case OP_ROTATE: {   // d3.py:347-360: p @ M, M row-major
-            const T nx = dot3(x, y, z, c[0], c[3], c[6]);
-            const T ny = dot3(x, y, z, c[1], c[4], c[7]);
-            const T nz = dot3(x, y, z, c[2], c[5], c[8]);
+            const V nx = dot3(x, y, z, c[0], c[3], c[6]);
+            const V ny = dot3(x, y, z, c[1], c[4], c[7]);
+            const V nz = dot3(x, y, z, c[2], c[5], c[8]);
             x = nx; y = ny; z = nz; break; }
         case OP_ELONGATE: {  // d3.py:396-405
-            const T qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1], qz = m_fabs(z) - c[2];
-            DS.set(sa, np_min(np_max(qx, np_max(qy, qz)), T(0)));
+            const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1], qz = m_fabs(z) - c[2];
+            DSET(sa, np_min(np_max(qx, np_max(qy, qz)), T(0)));
             x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); break; }
         case OP_BEND_LINEAR: {  // d3.py:435-445
-            T tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
-            tt = ease_apply<T, FULL>((int)c[10], tt);
+            V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
+            tt = ease_apply<T, FULL, NS>((int)c[10], tt);
             x = x + tt * c[7]; y = y + tt * c[8]; z = z + tt * c[9]; break; }
         case OP_REP_PREP: {  // dn.py:80-112: cell index of p
             const int dim = (int)c[0];
-            T idx[3] = {T(0), T(0), T(0)};
-            const T pp[3] = {x, y, z};
-#pragma unroll
+            V idx[3] = {V(T(0)), V(T(0)), V(T(0))};
+            const V pp[3] = {x, y, z};
+            SDF_UNROLL
             for (int i = 0; i < 3; i++) {
                 if (i < dim) {
                     const T s = c[1 + i];
-                    const T qq = s != T(0) ? pp[i] / s : T(0);
-                    T r = m_rint(qq);
+                    V r = m_rint(s != T(0) ? pp[i] / s : V(T(0)));
                     if (c[4] != T(0)) r = np_clip(r, -c[5 + i], c[5 + i]);
                     idx[i] = r;
                 }
             }
-            PSx.set(sa, idx[0]); PSy.set(sa, idx[1]); PSz.set(sa, idx[2]); break; }
+            PSET(sa, idx[0], idx[1], idx[2]); break; }
         case OP_REP_SET:   // p = p0 - spacing * (index + n)
-            x = PSx.get(sa) - c[0] * (PSx.get(sb) + c[3]);
-            y = PSy.get(sa) - c[1] * (PSy.get(sb) + c[4]);
-            z = PSz.get(sa) - c[2] * (PSz.get(sb) + c[5]); break;
+        {   V ax, ay, az, bx, by, bz;
+            PGET(sa, ax, ay, az); PGET(sb, bx, by, bz);
+            x = ax - c[0] * (bx + c[3]);
+            y = ay - c[1] * (by + c[4]);
+            z = az - c[2] * (bz + c[5]); break; }
         case OP_TRANSLATE2: x = x - c[0]; y = y - c[1]; break;   // d2.py:211-215
         case OP_SCALE2: x = x / c[0]; y = y / c[1]; break;       // d2.py:217-227
         case OP_ROTATE2: {  // d2.py:229-240
-            const T nx = dot2(x, y, c[0], c[2]), ny = dot2(x, y, c[1], c[3]);
+            const V nx = dot2(x, y, c[0], c[2]), ny = dot2(x, y, c[1], c[3]);
             x = nx; y = ny; break; }
         case OP_ELONGATE2: {  // d2.py:249-257
-            const T qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1];
-            DS.set(sa, np_min(np_max(qx, qy), T(0)));
+            const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1];
+            DSET(sa, np_min(np_max(qx, qy), T(0)));
             x = np_max(qx, T(0)); y = np_max(qy, T(0)); break; }
         case OP_REVOLVE: {  // d2.py:280-286
-            const T nx = len2(x, y) - c[0];
-            y = z; x = nx; z = T(0); break; }
-        case OP_SETZ0: z = T(0); break;                           // d3.py:513
-        case OP_SAVE_P: PSx.set(sa, x); PSy.set(sa, y); PSz.set(sa, z); break;
-        case OP_LOAD_P: x = PSx.get(sa); y = PSy.get(sa); z = PSz.get(sa); break;
+            const V nx = len2(x, y) - c[0];
+            y = z; x = nx; z = V(T(0)); break; }
+        case OP_SETZ0: z = V(T(0)); break;                        // d3.py:513
+        case OP_SAVE_P: PSET(sa, x, y, z); break;
+        case OP_LOAD_P: PGET(sa, x, y, z); break;
         // ---------------- distance ops ----------------
-        case OP_PUSH_D: DS.set(sa, acc); break;
+        case OP_PUSH_D: DSET(sa, acc); break;
         case OP_NEG: acc = -acc; break;                            // dn.py:60-63
         case OP_ADDC: acc = acc + c[0]; break;                     // dn.py:70-73
         case OP_SUBC: acc = acc - c[0]; break;                     // dn.py:65-68
         case OP_MULC: acc = acc * c[0]; break;                     // d3.py:344
         case OP_SHELL: acc = m_fabs(acc) - c[0]; break;            // dn.py:75-78
-        case OP_ADD_DS: acc = acc + DS.get(sa); break;                 // d3.py:405
+        case OP_ADD_DS: { V t; DGET(t, sa); acc = acc + t; break; }   // d3.py:405
         case OP_TRANS_LIN_PRE: {  // d3.py:459-470
-            const T tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
-            DS.set(sa, ease_apply<T, FULL>((int)c[7], tt)); break; }
+            const V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
+            DSET(sa, ease_apply<T, FULL, NS>((int)c[7], tt)); break; }
         case OP_TRANS_MIX: {  // t * d2 + (1 - t) * d1
-            const T tt = DS.get(sa);
-            acc = tt * acc + (T(1) - tt) * DS.get(sb); break; }
-        case OP_EXT_PRE: DS.set(sa, m_fabs(z) - c[0]); break;         // d2.py:264-266
+            V tt, dd; DGET(tt, sa); DGET(dd, sb);
+            acc = tt * acc + (T(1) - tt) * dd; break; }
+        case OP_EXT_PRE: DSET(sa, m_fabs(z) - c[0]); break;      // d2.py:264-266
         case OP_EXT_POST: {  // d2.py:267
-            const T w1 = DS.get(sa);
+            V w1; DGET(w1, sa);
             acc = np_min(np_max(acc, w1), T(0)) + len2(np_max(acc, T(0)), np_max(w1, T(0))); break; }
         case OP_EXTTO_PRE:   // d2.py:274
-            DS.set(sa, ease_apply<T, FULL>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5))); break;
+            DSET(sa, ease_apply<T, FULL, NS>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5))); break;
         case OP_EXTTO_MIX: {  // d2.py:275
-            const T dd1 = DS.get(sb);
-            acc = dd1 + (acc - dd1) * DS.get(sa); break; }
+            V dd1, tt; DGET(dd1, sb); DGET(tt, sa);
+            acc = dd1 + (acc - dd1) * tt; break; }
         case OP_SLICE_POST: {  // d3.py:515-519
-            const T A = DS.get(sa), B = -acc;
-            acc = A <= T(0) ? B : A; break; }
+            V A; DGET(A, sa); const V B = -acc;
+            acc = vsel(A <= T(0), B, A); break; }
         default:
             if constexpr (FULL) {
                 switch (op) {
                 case OP_TWIST: {  // d3.py:407-419
-                    const T cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
-                    const T nx = cc * x - s * y, ny = s * x + cc * y;
+                    const V cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
+                    const V nx = cc * x - s * y, ny = s * x + cc * y;
                     x = nx; y = ny; break; }
                 case OP_BEND: {   // d3.py:421-433
-                    const T cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
-                    const T nx = cc * x - s * y, ny = s * x + cc * y;
+                    const V cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
+                    const V nx = cc * x - s * y, ny = s * x + cc * y;
                     x = nx; y = ny; break; }
                 case OP_BEND_RADIAL: {  // d3.py:447-457
-                    const T r = m_hypot(x, y);
-                    const T tt = np_clip((r - c[0]) / c[1], T(0), T(1));
-                    z = z - c[2] * ease_apply<T, FULL>((int)c[3], tt); break; }
+                    const V r = m_hypot(x, y);
+                    const V tt = np_clip((r - c[0]) / c[1], T(0), T(1));
+                    z = z - c[2] * ease_apply<T, FULL, NS>((int)c[3], tt); break; }
                 case OP_WRAP_AROUND: {  // d3.py:483-502
                     const T pi = T(3.141592653589793);
-                    const T d = m_hypot(x, y) - c[9];
-                    const T a = m_atan2(y, x);
-                    const T tt = ease_apply<T, FULL>((int)c[10], (a + pi) / (T(2) * pi));
+                    const V d = m_hypot(x, y) - c[9];
+                    const V a = m_atan2(y, x);
+                    const V tt = ease_apply<T, FULL, NS>((int)c[10], (a + pi) / (T(2) * pi));
                     x = c[0] + c[3] * tt + c[6] * d;
                     y = c[1] + c[4] * tt + c[7] * d; break; }
                 case OP_CIRC_PREP: {  // d3.py:379-392: PS[sa] = (d, a, z)
-                    PSx.set(sa, m_hypot(x, y));
-                    PSy.set(sa, np_mod(m_atan2(y, x), c[0]));
-                    PSz.set(sa, z); break; }
+                    PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); break; }
                 case OP_CIRC_SET: {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
-                    const T ang = PSy.get(sa) - c[0], d = PSx.get(sa);
-                    x = m_cos(ang) * d; y = m_sin(ang) * d; z = PSz.get(sa); break; }
+                    V d, a0, z0; PGET(sa, d, a0, z0);
+                    const V ang = a0 - c[0];
+                    x = m_cos(ang) * d; y = m_sin(ang) * d; z = z0; break; }
                 case OP_TRANS_RAD_PRE: {  // d3.py:472-481
-                    const T r = m_hypot(x, y);
-                    DS.set(sa, ease_apply<T, FULL>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); break; }
+                    const V r = m_hypot(x, y);
+                    DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); break; }
                 default: break;
                 }
             }
             break;
         }
     }
+}
+
+#undef DGET
+#undef DSET
+#undef PGET
+#undef PSET
+
+// one sample per lane, the largest register files: the variant the non-hot kernels use
+template <typename T, bool FULL>
+__device__ __forceinline__ T run_tape1(const uint32_t *__restrict__ code, const T *__restrict__ consts, T x, T y, T z) {
+    return run_tape<T, FULL, SDF_NP_SLOTS, SDF_ND_SLOTS, 1>(code, consts, Vec<T, 1>(x), Vec<T, 1>(y), Vec<T, 1>(z)).v[0];
 }
 
 }  // namespace sdfk
