@@ -7,7 +7,9 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
+# -structurizecfg-skip-uniform-regions: every branch of the interpreter is wave-uniform; without it
+# the backend structurises the dispatch tree anyway and pays ~100 register copies per tape instruction
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -mllvm -structurizecfg-skip-uniform-regions=1"
 mkdir -p build
 pids=""
 $HIPCC $FLAGS -c -o build/sdf_hip.o sdf_hip.hip "$@" & pids="$pids $!"

@@ -58,6 +58,7 @@ struct MeshArgs {
     MeshCounters *ctr;
     int list_off;                  // byte offset of the triangle work list in dynamic LDS
     int list_cap;                  // its capacity in entries
+    unsigned long long *prof;      // NULL, or 8 phase cycle counters (SDF_MESH_PROF=1 diagnostics)
 };
 
 // dynamic LDS layout of k_mesh
@@ -137,6 +138,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
 
     if (tid < 256) ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
 
+    long long tprev = a.prof ? clock64() : 0;
+#define SDF_PROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     for (;;) {
         if (tid == 0) bcast[0] = a.work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
         __syncthreads();
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
         else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
         __syncthreads();
+        SDF_PROF(0);
 
         // ---- 1. sample: volume = sdf(P).reshape(shape), cast to float32 (core.py:50-52) ----
         const int nvox = lx * ly * lz;
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
         }
         __syncthreads();
+        SDF_PROF(1);
 
         // ---- 2. count: a thread owns the i2-rows of cells (i0, i1) = row tid + k * BLOCK ----
         const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         __syncthreads();
         const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
         const bool fits = base + (unsigned long long)total <= a.arena_cap;
+        SDF_PROF(2);
 
         // ---- 3 + 4. per-triangle work list in LDS, then one lane per triangle ----
         for (int lo = 0; fits && lo < total; lo += a.list_cap) {
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 }
             }
             __syncthreads();
+            SDF_PROF(3);
             float *dst0 = a.arena + (base + (unsigned long long)lo) * 9ull;
             for (int t = tid; t < cn; t += BLOCK) {
                 const unsigned e = list[t];
@@ -258,14 +265,17 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 for (int q = 0; q < 9; q++) dst[q] = o[q];
             }
             __syncthreads();   // list / vol are reused
+            SDF_PROF(4);
         }
         __syncthreads();   // vol / bcast are reused by the next batch
     }
+    SDF_PROF(5);
+#undef SDF_PROF
 }
 
 // host-side launcher of one (T, FULL) family, defined in sdf_mesh_inst.hip (one translation
 // unit per family so the variants compile in parallel).  slots: 0 = (2,2), 1 = (4,4), 2 = (8,8)
-// register files; shape: 0 = 1024 threads x 1 sample, 1 = 512 x 2, 2 = 256 x 4.
+// register files; shape: 0 = 1024 threads x 1 sample, 1 = 512 x 2, 2 = 256 x 4, 3 = 1024 x 2.
 #define SDF_DECLARE_MESH_LAUNCH(NAME, T) \
     int NAME(int slots, int shape, int grid, size_t lds, hipStream_t stream, const uint32_t *code, const T *consts, const MeshArgs &a)
 SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f64, double);

@@ -273,6 +273,7 @@ struct sdf_ctx {
     size_t lds_max = 0;
     DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, counters, nwork, scratch_in, scratch_out, rows, rows_off, mc;
     int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
+    DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
     std::vector<DevBuf> arena_pool;   // arenas handed back by destroyed meshes
     unsigned long long last_tris_per_batch = 0;
@@ -372,6 +373,7 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     HIPCHK(hipMemcpy(c->mc.p, &t, sizeof(t), hipMemcpyHostToDevice));
     if (const char *e = getenv("SDF_MESH_SHAPE")) c->mesh_shape = atoi(e);
     if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
+    if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(64)) return 1; }
     *out = c;
     return 0;
 }
@@ -381,7 +383,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->axes, &c->kinds, &c->worklist, &c->batch_count, &c->batch_base, &c->batch_final, &c->counters,
-                      &c->nwork, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc})
+                      &c->nwork, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof})
         b->release();
     for (auto &b : c->arena_pool) b.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -559,8 +561,10 @@ static int launch_mesh(sdf_tape *t, int precision, MeshArgs &a, int grid, int bs
     const uint32_t need = std::max(t->n_p, t->n_d);
     int slots = need <= 2 ? 0 : (need <= 4 ? 1 : 2);
     if (c->mesh_slots >= 0) slots = std::max(slots, std::min(c->mesh_slots, 2));
-    int shape = 1;
-    if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 2);
+    // measured on the 512^3 example: 4 waves per SIMD beat 2, and two samples per lane
+    // beat one whenever the variant still fits 128 VGPRs
+    int shape = slots == 0 ? 3 : 0;
+    if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
     int rc;
     if (precision == SDF_PRECISION_F64)
         rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, grid, lds, c->stream, t->d_code, t->d_c64, a)
@@ -640,6 +644,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             const int grid = std::min(nshard, c->n_cu);
             HIPCHK(hipEventRecord(c->ev[3], c->stream));
             a.mc = (const McTables *)c->mc.p;
+            a.prof = (unsigned long long *)c->prof.p;
+            if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 64, c->stream));
             if (launch_mesh(t, precision, a, grid, bs)) return 1;
             HIPCHK(hipEventRecord(c->ev[4], c->stream));
             hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)m->batch_count.p, m->work_begin,
@@ -650,6 +656,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
             m->st.ms_mesh = ms;
+            if (c->prof.p) {
+                unsigned long long pc[8];
+                HIPCHK(hipMemcpy(pc, c->prof.p, 64, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu list %llu emit %llu tail %llu\n",
+                        ms, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5]);
+            }
             m->st.n_retries = attempt;
             if (h.overflow) {
                 if (attempt >= 3) return fail("sdf_generate: triangle arena overflow persists");

@@ -281,8 +281,9 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
         const T *c = consts + coff + 1;          // c[-1] is K
         w0 = __builtin_amdgcn_readfirstlane(code[pc]);       // prefetch (the tape always ends in END)
         coff = __builtin_amdgcn_readfirstlane(code[pc + 1]);
-        V v(T(0)), d1 = acc;
-        bool produces = true;
+        // a case that `break`s has produced a leaf value v, folded into acc below; every other
+        // case `continue`s (one switch, no flags: the dispatch is a tree of wave-uniform branches)
+        V v;
         switch (op) {
         // ---------------- 3-D leaves ----------------
         case OP_L_SPHERE:   // d3.py:92-96
@@ -438,30 +439,25 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const V px = m_fabs(x), py = m_fabs(y);
             v = vsel((py - b) * d > px * b, len2(px - T(0), py - b), len2(px - (-d), py - T(0)) - r); break; }
         // ---------------- fold a parked distance ----------------
-        case OP_COMB: v = acc; DGET(d1, sa); break;
-        default: produces = false; break;
-        }
-        if (produces) { acc = post_combine(post, d1, v, c[-1]); continue; }
-
-        switch (op) {
+        case OP_COMB: { V d1; DGET(d1, sa); acc = post_combine(post, d1, acc, c[-1]); continue; }
         // ---------------- point ops ----------------
         case OP_TRANSLATE:  // d3.py:329-333
-            x = x - c[0]; y = y - c[1]; z = z - c[2]; break;
+            x = x - c[0]; y = y - c[1]; z = z - c[2]; continue;
         case OP_SCALE:      // d3.py:335-345
-            x = x / c[0]; y = y / c[1]; z = z / c[2]; break;
+            x = x / c[0]; y = y / c[1]; z = z / c[2]; continue;
         case OP_ROTATE: {   // d3.py:347-360: p @ M, M row-major
             const V nx = dot3(x, y, z, c[0], c[3], c[6]);
             const V ny = dot3(x, y, z, c[1], c[4], c[7]);
             const V nz = dot3(x, y, z, c[2], c[5], c[8]);
-            x = nx; y = ny; z = nz; break; }
+            x = nx; y = ny; z = nz; continue; }
         case OP_ELONGATE: {  // d3.py:396-405
             const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1], qz = m_fabs(z) - c[2];
             DSET(sa, np_min(np_max(qx, np_max(qy, qz)), T(0)));
-            x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); break; }
+            x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); continue; }
         case OP_BEND_LINEAR: {  // d3.py:435-445
             V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
             tt = ease_apply<T, FULL, NS>((int)c[10], tt);
-            x = x + tt * c[7]; y = y + tt * c[8]; z = z + tt * c[9]; break; }
+            x = x + tt * c[7]; y = y + tt * c[8]; z = z + tt * c[9]; continue; }
         case OP_REP_PREP: {  // dn.py:80-112: cell index of p
             const int dim = (int)c[0];
             V idx[3] = {V(T(0)), V(T(0)), V(T(0))};
@@ -475,90 +471,91 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
                     idx[i] = r;
                 }
             }
-            PSET(sa, idx[0], idx[1], idx[2]); break; }
+            PSET(sa, idx[0], idx[1], idx[2]); continue; }
         case OP_REP_SET:   // p = p0 - spacing * (index + n)
         {   V ax, ay, az, bx, by, bz;
             PGET(sa, ax, ay, az); PGET(sb, bx, by, bz);
             x = ax - c[0] * (bx + c[3]);
             y = ay - c[1] * (by + c[4]);
-            z = az - c[2] * (bz + c[5]); break; }
-        case OP_TRANSLATE2: x = x - c[0]; y = y - c[1]; break;   // d2.py:211-215
-        case OP_SCALE2: x = x / c[0]; y = y / c[1]; break;       // d2.py:217-227
+            z = az - c[2] * (bz + c[5]); continue; }
+        case OP_TRANSLATE2: x = x - c[0]; y = y - c[1]; continue;   // d2.py:211-215
+        case OP_SCALE2: x = x / c[0]; y = y / c[1]; continue;       // d2.py:217-227
         case OP_ROTATE2: {  // d2.py:229-240
             const V nx = dot2(x, y, c[0], c[2]), ny = dot2(x, y, c[1], c[3]);
-            x = nx; y = ny; break; }
+            x = nx; y = ny; continue; }
         case OP_ELONGATE2: {  // d2.py:249-257
             const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1];
             DSET(sa, np_min(np_max(qx, qy), T(0)));
-            x = np_max(qx, T(0)); y = np_max(qy, T(0)); break; }
+            x = np_max(qx, T(0)); y = np_max(qy, T(0)); continue; }
         case OP_REVOLVE: {  // d2.py:280-286
             const V nx = len2(x, y) - c[0];
-            y = z; x = nx; z = V(T(0)); break; }
-        case OP_SETZ0: z = V(T(0)); break;                        // d3.py:513
-        case OP_SAVE_P: PSET(sa, x, y, z); break;
-        case OP_LOAD_P: PGET(sa, x, y, z); break;
+            y = z; x = nx; z = V(T(0)); continue; }
+        case OP_SETZ0: z = V(T(0)); continue;                        // d3.py:513
+        case OP_SAVE_P: PSET(sa, x, y, z); continue;
+        case OP_LOAD_P: PGET(sa, x, y, z); continue;
         // ---------------- distance ops ----------------
-        case OP_PUSH_D: DSET(sa, acc); break;
-        case OP_NEG: acc = -acc; break;                            // dn.py:60-63
-        case OP_ADDC: acc = acc + c[0]; break;                     // dn.py:70-73
-        case OP_SUBC: acc = acc - c[0]; break;                     // dn.py:65-68
-        case OP_MULC: acc = acc * c[0]; break;                     // d3.py:344
-        case OP_SHELL: acc = m_fabs(acc) - c[0]; break;            // dn.py:75-78
-        case OP_ADD_DS: { V t; DGET(t, sa); acc = acc + t; break; }   // d3.py:405
+        case OP_PUSH_D: DSET(sa, acc); continue;
+        case OP_NEG: acc = -acc; continue;                            // dn.py:60-63
+        case OP_ADDC: acc = acc + c[0]; continue;                     // dn.py:70-73
+        case OP_SUBC: acc = acc - c[0]; continue;                     // dn.py:65-68
+        case OP_MULC: acc = acc * c[0]; continue;                     // d3.py:344
+        case OP_SHELL: acc = m_fabs(acc) - c[0]; continue;            // dn.py:75-78
+        case OP_ADD_DS: { V t; DGET(t, sa); acc = acc + t; continue; }   // d3.py:405
         case OP_TRANS_LIN_PRE: {  // d3.py:459-470
             const V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
-            DSET(sa, ease_apply<T, FULL, NS>((int)c[7], tt)); break; }
+            DSET(sa, ease_apply<T, FULL, NS>((int)c[7], tt)); continue; }
         case OP_TRANS_MIX: {  // t * d2 + (1 - t) * d1
             V tt, dd; DGET(tt, sa); DGET(dd, sb);
-            acc = tt * acc + (T(1) - tt) * dd; break; }
-        case OP_EXT_PRE: DSET(sa, m_fabs(z) - c[0]); break;      // d2.py:264-266
+            acc = tt * acc + (T(1) - tt) * dd; continue; }
+        case OP_EXT_PRE: DSET(sa, m_fabs(z) - c[0]); continue;      // d2.py:264-266
         case OP_EXT_POST: {  // d2.py:267
             V w1; DGET(w1, sa);
-            acc = np_min(np_max(acc, w1), T(0)) + len2(np_max(acc, T(0)), np_max(w1, T(0))); break; }
+            acc = np_min(np_max(acc, w1), T(0)) + len2(np_max(acc, T(0)), np_max(w1, T(0))); continue; }
         case OP_EXTTO_PRE:   // d2.py:274
-            DSET(sa, ease_apply<T, FULL, NS>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5))); break;
+            DSET(sa, ease_apply<T, FULL, NS>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5))); continue;
         case OP_EXTTO_MIX: {  // d2.py:275
             V dd1, tt; DGET(dd1, sb); DGET(tt, sa);
-            acc = dd1 + (acc - dd1) * tt; break; }
+            acc = dd1 + (acc - dd1) * tt; continue; }
         case OP_SLICE_POST: {  // d3.py:515-519
             V A; DGET(A, sa); const V B = -acc;
-            acc = vsel(A <= T(0), B, A); break; }
+            acc = vsel(A <= T(0), B, A); continue; }
         default:
             if constexpr (FULL) {
                 switch (op) {
                 case OP_TWIST: {  // d3.py:407-419
                     const V cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
                     const V nx = cc * x - s * y, ny = s * x + cc * y;
-                    x = nx; y = ny; break; }
+                    x = nx; y = ny; continue; }
                 case OP_BEND: {   // d3.py:421-433
                     const V cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
                     const V nx = cc * x - s * y, ny = s * x + cc * y;
-                    x = nx; y = ny; break; }
+                    x = nx; y = ny; continue; }
                 case OP_BEND_RADIAL: {  // d3.py:447-457
                     const V r = m_hypot(x, y);
                     const V tt = np_clip((r - c[0]) / c[1], T(0), T(1));
-                    z = z - c[2] * ease_apply<T, FULL, NS>((int)c[3], tt); break; }
+                    z = z - c[2] * ease_apply<T, FULL, NS>((int)c[3], tt); continue; }
                 case OP_WRAP_AROUND: {  // d3.py:483-502
                     const T pi = T(3.141592653589793);
                     const V d = m_hypot(x, y) - c[9];
                     const V a = m_atan2(y, x);
                     const V tt = ease_apply<T, FULL, NS>((int)c[10], (a + pi) / (T(2) * pi));
                     x = c[0] + c[3] * tt + c[6] * d;
-                    y = c[1] + c[4] * tt + c[7] * d; break; }
+                    y = c[1] + c[4] * tt + c[7] * d; continue; }
                 case OP_CIRC_PREP: {  // d3.py:379-392: PS[sa] = (d, a, z)
-                    PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); break; }
+                    PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); continue; }
                 case OP_CIRC_SET: {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
                     V d, a0, z0; PGET(sa, d, a0, z0);
                     const V ang = a0 - c[0];
-                    x = m_cos(ang) * d; y = m_sin(ang) * d; z = z0; break; }
+                    x = m_cos(ang) * d; y = m_sin(ang) * d; z = z0; continue; }
                 case OP_TRANS_RAD_PRE: {  // d3.py:472-481
                     const V r = m_hypot(x, y);
-                    DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); break; }
-                default: break;
+                    DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); continue; }
+                default: continue;
                 }
             }
-            break;
+            continue;
         }
+        acc = post_combine(post, acc, v, c[-1]);
     }
 }
 

@@ -73,13 +73,13 @@ def main():
         if k in stats:
             out['kernels'][k]['avg_us'] = stats[k]['avg_us']
     tris = bench_line['config']['triangles'] if bench_line else None
-    dom = next((k for k in per if k.startswith('k_mesh')), None)
+    dom = next((k for k in per if 'k_mesh' in k), None)
     if dom:
         d = out['kernels'][dom]
         fetch_kib = d.get('FETCH_SIZE', {}).get('mean')
         write_kib = d.get('WRITE_SIZE', {}).get('mean')
         cal = None
-        g = next((k for k in per if k.startswith('k_gather')), None)
+        g = next((k for k in per if 'k_gather' in k), None)
         if g and tris and 'WRITE_SIZE' in out['kernels'][g]:
             cal = (72.0 * tris) / (out['kernels'][g]['WRITE_SIZE']['mean'] * 1024.0)
         hbm = None
