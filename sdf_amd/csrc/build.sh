@@ -11,6 +11,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # the backend structurises the dispatch tree anyway and pays ~100 register copies per tape instruction
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -mllvm -structurizecfg-skip-uniform-regions=1"
 mkdir -p build
+rm -f libsdf_hip.so build/*.o
 pids=""
 $HIPCC $FLAGS -c -o build/sdf_hip.o sdf_hip.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f64 -c -o build/mesh_f64.o sdf_mesh_inst.hip "$@" & pids="$pids $!"

@@ -37,18 +37,34 @@ SDF_DEV double m_fabs(double x) { return fabs(x); }
 SDF_DEV float m_fabs(float x) { return fabsf(x); }
 SDF_DEV double m_rint(double x) { return rint(x); }
 SDF_DEV float m_rint(float x) { return rintf(x); }
-SDF_DEV double m_sin(double x) { return sin(x); }
-SDF_DEV float m_sin(float x) { return sinf(x); }
-SDF_DEV double m_cos(double x) { return cos(x); }
-SDF_DEV float m_cos(float x) { return cosf(x); }
-SDF_DEV double m_atan2(double y, double x) { return atan2(y, x); }
-SDF_DEV float m_atan2(float y, float x) { return atan2f(y, x); }
-SDF_DEV double m_hypot(double x, double y) { return hypot(x, y); }
-SDF_DEV float m_hypot(float x, float y) { return hypotf(x, y); }
-SDF_DEV double m_fmod(double x, double y) { return fmod(x, y); }
-SDF_DEV float m_fmod(float x, float y) { return fmodf(x, y); }
-SDF_DEV double m_pow2(double x) { return pow(2.0, x); }
-SDF_DEV float m_pow2(float x) { return powf(2.0f, x); }
+// The libm bodies (ocml: argument reduction, polynomial tables) are large -- inlined at every use
+// they made the trig-capable kernels 370 KB of code.  They are outlined: one copy per translation
+// unit, reached by s_swappc; the call overhead is small next to the functions themselves.
+#define SDF_OUTLINE static __device__ __attribute__((noinline))
+SDF_OUTLINE double o_sin(double x) { return sin(x); }
+SDF_OUTLINE float o_sin(float x) { return sinf(x); }
+SDF_OUTLINE double o_cos(double x) { return cos(x); }
+SDF_OUTLINE float o_cos(float x) { return cosf(x); }
+SDF_OUTLINE double o_atan2(double y, double x) { return atan2(y, x); }
+SDF_OUTLINE float o_atan2(float y, float x) { return atan2f(y, x); }
+SDF_OUTLINE double o_hypot(double x, double y) { return hypot(x, y); }
+SDF_OUTLINE float o_hypot(float x, float y) { return hypotf(x, y); }
+SDF_OUTLINE double o_fmod(double x, double y) { return fmod(x, y); }
+SDF_OUTLINE float o_fmod(float x, float y) { return fmodf(x, y); }
+SDF_OUTLINE double o_pow2(double x) { return pow(2.0, x); }
+SDF_OUTLINE float o_pow2(float x) { return powf(2.0f, x); }
+SDF_DEV double m_sin(double x) { return o_sin(x); }
+SDF_DEV float m_sin(float x) { return o_sin(x); }
+SDF_DEV double m_cos(double x) { return o_cos(x); }
+SDF_DEV float m_cos(float x) { return o_cos(x); }
+SDF_DEV double m_atan2(double y, double x) { return o_atan2(y, x); }
+SDF_DEV float m_atan2(float y, float x) { return o_atan2(y, x); }
+SDF_DEV double m_hypot(double x, double y) { return o_hypot(x, y); }
+SDF_DEV float m_hypot(float x, float y) { return o_hypot(x, y); }
+SDF_DEV double m_fmod(double x, double y) { return o_fmod(x, y); }
+SDF_DEV float m_fmod(float x, float y) { return o_fmod(x, y); }
+SDF_DEV double m_pow2(double x) { return o_pow2(x); }
+SDF_DEV float m_pow2(float x) { return o_pow2(x); }
 SDF_DEV double m_copysign(double x, double y) { return copysign(x, y); }
 SDF_DEV float m_copysign(float x, float y) { return copysignf(x, y); }
 
@@ -250,6 +266,9 @@ template <typename V> SDF_DEV V box_like(const V &qx, const V &qy, const V &qz) 
     return len3(np_max(qx, T(0)), np_max(qy, T(0)), np_max(qz, T(0))) + np_min(mx, T(0));
 }
 
+#define SDF_JT_ROW(NAME) "s_branch %l[L_" #NAME "]\n\t"
+#define SDF_JT_LABEL(NAME) L_##NAME,
+
 // Run the whole tape for NS samples per lane.  FULL=false builds leave out the ops that need
 // sin/cos/atan2/hypot/fmod/pow (their ocml bodies cost registers); NP / ND are the register-file
 // sizes; the host picks the variant from the opcodes and slot counts of the tape.
@@ -277,41 +296,54 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
     uint32_t coff = __builtin_amdgcn_readfirstlane(code[1]);
     for (uint32_t pc = 2;; pc += 2) {
         const uint32_t op = w0 & 255u, post = (w0 >> 8) & 255u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
-        if (op == OP_END) return acc;
+        if (op == OP_END) return acc;   // (the table row of END is never taken)
         const T *c = consts + coff + 1;          // c[-1] is K
         w0 = __builtin_amdgcn_readfirstlane(code[pc]);       // prefetch (the tape always ends in END)
         coff = __builtin_amdgcn_readfirstlane(code[pc + 1]);
-        // a case that `break`s has produced a leaf value v, folded into acc below; every other
-        // case `continue`s (one switch, no flags: the dispatch is a tree of wave-uniform branches)
+        // Dispatch: ONE indirect jump through a table of s_branch instructions (the compiler only
+        // offers a compare-and-branch tree for `switch`, and every taken branch costs an instruction
+        // buffer refill).  s_getpc returns the address A of the instruction after it; the table
+        // starts at A + 12 (three 4-byte SALU instructions), so the target is A + 4 * (op + 3).
+        // s_lshl2_add_u32 leaves the carry of the 32-bit add in SCC for the s_addc.
+        // A leaf computes v and jumps to `fold`; every other op `continue`s.
         V v;
-        switch (op) {
+        const uint32_t jt = op + 3u;
+        asm goto(
+            "s_getpc_b64 vcc\n\t"
+            "s_lshl2_add_u32 vcc_lo, %0, vcc_lo\n\t"
+            "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+            "s_setpc_b64 vcc\n\t"
+            SDF_OPCODE_LIST(SDF_JT_ROW)
+            : : "s"(jt) : "vcc", "scc" : SDF_OPCODE_LIST(SDF_JT_LABEL) L_BAD);
+        continue;   // never reached: the asm always jumps (kept inside the loop for the CFG passes)
+        {
         // ---------------- 3-D leaves ----------------
-        case OP_L_SPHERE:   // d3.py:92-96
-            v = len3(x - c[1], y - c[2], z - c[3]) - c[0]; break;
-        case OP_L_PLANE:    // d3.py:98-103
-            v = dot3(c[3] - x, c[4] - y, c[5] - z, c[0], c[1], c[2]); break;
-        case OP_L_BOX:      // d3.py:122-134
-            v = box_like(m_fabs(x - c[0]) - c[3], m_fabs(y - c[1]) - c[4], m_fabs(z - c[2]) - c[5]); break;
-        case OP_L_ROUNDED_BOX:  // d3.py:136-142
-            v = box_like(m_fabs(x) - c[0] + c[3], m_fabs(y) - c[1] + c[3], m_fabs(z) - c[2] + c[3]) - c[3]; break;
-        case OP_L_WIREFRAME_BOX: {  // d3.py:144-155
+        L_L_SPHERE:   // d3.py:92-96
+            v = len3(x - c[1], y - c[2], z - c[3]) - c[0]; goto fold;
+        L_L_PLANE:    // d3.py:98-103
+            v = dot3(c[3] - x, c[4] - y, c[5] - z, c[0], c[1], c[2]); goto fold;
+        L_L_BOX:      // d3.py:122-134
+            v = box_like(m_fabs(x - c[0]) - c[3], m_fabs(y - c[1]) - c[4], m_fabs(z - c[2]) - c[5]); goto fold;
+        L_L_ROUNDED_BOX:  // d3.py:136-142
+            v = box_like(m_fabs(x) - c[0] + c[3], m_fabs(y) - c[1] + c[3], m_fabs(z) - c[2] + c[3]) - c[3]; goto fold;
+        L_L_WIREFRAME_BOX: {  // d3.py:144-155
             const T t2 = c[3];
             const V px = m_fabs(x) - c[0] - t2, py = m_fabs(y) - c[1] - t2, pz = m_fabs(z) - c[2] - t2;
             const V qx = m_fabs(px + t2) - t2, qy = m_fabs(py + t2) - t2, qz = m_fabs(pz + t2) - t2;
             auto g = [](const V &a, const V &b, const V &cc) {
                 return len3(np_max(a, T(0)), np_max(b, T(0)), np_max(cc, T(0))) + np_min(np_max(a, np_max(b, cc)), T(0));
             };
-            v = np_min(np_min(g(px, qy, qz), g(qx, py, qz)), g(qx, qy, pz)); break; }
-        case OP_L_TORUS: {  // d3.py:157-165
+            v = np_min(np_min(g(px, qy, qz), g(qx, py, qz)), g(qx, qy, pz)); goto fold; }
+        L_L_TORUS: {  // d3.py:157-165
             const V a = len2(x, y) - c[0];
-            v = len2(a, z) - c[1]; break; }
-        case OP_L_CAPSULE: {  // d3.py:167-176
+            v = len2(a, z) - c[1]; goto fold; }
+        L_L_CAPSULE: {  // d3.py:167-176
             const V pax = x - c[0], pay = y - c[1], paz = z - c[2];
             const V h = np_clip(dot3(pax, pay, paz, c[3], c[4], c[5]) / c[6], T(0), T(1));
-            v = len3(pax - c[3] * h, pay - c[4] * h, paz - c[5] * h) - c[7]; break; }
-        case OP_L_CYLINDER:  // d3.py:178-182
-            v = len2(x, y) - c[0]; break;
-        case OP_L_CAPPED_CYLINDER: {  // d3.py:184-204
+            v = len3(pax - c[3] * h, pay - c[4] * h, paz - c[5] * h) - c[7]; goto fold; }
+        L_L_CYLINDER:  // d3.py:178-182
+            v = len2(x, y) - c[0]; goto fold;
+        L_L_CAPPED_CYLINDER: {  // d3.py:184-204
             const T bax = c[3], bay = c[4], baz = c[5], baba = c[6];
             const V pax = x - c[0], pay = y - c[1], paz = z - c[2];
             const V paba = dot3(pax, pay, paz, bax, bay, baz);
@@ -321,12 +353,12 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const V din = -np_min(x2, y2);
             const V dout = vsel(xx > T(0), x2, T(0)) + vsel(yy > T(0), y2, T(0));
             const V d = vsel(np_max(xx, yy) < T(0), din, dout);
-            v = np_sign(d) * m_sqrt(m_fabs(d)) / baba; break; }
-        case OP_L_ROUNDED_CYLINDER: {  // d3.py:206-215
+            v = np_sign(d) * m_sqrt(m_fabs(d)) / baba; goto fold; }
+        L_L_ROUNDED_CYLINDER: {  // d3.py:206-215
             const V d0 = len2(x, y) - c[0] + c[1];
             const V dd1 = m_fabs(z) - c[2] + c[1];
-            v = np_min(np_max(d0, dd1), T(0)) + len2(np_max(d0, T(0)), np_max(dd1, T(0))) - c[1]; break; }
-        case OP_L_CAPPED_CONE: {  // d3.py:217-237
+            v = np_min(np_max(d0, dd1), T(0)) + len2(np_max(d0, T(0)), np_max(dd1, T(0))) - c[1]; goto fold; }
+        L_L_CAPPED_CONE: {  // d3.py:217-237
             const T ra = c[6], rb = c[7], baba = c[8], rba = c[9], k = c[10];
             const V pax = x - c[0], pay = y - c[1], paz = z - c[2];
             const V papa = (pax * pax + pay * pay) + paz * paz;
@@ -338,20 +370,20 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const V cbx = xx - ra - f * rba;
             const V cby = paba - f;
             const V s = vsel_s((cbx < T(0)) & (cay < T(0)), T(-1), T(1));
-            v = s * m_sqrt(np_min(cax * cax + cay * cay * baba, cbx * cbx + cby * cby * baba)); break; }
-        case OP_L_ROUNDED_CONE: {  // d3.py:239-250
+            v = s * m_sqrt(np_min(cax * cax + cay * cay * baba, cbx * cbx + cby * cby * baba)); goto fold; }
+        L_L_ROUNDED_CONE: {  // d3.py:239-250
             const T r1 = c[0], r2 = c[1], h = c[2], b = c[3], a = c[4], ah = c[5];
             const V qx = len2(x, y), qy = z;
             const V k = dot2(qx, qy, -b, a);
             const V c1 = len2(qx, qy) - r1;
             const V c2 = len2(qx - T(0), qy - h) - r2;
             const V c3 = dot2(qx, qy, a, b) - r1;
-            v = vsel(k < T(0), c1, vsel(k > ah, c2, c3)); break; }
-        case OP_L_ELLIPSOID: {  // d3.py:252-259
+            v = vsel(k < T(0), c1, vsel(k > ah, c2, c3)); goto fold; }
+        L_L_ELLIPSOID: {  // d3.py:252-259
             const V k0 = len3(x / c[0], y / c[1], z / c[2]);
             const V k1 = len3(x / c[3], y / c[4], z / c[5]);
-            v = k0 * (k0 - T(1)) / k1; break; }
-        case OP_L_PYRAMID: {  // d3.py:261-282
+            v = k0 * (k0 - T(1)) / k1; goto fold; }
+        L_L_PYRAMID: {  // d3.py:261-282
             const T h = c[0], m2 = c[1], m2q = c[2];
             const V b0 = m_fabs(x) - T(0.5), b1 = m_fabs(y) - T(0.5);
             const Mask<NS> sw = b1 > b0;
@@ -363,31 +395,31 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const V a = m2 * ((qx + s) * (qx + s)) + qy * qy;
             const V b = m2 * ((qx + T(0.5) * tt) * (qx + T(0.5) * tt)) + (qy - m2 * tt) * (qy - m2 * tt);
             const V dd2 = vsel(np_min(qy, -qx * m2 - qy * T(0.5)) > T(0), T(0), np_min(a, b));
-            v = m_sqrt((dd2 + qz * qz) / m2) * np_sign(np_max(qz, -py)); break; }
-        case OP_L_TETRAHEDRON:  // d3.py:286-293
-            v = (np_max(m_fabs(x + y) - z, m_fabs(x - y) + z) - c[0]) / c[1]; break;
-        case OP_L_OCTAHEDRON:   // d3.py:295-299
-            v = (((m_fabs(x) + m_fabs(y)) + m_fabs(z)) - c[0]) * c[1]; break;
-        case OP_L_DODECAHEDRON: {  // d3.py:301-311
+            v = m_sqrt((dd2 + qz * qz) / m2) * np_sign(np_max(qz, -py)); goto fold; }
+        L_L_TETRAHEDRON:  // d3.py:286-293
+            v = (np_max(m_fabs(x + y) - z, m_fabs(x - y) + z) - c[0]) / c[1]; goto fold;
+        L_L_OCTAHEDRON:   // d3.py:295-299
+            v = (((m_fabs(x) + m_fabs(y)) + m_fabs(z)) - c[0]) * c[1]; goto fold;
+        L_L_DODECAHEDRON: {  // d3.py:301-311
             const T r = c[0], X = c[1], Y = c[2], Z = c[3];
             const V ax = m_fabs(x / r), ay = m_fabs(y / r), az = m_fabs(z / r);
             const V a = dot3(ax, ay, az, X, Y, Z), b = dot3(ax, ay, az, Z, X, Y), cc = dot3(ax, ay, az, Y, Z, X);
-            v = (np_max(np_max(a, b), cc) - X) * r; break; }
-        case OP_L_ICOSAHEDRON: {  // d3.py:313-325
+            v = (np_max(np_max(a, b), cc) - X) * r; goto fold; }
+        L_L_ICOSAHEDRON: {  // d3.py:313-325
             const T r = c[0], X = c[1], Y = c[2], Z = c[3], w = c[4];
             const V ax = m_fabs(x / r), ay = m_fabs(y / r), az = m_fabs(z / r);
             const V a = dot3(ax, ay, az, X, Y, Z), b = dot3(ax, ay, az, Z, X, Y), cc = dot3(ax, ay, az, Y, Z, X);
             const V d = dot3(ax, ay, az, w, w, w) - X;
-            v = np_max(np_max(np_max(a, b), cc) - X, d) * r; break; }
+            v = np_max(np_max(np_max(a, b), cc) - X, d) * r; goto fold; }
         // ---------------- 2-D leaves: the point is (x, y) ----------------
-        case OP_L_CIRCLE:  // d2.py:76-80
-            v = len2(x - c[1], y - c[2]) - c[0]; break;
-        case OP_L_LINE:    // d2.py:82-87
-            v = dot2(c[2] - x, c[3] - y, c[0], c[1]); break;
-        case OP_L_RECTANGLE: {  // d2.py:102-114
+        L_L_CIRCLE:  // d2.py:76-80
+            v = len2(x - c[1], y - c[2]) - c[0]; goto fold;
+        L_L_LINE:    // d2.py:82-87
+            v = dot2(c[2] - x, c[3] - y, c[0], c[1]); goto fold;
+        L_L_RECTANGLE: {  // d2.py:102-114
             const V qx = m_fabs(x - c[0]) - c[2], qy = m_fabs(y - c[1]) - c[3];
-            v = len2(np_max(qx, T(0)), np_max(qy, T(0))) + np_min(np_max(qx, qy), T(0)); break; }
-        case OP_L_ROUNDED_RECTANGLE: {  // d2.py:116-134 (later assignments win, as in the reference)
+            v = len2(np_max(qx, T(0)), np_max(qy, T(0))) + np_min(np_max(qx, qy), T(0)); goto fold; }
+        L_L_ROUNDED_RECTANGLE: {  // d2.py:116-134 (later assignments win, as in the reference)
             const Mask<NS> xp = x > T(0), yp = y > T(0);
             V r(T(0));
             r = vsel(xp & yp, c[2], r);
@@ -395,27 +427,27 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             r = vsel(!xp & !yp, c[4], r);
             r = vsel(!xp & yp, c[5], r);
             const V qx = m_fabs(x) - c[0] + r, qy = m_fabs(y) - c[1] + r;
-            v = np_min(np_max(qx, qy), T(0)) + len2(np_max(qx, T(0)), np_max(qy, T(0))) - r; break; }
-        case OP_L_EQUILATERAL_TRIANGLE: {  // d2.py:136-152
+            v = np_min(np_max(qx, qy), T(0)) + len2(np_max(qx, T(0)), np_max(qy, T(0))) - r; goto fold; }
+        L_L_EQUILATERAL_TRIANGLE: {  // d2.py:136-152
             const T k = c[0];
             V px = m_fabs(x) - T(1), py = y + c[1];
             const Mask<NS> w = px + k * py > T(0);
             const V nx = (px - k * py) / T(2), ny = (-k * px - py) / T(2);
             px = vsel(w, nx, px); py = vsel(w, ny, py);
             px = px - np_clip(px, T(-2), T(0));
-            v = -len2(px, py) * np_sign(py); break; }
-        case OP_L_HEXAGON: {  // d2.py:154-165
+            v = -len2(px, py) * np_sign(py); goto fold; }
+        L_L_HEXAGON: {  // d2.py:154-165
             const T r = c[0], k0 = c[1], k1 = c[2];
             V px = m_fabs(x), py = m_fabs(y);
             const V m = np_min(k0 * px + k1 * py, T(0));
             px = px - c[4] * m; py = py - c[5] * m;
             px = px - np_clip(px, c[6], c[7]); py = py - (T(0) + r);
-            v = len2(px, py) * np_sign(py); break; }
-        case OP_L_ROUNDED_X: {  // d2.py:167-173
+            v = len2(px, py) * np_sign(py); goto fold; }
+        L_L_ROUNDED_X: {  // d2.py:167-173
             const V px = m_fabs(x), py = m_fabs(y);
             const V qq = np_min(px + py, c[0]) * T(0.5);
-            v = len2(px - qq, py - qq) - c[1]; break; }
-        case OP_L_POLYGON: {  // d2.py:175-196
+            v = len2(px - qq, py - qq) - c[1]; goto fold; }
+        L_L_POLYGON: {  // d2.py:175-196
             const int np_ = (int)c[0];
             const T *pv = c + 1;
             const V dx = x - pv[0], dy = y - pv[1];
@@ -433,32 +465,32 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
                 const Mask<NS> c1 = y >= viy, c2 = y < vjy, c3 = ex * wy > ey * wx;
                 s = vsel((c1 & c2 & c3) | (!c1 & !c2 & !c3), -s, s);
             }
-            v = s * m_sqrt(d); break; }
-        case OP_L_VESICA: {  // d2.py:198-207
+            v = s * m_sqrt(d); goto fold; }
+        L_L_VESICA: {  // d2.py:198-207
             const T r = c[0], d = c[1], b = c[2];
             const V px = m_fabs(x), py = m_fabs(y);
-            v = vsel((py - b) * d > px * b, len2(px - T(0), py - b), len2(px - (-d), py - T(0)) - r); break; }
+            v = vsel((py - b) * d > px * b, len2(px - T(0), py - b), len2(px - (-d), py - T(0)) - r); goto fold; }
         // ---------------- fold a parked distance ----------------
-        case OP_COMB: { V d1; DGET(d1, sa); acc = post_combine(post, d1, acc, c[-1]); continue; }
+        L_COMB: { V d1; DGET(d1, sa); acc = post_combine(post, d1, acc, c[-1]); continue; }
         // ---------------- point ops ----------------
-        case OP_TRANSLATE:  // d3.py:329-333
+        L_TRANSLATE:  // d3.py:329-333
             x = x - c[0]; y = y - c[1]; z = z - c[2]; continue;
-        case OP_SCALE:      // d3.py:335-345
+        L_SCALE:      // d3.py:335-345
             x = x / c[0]; y = y / c[1]; z = z / c[2]; continue;
-        case OP_ROTATE: {   // d3.py:347-360: p @ M, M row-major
+        L_ROTATE: {   // d3.py:347-360: p @ M, M row-major
             const V nx = dot3(x, y, z, c[0], c[3], c[6]);
             const V ny = dot3(x, y, z, c[1], c[4], c[7]);
             const V nz = dot3(x, y, z, c[2], c[5], c[8]);
             x = nx; y = ny; z = nz; continue; }
-        case OP_ELONGATE: {  // d3.py:396-405
+        L_ELONGATE: {  // d3.py:396-405
             const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1], qz = m_fabs(z) - c[2];
             DSET(sa, np_min(np_max(qx, np_max(qy, qz)), T(0)));
             x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); continue; }
-        case OP_BEND_LINEAR: {  // d3.py:435-445
+        L_BEND_LINEAR: {  // d3.py:435-445
             V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
             tt = ease_apply<T, FULL, NS>((int)c[10], tt);
             x = x + tt * c[7]; y = y + tt * c[8]; z = z + tt * c[9]; continue; }
-        case OP_REP_PREP: {  // dn.py:80-112: cell index of p
+        L_REP_PREP: {  // dn.py:80-112: cell index of p
             const int dim = (int)c[0];
             V idx[3] = {V(T(0)), V(T(0)), V(T(0))};
             const V pp[3] = {x, y, z};
@@ -472,89 +504,84 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
                 }
             }
             PSET(sa, idx[0], idx[1], idx[2]); continue; }
-        case OP_REP_SET:   // p = p0 - spacing * (index + n)
+        L_REP_SET:   // p = p0 - spacing * (index + n)
         {   V ax, ay, az, bx, by, bz;
             PGET(sa, ax, ay, az); PGET(sb, bx, by, bz);
             x = ax - c[0] * (bx + c[3]);
             y = ay - c[1] * (by + c[4]);
             z = az - c[2] * (bz + c[5]); continue; }
-        case OP_TRANSLATE2: x = x - c[0]; y = y - c[1]; continue;   // d2.py:211-215
-        case OP_SCALE2: x = x / c[0]; y = y / c[1]; continue;       // d2.py:217-227
-        case OP_ROTATE2: {  // d2.py:229-240
+        L_TRANSLATE2: x = x - c[0]; y = y - c[1]; continue;   // d2.py:211-215
+        L_SCALE2: x = x / c[0]; y = y / c[1]; continue;       // d2.py:217-227
+        L_ROTATE2: {  // d2.py:229-240
             const V nx = dot2(x, y, c[0], c[2]), ny = dot2(x, y, c[1], c[3]);
             x = nx; y = ny; continue; }
-        case OP_ELONGATE2: {  // d2.py:249-257
+        L_ELONGATE2: {  // d2.py:249-257
             const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1];
             DSET(sa, np_min(np_max(qx, qy), T(0)));
             x = np_max(qx, T(0)); y = np_max(qy, T(0)); continue; }
-        case OP_REVOLVE: {  // d2.py:280-286
+        L_REVOLVE: {  // d2.py:280-286
             const V nx = len2(x, y) - c[0];
             y = z; x = nx; z = V(T(0)); continue; }
-        case OP_SETZ0: z = V(T(0)); continue;                        // d3.py:513
-        case OP_SAVE_P: PSET(sa, x, y, z); continue;
-        case OP_LOAD_P: PGET(sa, x, y, z); continue;
+        L_SETZ0: z = V(T(0)); continue;                        // d3.py:513
+        L_SAVE_P: PSET(sa, x, y, z); continue;
+        L_LOAD_P: PGET(sa, x, y, z); continue;
         // ---------------- distance ops ----------------
-        case OP_PUSH_D: DSET(sa, acc); continue;
-        case OP_NEG: acc = -acc; continue;                            // dn.py:60-63
-        case OP_ADDC: acc = acc + c[0]; continue;                     // dn.py:70-73
-        case OP_SUBC: acc = acc - c[0]; continue;                     // dn.py:65-68
-        case OP_MULC: acc = acc * c[0]; continue;                     // d3.py:344
-        case OP_SHELL: acc = m_fabs(acc) - c[0]; continue;            // dn.py:75-78
-        case OP_ADD_DS: { V t; DGET(t, sa); acc = acc + t; continue; }   // d3.py:405
-        case OP_TRANS_LIN_PRE: {  // d3.py:459-470
+        L_PUSH_D: DSET(sa, acc); continue;
+        L_NEG: acc = -acc; continue;                            // dn.py:60-63
+        L_ADDC: acc = acc + c[0]; continue;                     // dn.py:70-73
+        L_SUBC: acc = acc - c[0]; continue;                     // dn.py:65-68
+        L_MULC: acc = acc * c[0]; continue;                     // d3.py:344
+        L_SHELL: acc = m_fabs(acc) - c[0]; continue;            // dn.py:75-78
+        L_ADD_DS: { V t; DGET(t, sa); acc = acc + t; continue; }   // d3.py:405
+        L_TRANS_LIN_PRE: {  // d3.py:459-470
             const V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
             DSET(sa, ease_apply<T, FULL, NS>((int)c[7], tt)); continue; }
-        case OP_TRANS_MIX: {  // t * d2 + (1 - t) * d1
+        L_TRANS_MIX: {  // t * d2 + (1 - t) * d1
             V tt, dd; DGET(tt, sa); DGET(dd, sb);
             acc = tt * acc + (T(1) - tt) * dd; continue; }
-        case OP_EXT_PRE: DSET(sa, m_fabs(z) - c[0]); continue;      // d2.py:264-266
-        case OP_EXT_POST: {  // d2.py:267
+        L_EXT_PRE: DSET(sa, m_fabs(z) - c[0]); continue;      // d2.py:264-266
+        L_EXT_POST: {  // d2.py:267
             V w1; DGET(w1, sa);
             acc = np_min(np_max(acc, w1), T(0)) + len2(np_max(acc, T(0)), np_max(w1, T(0))); continue; }
-        case OP_EXTTO_PRE:   // d2.py:274
+        L_EXTTO_PRE:   // d2.py:274
             DSET(sa, ease_apply<T, FULL, NS>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5))); continue;
-        case OP_EXTTO_MIX: {  // d2.py:275
+        L_EXTTO_MIX: {  // d2.py:275
             V dd1, tt; DGET(dd1, sb); DGET(tt, sa);
             acc = dd1 + (acc - dd1) * tt; continue; }
-        case OP_SLICE_POST: {  // d3.py:515-519
+        L_SLICE_POST: {  // d3.py:515-519
             V A; DGET(A, sa); const V B = -acc;
             acc = vsel(A <= T(0), B, A); continue; }
-        default:
-            if constexpr (FULL) {
-                switch (op) {
-                case OP_TWIST: {  // d3.py:407-419
-                    const V cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
-                    const V nx = cc * x - s * y, ny = s * x + cc * y;
-                    x = nx; y = ny; continue; }
-                case OP_BEND: {   // d3.py:421-433
-                    const V cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
-                    const V nx = cc * x - s * y, ny = s * x + cc * y;
-                    x = nx; y = ny; continue; }
-                case OP_BEND_RADIAL: {  // d3.py:447-457
-                    const V r = m_hypot(x, y);
-                    const V tt = np_clip((r - c[0]) / c[1], T(0), T(1));
-                    z = z - c[2] * ease_apply<T, FULL, NS>((int)c[3], tt); continue; }
-                case OP_WRAP_AROUND: {  // d3.py:483-502
-                    const T pi = T(3.141592653589793);
-                    const V d = m_hypot(x, y) - c[9];
-                    const V a = m_atan2(y, x);
-                    const V tt = ease_apply<T, FULL, NS>((int)c[10], (a + pi) / (T(2) * pi));
-                    x = c[0] + c[3] * tt + c[6] * d;
-                    y = c[1] + c[4] * tt + c[7] * d; continue; }
-                case OP_CIRC_PREP: {  // d3.py:379-392: PS[sa] = (d, a, z)
-                    PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); continue; }
-                case OP_CIRC_SET: {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
-                    V d, a0, z0; PGET(sa, d, a0, z0);
-                    const V ang = a0 - c[0];
-                    x = m_cos(ang) * d; y = m_sin(ang) * d; z = z0; continue; }
-                case OP_TRANS_RAD_PRE: {  // d3.py:472-481
-                    const V r = m_hypot(x, y);
-                    DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); continue; }
-                default: continue;
-                }
-            }
-            continue;
+        L_TWIST: if constexpr (FULL) {  // d3.py:407-419
+            const V cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
+            const V nx = cc * x - s * y, ny = s * x + cc * y;
+            x = nx; y = ny; } continue;
+        L_BEND: if constexpr (FULL) {   // d3.py:421-433
+            const V cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
+            const V nx = cc * x - s * y, ny = s * x + cc * y;
+            x = nx; y = ny; } continue;
+        L_BEND_RADIAL: if constexpr (FULL) {  // d3.py:447-457
+            const V r = m_hypot(x, y);
+            const V tt = np_clip((r - c[0]) / c[1], T(0), T(1));
+            z = z - c[2] * ease_apply<T, FULL, NS>((int)c[3], tt); } continue;
+        L_WRAP_AROUND: if constexpr (FULL) {  // d3.py:483-502
+            const T pi = T(3.141592653589793);
+            const V d = m_hypot(x, y) - c[9];
+            const V a = m_atan2(y, x);
+            const V tt = ease_apply<T, FULL, NS>((int)c[10], (a + pi) / (T(2) * pi));
+            x = c[0] + c[3] * tt + c[6] * d;
+            y = c[1] + c[4] * tt + c[7] * d; } continue;
+        L_CIRC_PREP: if constexpr (FULL) {  // d3.py:379-392: PS[sa] = (d, a, z)
+            PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); } continue;
+        L_CIRC_SET: if constexpr (FULL) {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
+            V d, a0, z0; PGET(sa, d, a0, z0);
+            const V ang = a0 - c[0];
+            x = m_cos(ang) * d; y = m_sin(ang) * d; z = z0; } continue;
+        L_TRANS_RAD_PRE: if constexpr (FULL) {  // d3.py:472-481
+            const V r = m_hypot(x, y);
+            DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); } continue;
+        L_END: L_BAD: continue;
         }
+        fold:
         acc = post_combine(post, acc, v, c[-1]);
     }
 }

@@ -19,7 +19,6 @@ static int launch_shape(int shape, int grid, size_t lds, hipStream_t stream, con
     switch (shape) {
     case 0: return launch_one<NP, ND, 1, 1024>(grid, lds, stream, code, consts, a);
     case 1: return launch_one<NP, ND, 2, 512>(grid, lds, stream, code, consts, a);
-    case 2: return launch_one<NP, ND, 4, 256>(grid, lds, stream, code, consts, a);
     default: return launch_one<NP, ND, 2, 1024>(grid, lds, stream, code, consts, a);
     }
 }
