@@ -416,10 +416,12 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     t->n_p = n_p; t->n_d = n_d;
     std::vector<float> c32(n_consts);
     for (uint32_t i = 0; i < n_consts; i++) c32[i] = (float)consts[i];
-    HIPCHK(hipMalloc((void **)&t->d_code, n_words * sizeof(uint32_t)));
+    std::vector<uint32_t> pcode(code, code + n_words);   // + one more END: the interpreter looks one instruction ahead
+    pcode.push_back(code[n_words - 2]); pcode.push_back(code[n_words - 1]);
+    HIPCHK(hipMalloc((void **)&t->d_code, pcode.size() * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&t->d_c64, n_consts * sizeof(double)));
     HIPCHK(hipMalloc((void **)&t->d_c32, n_consts * sizeof(float)));
-    HIPCHK(hipMemcpy(t->d_code, code, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->d_code, pcode.data(), pcode.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t->d_c64, consts, n_consts * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t->d_c32, c32.data(), n_consts * sizeof(float), hipMemcpyHostToDevice));
     *out = t;

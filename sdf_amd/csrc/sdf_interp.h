@@ -290,22 +290,27 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
 #define PGET(s, X, Y, Z) do { V _px, _py, _pz; SDF_RF_PICK(NP, s, SDF_PGET_); X = _px; Y = _py; Z = _pz; } while (0)
 #define PSET(s, X, Y, Z) do { const V _px = (X), _py = (Y), _pz = (Z); SDF_RF_PICK(NP, s, SDF_PSET_); } while (0)
 
-    // the next instruction's words are requested before the current one executes, so their
-    // scalar-cache latency overlaps the constant loads and the arithmetic of this instruction
+    // The next instruction's words are requested before the current one executes, so their
+    // scalar-cache latency overlaps this instruction's arithmetic (the host pads the code with a
+    // second END so the look-ahead of END itself stays inside the buffer).  The loop is a plain
+    // do-while with one latch: END sets `done` like any other op instead of leaving from the
+    // middle, which keeps the control-flow graph around the jump table reducible and copy-free.
     uint32_t w0 = __builtin_amdgcn_readfirstlane(code[0]);
     uint32_t coff = __builtin_amdgcn_readfirstlane(code[1]);
-    for (uint32_t pc = 2;; pc += 2) {
+    uint32_t pc = 2;
+    bool done = false;
+    do {
         const uint32_t op = w0 & 255u, post = (w0 >> 8) & 255u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
-        if (op == OP_END) return acc;   // (the table row of END is never taken)
         const T *c = consts + coff + 1;          // c[-1] is K
-        w0 = __builtin_amdgcn_readfirstlane(code[pc]);       // prefetch (the tape always ends in END)
+        w0 = __builtin_amdgcn_readfirstlane(code[pc]);
         coff = __builtin_amdgcn_readfirstlane(code[pc + 1]);
+        pc += 2;
         // Dispatch: ONE indirect jump through a table of s_branch instructions (the compiler only
         // offers a compare-and-branch tree for `switch`, and every taken branch costs an instruction
         // buffer refill).  s_getpc returns the address A of the instruction after it; the table
         // starts at A + 12 (three 4-byte SALU instructions), so the target is A + 4 * (op + 3).
         // s_lshl2_add_u32 leaves the carry of the 32-bit add in SCC for the s_addc.
-        // A leaf computes v and jumps to `fold`; every other op `continue`s.
+        // A leaf computes v and jumps to `fold`; every other op jumps to `next`.
         V v;
         const uint32_t jt = op + 3u;
         asm goto(
@@ -315,7 +320,7 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             "s_setpc_b64 vcc\n\t"
             SDF_OPCODE_LIST(SDF_JT_ROW)
             : : "s"(jt) : "vcc", "scc" : SDF_OPCODE_LIST(SDF_JT_LABEL) L_BAD);
-        continue;   // never reached: the asm always jumps (kept inside the loop for the CFG passes)
+        goto next;   // never reached: the asm always jumps (kept inside the loop for the CFG passes)
         {
         // ---------------- 3-D leaves ----------------
         L_L_SPHERE:   // d3.py:92-96
@@ -471,25 +476,25 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const V px = m_fabs(x), py = m_fabs(y);
             v = vsel((py - b) * d > px * b, len2(px - T(0), py - b), len2(px - (-d), py - T(0)) - r); goto fold; }
         // ---------------- fold a parked distance ----------------
-        L_COMB: { V d1; DGET(d1, sa); acc = post_combine(post, d1, acc, c[-1]); continue; }
+        L_COMB: { V d1; DGET(d1, sa); acc = post_combine(post, d1, acc, c[-1]); goto next; }
         // ---------------- point ops ----------------
         L_TRANSLATE:  // d3.py:329-333
-            x = x - c[0]; y = y - c[1]; z = z - c[2]; continue;
+            x = x - c[0]; y = y - c[1]; z = z - c[2]; goto next;
         L_SCALE:      // d3.py:335-345
-            x = x / c[0]; y = y / c[1]; z = z / c[2]; continue;
+            x = x / c[0]; y = y / c[1]; z = z / c[2]; goto next;
         L_ROTATE: {   // d3.py:347-360: p @ M, M row-major
             const V nx = dot3(x, y, z, c[0], c[3], c[6]);
             const V ny = dot3(x, y, z, c[1], c[4], c[7]);
             const V nz = dot3(x, y, z, c[2], c[5], c[8]);
-            x = nx; y = ny; z = nz; continue; }
+            x = nx; y = ny; z = nz; goto next; }
         L_ELONGATE: {  // d3.py:396-405
             const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1], qz = m_fabs(z) - c[2];
             DSET(sa, np_min(np_max(qx, np_max(qy, qz)), T(0)));
-            x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); continue; }
+            x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); goto next; }
         L_BEND_LINEAR: {  // d3.py:435-445
             V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
             tt = ease_apply<T, FULL, NS>((int)c[10], tt);
-            x = x + tt * c[7]; y = y + tt * c[8]; z = z + tt * c[9]; continue; }
+            x = x + tt * c[7]; y = y + tt * c[8]; z = z + tt * c[9]; goto next; }
         L_REP_PREP: {  // dn.py:80-112: cell index of p
             const int dim = (int)c[0];
             V idx[3] = {V(T(0)), V(T(0)), V(T(0))};
@@ -503,87 +508,90 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
                     idx[i] = r;
                 }
             }
-            PSET(sa, idx[0], idx[1], idx[2]); continue; }
+            PSET(sa, idx[0], idx[1], idx[2]); goto next; }
         L_REP_SET:   // p = p0 - spacing * (index + n)
         {   V ax, ay, az, bx, by, bz;
             PGET(sa, ax, ay, az); PGET(sb, bx, by, bz);
             x = ax - c[0] * (bx + c[3]);
             y = ay - c[1] * (by + c[4]);
-            z = az - c[2] * (bz + c[5]); continue; }
-        L_TRANSLATE2: x = x - c[0]; y = y - c[1]; continue;   // d2.py:211-215
-        L_SCALE2: x = x / c[0]; y = y / c[1]; continue;       // d2.py:217-227
+            z = az - c[2] * (bz + c[5]); goto next; }
+        L_TRANSLATE2: x = x - c[0]; y = y - c[1]; goto next;   // d2.py:211-215
+        L_SCALE2: x = x / c[0]; y = y / c[1]; goto next;       // d2.py:217-227
         L_ROTATE2: {  // d2.py:229-240
             const V nx = dot2(x, y, c[0], c[2]), ny = dot2(x, y, c[1], c[3]);
-            x = nx; y = ny; continue; }
+            x = nx; y = ny; goto next; }
         L_ELONGATE2: {  // d2.py:249-257
             const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1];
             DSET(sa, np_min(np_max(qx, qy), T(0)));
-            x = np_max(qx, T(0)); y = np_max(qy, T(0)); continue; }
+            x = np_max(qx, T(0)); y = np_max(qy, T(0)); goto next; }
         L_REVOLVE: {  // d2.py:280-286
             const V nx = len2(x, y) - c[0];
-            y = z; x = nx; z = V(T(0)); continue; }
-        L_SETZ0: z = V(T(0)); continue;                        // d3.py:513
-        L_SAVE_P: PSET(sa, x, y, z); continue;
-        L_LOAD_P: PGET(sa, x, y, z); continue;
+            y = z; x = nx; z = V(T(0)); goto next; }
+        L_SETZ0: z = V(T(0)); goto next;                        // d3.py:513
+        L_SAVE_P: PSET(sa, x, y, z); goto next;
+        L_LOAD_P: PGET(sa, x, y, z); goto next;
         // ---------------- distance ops ----------------
-        L_PUSH_D: DSET(sa, acc); continue;
-        L_NEG: acc = -acc; continue;                            // dn.py:60-63
-        L_ADDC: acc = acc + c[0]; continue;                     // dn.py:70-73
-        L_SUBC: acc = acc - c[0]; continue;                     // dn.py:65-68
-        L_MULC: acc = acc * c[0]; continue;                     // d3.py:344
-        L_SHELL: acc = m_fabs(acc) - c[0]; continue;            // dn.py:75-78
-        L_ADD_DS: { V t; DGET(t, sa); acc = acc + t; continue; }   // d3.py:405
+        L_PUSH_D: DSET(sa, acc); goto next;
+        L_NEG: acc = -acc; goto next;                            // dn.py:60-63
+        L_ADDC: acc = acc + c[0]; goto next;                     // dn.py:70-73
+        L_SUBC: acc = acc - c[0]; goto next;                     // dn.py:65-68
+        L_MULC: acc = acc * c[0]; goto next;                     // d3.py:344
+        L_SHELL: acc = m_fabs(acc) - c[0]; goto next;            // dn.py:75-78
+        L_ADD_DS: { V t; DGET(t, sa); acc = acc + t; goto next; }   // d3.py:405
         L_TRANS_LIN_PRE: {  // d3.py:459-470
             const V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
-            DSET(sa, ease_apply<T, FULL, NS>((int)c[7], tt)); continue; }
+            DSET(sa, ease_apply<T, FULL, NS>((int)c[7], tt)); goto next; }
         L_TRANS_MIX: {  // t * d2 + (1 - t) * d1
             V tt, dd; DGET(tt, sa); DGET(dd, sb);
-            acc = tt * acc + (T(1) - tt) * dd; continue; }
-        L_EXT_PRE: DSET(sa, m_fabs(z) - c[0]); continue;      // d2.py:264-266
+            acc = tt * acc + (T(1) - tt) * dd; goto next; }
+        L_EXT_PRE: DSET(sa, m_fabs(z) - c[0]); goto next;      // d2.py:264-266
         L_EXT_POST: {  // d2.py:267
             V w1; DGET(w1, sa);
-            acc = np_min(np_max(acc, w1), T(0)) + len2(np_max(acc, T(0)), np_max(w1, T(0))); continue; }
+            acc = np_min(np_max(acc, w1), T(0)) + len2(np_max(acc, T(0)), np_max(w1, T(0))); goto next; }
         L_EXTTO_PRE:   // d2.py:274
-            DSET(sa, ease_apply<T, FULL, NS>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5))); continue;
+            DSET(sa, ease_apply<T, FULL, NS>((int)c[1], np_clip(z / c[0], T(-0.5), T(0.5)) + T(0.5))); goto next;
         L_EXTTO_MIX: {  // d2.py:275
             V dd1, tt; DGET(dd1, sb); DGET(tt, sa);
-            acc = dd1 + (acc - dd1) * tt; continue; }
+            acc = dd1 + (acc - dd1) * tt; goto next; }
         L_SLICE_POST: {  // d3.py:515-519
             V A; DGET(A, sa); const V B = -acc;
-            acc = vsel(A <= T(0), B, A); continue; }
+            acc = vsel(A <= T(0), B, A); goto next; }
         L_TWIST: if constexpr (FULL) {  // d3.py:407-419
             const V cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
             const V nx = cc * x - s * y, ny = s * x + cc * y;
-            x = nx; y = ny; } continue;
+            x = nx; y = ny; } goto next;
         L_BEND: if constexpr (FULL) {   // d3.py:421-433
             const V cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
             const V nx = cc * x - s * y, ny = s * x + cc * y;
-            x = nx; y = ny; } continue;
+            x = nx; y = ny; } goto next;
         L_BEND_RADIAL: if constexpr (FULL) {  // d3.py:447-457
             const V r = m_hypot(x, y);
             const V tt = np_clip((r - c[0]) / c[1], T(0), T(1));
-            z = z - c[2] * ease_apply<T, FULL, NS>((int)c[3], tt); } continue;
+            z = z - c[2] * ease_apply<T, FULL, NS>((int)c[3], tt); } goto next;
         L_WRAP_AROUND: if constexpr (FULL) {  // d3.py:483-502
             const T pi = T(3.141592653589793);
             const V d = m_hypot(x, y) - c[9];
             const V a = m_atan2(y, x);
             const V tt = ease_apply<T, FULL, NS>((int)c[10], (a + pi) / (T(2) * pi));
             x = c[0] + c[3] * tt + c[6] * d;
-            y = c[1] + c[4] * tt + c[7] * d; } continue;
+            y = c[1] + c[4] * tt + c[7] * d; } goto next;
         L_CIRC_PREP: if constexpr (FULL) {  // d3.py:379-392: PS[sa] = (d, a, z)
-            PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); } continue;
+            PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); } goto next;
         L_CIRC_SET: if constexpr (FULL) {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
             V d, a0, z0; PGET(sa, d, a0, z0);
             const V ang = a0 - c[0];
-            x = m_cos(ang) * d; y = m_sin(ang) * d; z = z0; } continue;
+            x = m_cos(ang) * d; y = m_sin(ang) * d; z = z0; } goto next;
         L_TRANS_RAD_PRE: if constexpr (FULL) {  // d3.py:472-481
             const V r = m_hypot(x, y);
-            DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); } continue;
-        L_END: L_BAD: continue;
+            DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); } goto next;
+        L_END: done = true; goto next;
+        L_BAD: goto next;
         }
         fold:
         acc = post_combine(post, acc, v, c[-1]);
-    }
+        next:;
+    } while (!done);
+    return acc;
 }
 
 #undef DGET
