@@ -36,7 +36,11 @@ struct MeshCounters {   // zeroed before every k_mesh run
     unsigned int n_empty, n_nonempty;
     unsigned long long n_ambiguous;
     unsigned long long total;         // written by k_scan
+    // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
+    // and this shard's slice of it, so k_mesh can start without a host round trip
+    int nwork, work_begin, work_end, pad_;
 };
+enum { MESH_COUNTERS_RESET_BYTES = 48 };   // the part of MeshCounters cleared before every k_mesh run
 
 struct GridDesc {
     const double *X, *Y, *Z;   // device copies of the np.arange axes
@@ -48,8 +52,7 @@ struct GridDesc {
 struct MeshArgs {
     GridDesc g;
     const McTables *mc;
-    const int *worklist;
-    int work_begin, work_end;      // this shard's slice of the work list
+    const int *worklist;           // its length and this shard's slice are in ctr (device side)
     unsigned char *kinds;          // per batch
     unsigned int *batch_count;     // per work item: triangles
     unsigned long long *batch_base;  // per work item: first triangle slot in the arena
@@ -138,13 +141,14 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
 
     if (tid < 256) ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
 
+    const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
     long long tprev = a.prof ? clock64() : 0;
 #define SDF_PROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     for (;;) {
-        if (tid == 0) bcast[0] = a.work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
+        if (tid == 0) bcast[0] = work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
         __syncthreads();
         const int w = bcast[0];
-        if (w >= a.work_end) break;
+        if (w >= work_end) break;
         const int b = a.worklist[w];
         int ox, oy, oz, lx, ly, lz;
         batch_origin(g, b, ox, oy, oz, lx, ly, lz);

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
 
 // ordered compaction of the pending batches into the work list (single workgroup)
 __global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restrict__ kinds, int nbatches,
-                                                  int *__restrict__ worklist, int *__restrict__ nwork) {
+                                                  int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
+                                                  long long shard_index, long long shard_count) {
     __shared__ int wave_sums[16];
     int base = 0;
     for (int start = 0; start < nbatches; start += 1024) {
@@ -105,12 +106,17 @@ __global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restric
         if (f) worklist[base + pos] = b;
         base += tot;
     }
-    if (threadIdx.x == 0) *nwork = base;
+    if (threadIdx.x == 0) {   // contiguous chunk of the work list for this shard (same formula as sdf_amd/dist.py)
+        ctr->nwork = base;
+        ctr->work_begin = (int)(((long long)base * shard_index) / shard_count);
+        ctr->work_end = (int)(((long long)base * (shard_index + 1)) / shard_count);
+    }
 }
 
 // exclusive scan of batch_count[w0..w1) -> batch_final (triangle index in the ordered soup)
-__global__ __launch_bounds__(1024) void k_scan(const unsigned int *__restrict__ batch_count, int w0, int w1,
+__global__ __launch_bounds__(1024) void k_scan(const unsigned int *__restrict__ batch_count,
                                                unsigned long long *__restrict__ batch_final, MeshCounters *ctr) {
+    const int w0 = ctr->work_begin, w1 = ctr->work_end;
     __shared__ int wave_sums[16];
     unsigned long long base = 0;
     for (int start = w0; start < w1; start += 1024) {
@@ -271,12 +277,11 @@ struct sdf_ctx {
     hipEvent_t ev[6] = {};
     int n_cu = 256;
     size_t lds_max = 0;
-    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, counters, nwork, scratch_in, scratch_out, rows, rows_off, mc;
+    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, counters, scratch_in, scratch_out, rows, rows_off, mc;
     int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
     std::vector<DevBuf> arena_pool;   // arenas handed back by destroyed meshes
-    unsigned long long last_tris_per_batch = 0;
 };
 
 struct sdf_tape {
@@ -287,7 +292,7 @@ struct sdf_tape {
     uint32_t n_words = 0, n_consts = 0;
     bool full = false;
     uint32_t n_p = 0, n_d = 0;
-    unsigned long long hint_tris_per_batch = 0;
+    unsigned long long hint_key = 0, hint_total_tris = 0;   // arena sizing: last call of this tape
 };
 
 struct sdf_mesh {
@@ -382,8 +387,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->axes, &c->kinds, &c->worklist, &c->batch_count, &c->batch_base, &c->batch_final, &c->counters,
-                      &c->nwork, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof})
+    for (DevBuf *b : {&c->axes, &c->kinds, &c->worklist, &c->batch_count, &c->batch_base, &c->batch_final, &c->counters, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof})
         b->release();
     for (auto &b : c->arena_pool) b.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -592,7 +596,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     if (nb == 0) return 0;
 
     if (m->axes.ensure((size_t)(nx + ny + nz) * 8) || m->kinds.ensure((size_t)nb) || m->worklist.ensure((size_t)nb * 4) ||
-        c->counters.ensure(sizeof(MeshCounters)) || c->nwork.ensure(4))
+        m->batch_count.ensure((size_t)nb * 4) || m->batch_base.ensure((size_t)nb * 8) || m->batch_final.ensure((size_t)nb * 8) ||
+        c->counters.ensure(sizeof(MeshCounters)))
         return 1;
     double *dX = (double *)m->axes.p, *dY = dX + nx, *dZ = dY + ny;
     g.X = dX; g.Y = dY; g.Z = dZ;
@@ -600,8 +605,9 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(MeshCounters), c->stream));
 
-    // ---- prepass: skip test for every batch, then the ordered work list ----
+    // ---- prepass: skip test for every batch, then the ordered work list (+ this shard's slice) ----
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     if (sparse) {
         const unsigned grid = (unsigned)(((long long)nb * 16 + 255) / 256);
@@ -610,73 +616,75 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
     }
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
-                       (int *)c->nwork.p);
+                       (MeshCounters *)c->counters.p, (long long)shard_index, (long long)shard_count);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    int nwork = 0;
-    HIPCHK(hipMemcpyAsync(&nwork, c->nwork.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    m->st.n_skipped = nb - nwork;
-    m->work_begin = (int)(((long long)nwork * shard_index) / shard_count);
-    m->work_end = (int)(((long long)nwork * (shard_index + 1)) / shard_count);
-    m->st.n_work_begin = m->work_begin; m->st.n_work_end = m->work_end;
-    const int nshard = m->work_end - m->work_begin;
 
+    // ---- meshing.  The whole chain (prepass -> k_mesh -> k_scan) is enqueued without a host round
+    // trip: the work-list length stays on the device.  The triangle arena is sized from the last
+    // call of this tape on the same grid (first call: from the work-list length, which costs one
+    // synchronisation); an overflow re-runs k_mesh once with the exact size. ----
+    const unsigned long long key = ((unsigned long long)nx << 42) ^ ((unsigned long long)ny << 21) ^ (unsigned long long)nz ^
+                                   ((unsigned long long)shard_index << 56) ^ ((unsigned long long)shard_count << 48) ^
+                                   ((unsigned long long)bs << 36) ^ (sparse ? 1ull << 63 : 0ull);
+    unsigned long long cap;
+    MeshCounters h;
+    if (t->hint_key == key && t->hint_total_tris) {
+        cap = t->hint_total_tris + t->hint_total_tris / 4 + 4096;
+    } else {
+        HIPCHK(hipMemcpyAsync(&h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const unsigned long long nshard0 = (unsigned long long)std::max(h.work_end - h.work_begin, 1);
+        cap = std::max<unsigned long long>(4096ull * nshard0, 1ull << 16);
+    }
     float ms = 0;
+    for (int attempt = 0;; attempt++) {
+        if (!m->arena.p && !c->arena_pool.empty()) { m->arena = c->arena_pool.back(); c->arena_pool.pop_back(); }
+        if (m->arena.ensure((size_t)cap * 36)) return 1;
+        cap = m->arena.bytes / 36;
+        if (attempt) HIPCHK(hipMemsetAsync(c->counters.p, 0, MESH_COUNTERS_RESET_BYTES, c->stream));
+        MeshArgs a;
+        a.g = g; a.worklist = (const int *)m->worklist.p;
+        a.kinds = (unsigned char *)m->kinds.p; a.batch_count = (unsigned *)m->batch_count.p;
+        a.batch_base = (unsigned long long *)m->batch_base.p; a.arena = (float *)m->arena.p; a.arena_cap = cap;
+        a.ctr = (MeshCounters *)c->counters.p;
+        a.mc = (const McTables *)c->mc.p;
+        a.prof = (unsigned long long *)c->prof.p;
+        if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 64, c->stream));
+        const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        if (launch_mesh(t, precision, a, grid, bs)) return 1;
+        HIPCHK(hipEventRecord(c->ev[4], c->stream));
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)m->batch_count.p,
+                           (unsigned long long *)m->batch_final.p, (MeshCounters *)c->counters.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+        m->st.ms_mesh = ms;
+        if (c->prof.p) {
+            unsigned long long pc[8];
+            HIPCHK(hipMemcpy(pc, c->prof.p, 64, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu list %llu emit %llu tail %llu\n",
+                    ms, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5]);
+        }
+        m->st.n_retries = attempt;
+        if (h.overflow) {
+            if (attempt >= 3) return fail("sdf_generate: triangle arena overflow persists");
+            cap = h.tri_counter + h.tri_counter / 8 + 1024;   // exact need is known now
+            continue;
+        }
+        break;
+    }
+    m->work_begin = h.work_begin; m->work_end = h.work_end;
+    m->st.n_skipped = nb - h.nwork;
+    m->st.n_work_begin = m->work_begin; m->st.n_work_end = m->work_end;
+    m->st.n_triangles = (int64_t)h.total;
+    m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
+    m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
+    t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
     HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
     m->st.ms_prepass = ms;
-    if (nshard > 0) {
-        if (m->batch_count.ensure((size_t)nwork * 4) || m->batch_base.ensure((size_t)nwork * 8) ||
-            m->batch_final.ensure((size_t)nwork * 8))
-            return 1;
-        HIPCHK(hipMemsetAsync(m->batch_count.p, 0, (size_t)nwork * 4, c->stream));
-        // arena: start from the model's last observed density (or 4096 triangles per batch)
-        unsigned long long per = t->hint_tris_per_batch ? t->hint_tris_per_batch + t->hint_tris_per_batch / 4 + 64 : 4096ull;
-        unsigned long long cap = std::max<unsigned long long>(per * (unsigned long long)nshard, 1ull << 16);
-        for (int attempt = 0;; attempt++) {
-            if (!m->arena.p && !c->arena_pool.empty()) { m->arena = c->arena_pool.back(); c->arena_pool.pop_back(); }
-            if (m->arena.ensure((size_t)cap * 36)) return 1;
-            cap = m->arena.bytes / 36;
-            HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(MeshCounters), c->stream));
-            MeshArgs a;
-            a.g = g; a.worklist = (const int *)m->worklist.p; a.work_begin = m->work_begin; a.work_end = m->work_end;
-            a.kinds = (unsigned char *)m->kinds.p; a.batch_count = (unsigned *)m->batch_count.p;
-            a.batch_base = (unsigned long long *)m->batch_base.p; a.arena = (float *)m->arena.p; a.arena_cap = cap;
-            a.ctr = (MeshCounters *)c->counters.p;
-            const int grid = std::min(nshard, c->n_cu);
-            HIPCHK(hipEventRecord(c->ev[3], c->stream));
-            a.mc = (const McTables *)c->mc.p;
-            a.prof = (unsigned long long *)c->prof.p;
-            if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 64, c->stream));
-            if (launch_mesh(t, precision, a, grid, bs)) return 1;
-            HIPCHK(hipEventRecord(c->ev[4], c->stream));
-            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)m->batch_count.p, m->work_begin,
-                               m->work_end, (unsigned long long *)m->batch_final.p, (MeshCounters *)c->counters.p);
-            HIPCHK(hipGetLastError());
-            MeshCounters h;
-            HIPCHK(hipMemcpyAsync(&h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-            m->st.ms_mesh = ms;
-            if (c->prof.p) {
-                unsigned long long pc[8];
-                HIPCHK(hipMemcpy(pc, c->prof.p, 64, hipMemcpyDeviceToHost));
-                fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu list %llu emit %llu tail %llu\n",
-                        ms, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5]);
-            }
-            m->st.n_retries = attempt;
-            if (h.overflow) {
-                if (attempt >= 3) return fail("sdf_generate: triangle arena overflow persists");
-                cap = h.tri_counter + h.tri_counter / 8 + 1024;   // exact need is known now
-                continue;
-            }
-            m->st.n_triangles = (int64_t)h.total;
-            m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
-            m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
-            t->hint_tris_per_batch = (h.total + (unsigned long long)nshard - 1) / (unsigned long long)nshard;
-            break;
-        }
-    }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));
     HIPCHK(hipEventSynchronize(c->ev[5]));
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[5]));
