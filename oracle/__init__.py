@@ -84,7 +84,7 @@ def marching_cubes(volume):
         return np.zeros((0, 3), np.float32), 0
     if vol.size and (0 < vol.min() or 0 > vol.max()):
         return np.zeros((0, 3), np.float32), 0
-    cap = 5 * max(1, (vol.shape[0] - 1) * (vol.shape[1] - 1) * (vol.shape[2] - 1))
+    cap = 12 * max(1, (vol.shape[0] - 1) * (vol.shape[1] - 1) * (vol.shape[2] - 1))
     out = np.empty((cap, 9), np.float32)
     namb = ctypes.c_int64(0)
     nt = lib().sdf_oracle_marching_cubes(_p(vol, _f32p), vol.shape[0], vol.shape[1], vol.shape[2],

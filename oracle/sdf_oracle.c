@@ -10,19 +10,19 @@
  *   eval_node()            the closure tree             reference sdf/d3.py, sdf/d2.py, sdf/dn.py,
  *                                                       sdf/ease.py  (file:line at every case)
  *   oracle_marching_cubes  skimage 0.18.3 measure.marching_cubes(volume, 0) as called by
- *                          reference sdf/core.py:16-18 -- third-party code that is not in
- *                          /root/reference; restated from its observed behaviour (SURVEY.md
- *                          App. B) with the per-cell table obtained by running it
- *                          (oracle/mc_table.h, tools/derive_mc_tables.py)
+ *                          reference sdf/core.py:16-18 -- third-party code (Lewiner's MC33) that
+ *                          is not in /root/reference; restated from the published algorithm and
+ *                          its observed behaviour (oracle/mc33.h) with the
+ *                          lookup tables obtained from the installed package
+ *                          (oracle/mc_table.h, oracle/mc33_tables.h; tools/derive_mc*_tables.py)
  *   oracle_skip            reference sdf/core.py:28-43
  *   oracle_generate        reference sdf/core.py:45-60 (_worker) + :114-141 (batch loop)
  *   oracle_estimate_bounds reference sdf/core.py:62-82
  *
- * Parity pinning: tests/test_oracle.py checks every function here against tests/golden/*.npz,
+ * Parity pinning: tests/test_oracle.py checks every function here against tests/golden/ (npz files),
  * which tools/make_golden.py produced by running the unmodified reference (Python 3.9,
- * numpy 1.26.4, scikit-image 0.18.3).  Known limit, stated in DESIGN.md: cells whose sign
- * configuration is ambiguous (MC_AMBIGUOUS) are tiled with the classic table, while skimage's
- * Lewiner method may choose another tiling of the same vertices.
+ * numpy 1.26.4, scikit-image 0.18.3): values, bounds, batch classification, marching cubes on
+ * volumes that reach every Lewiner case, and whole `generate` soups bit for bit.
  *
  * The tree comes from sdf_amd.ir.flatten(): nodes[n][5] = {op, param_off, nparams, child_off,
  * nchildren}, params[], children[].  It is evaluated by recursion, one point at a time -- on
@@ -34,6 +34,7 @@
 #include <string.h>
 
 #include "mc_table.h"
+#include "mc33.h"
 #include "node_ops.h"
 
 typedef struct {
@@ -520,8 +521,23 @@ static inline void mc_vertex(const float *v, int64_t s0, int64_t s1, int i0, int
     o[0] = (float)pos[0]; o[1] = (float)pos[1]; o[2] = (float)pos[2];
 }
 
+/* centre vertex of a cell (Lewiner's 13th vertex) as skimage places it: the centre of mass of
+ * the 8 corners weighted by w = 1/(eps + |v|), float64 arithmetic, stored as float32 */
+static void mc_centre_vertex(const double *lv, int i0, int i1, int i2, float *o) {
+    static const int X[8] = {0, 1, 1, 0, 0, 1, 1, 0}, Y[8] = {0, 0, 1, 1, 0, 0, 1, 1}, Z[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    double fx = 0, fy = 0, fz = 0, ff = 0;
+    for (int p = 0; p < 8; p++) {
+        double w = 1.0 / (MC_EPS + fabs(lv[p]));
+        fx += X[p] * w; fy += Y[p] * w; fz += Z[p] * w; ff += w;
+    }
+    /* Lewiner x, y, z = volume axes 2, 1, 0 */
+    o[0] = (float)((double)i0 + fz / ff); o[1] = (float)((double)i1 + fy / ff); o[2] = (float)((double)i2 + fx / ff);
+}
+
 /* volume: C-order float32 (n0,n1,n2).  Returns the triangle count; writes up to cap
- * triangles (9 floats each) to out.  Counts also the ambiguous cells it met.
+ * triangles (9 floats each) to out.  Counts also the cells whose sign configuration is
+ * ambiguous (they are tiled by Lewiner's tests, mc33.h; all others by the classic table, which
+ * is what Lewiner's tables reduce to there -- tools/derive_mc33_tables.py checks that).
  * Pre-checks of skimage: any dim < 2, or level outside [min,max] -> no surface. */
 int64_t sdf_oracle_marching_cubes(const float *vol, int n0, int n1, int n2, float *out, int64_t cap,
                                   int64_t *n_ambiguous) {
@@ -533,11 +549,30 @@ int64_t sdf_oracle_marching_cubes(const float *vol, int n0, int n1, int n2, floa
             for (int i2 = 0; i2 < n2 - 1; i2++) {
                 const float *v = vol + i0 * s0 + i1 * s1 + i2;
                 int cfg = mc_config(v, s0, s1);
-                int k = MC_NTRI[cfg];
-                if (!k) continue;
-                namb += MC_AMBIGUOUS[cfg];
-                for (int j = 0; j < 3 * k; j++) {
-                    if (nt + j / 3 < cap) mc_vertex(v, s0, s1, i0, i1, i2, MC_TRI[cfg][j], out + (nt + j / 3) * 9 + (j % 3) * 3);
+                if (cfg == 0 || cfg == 255) continue;
+                if (!MC_AMBIGUOUS[cfg]) {
+                    int k = MC_NTRI[cfg];
+                    for (int j = 0; j < 3 * k; j++)
+                        if (nt + j / 3 < cap) mc_vertex(v, s0, s1, i0, i1, i2, MC_TRI[cfg][j], out + (nt + j / 3) * 9 + (j % 3) * 3);
+                    nt += k;
+                    continue;
+                }
+                namb++;
+                double lv[8];   /* the cell in Lewiner corner order */
+                for (int p = 0; p < 8; p++) {
+                    int c = MC33_CORNER[p];
+                    lv[p] = (double)v[(c >> 2) * s0 + ((c >> 1) & 1) * s1 + (c & 1)];
+                }
+                const signed char *til;
+                int k = mc33_cell(lv, &til);
+                for (int j = 0; j < k; j++) {
+                    if (nt + j >= cap) continue;
+                    for (int q = 0; q < 3; q++) {
+                        int e = til[3 * j + 2 - q];   /* gradient_direction='descent' flips every face */
+                        float *o = out + (nt + j) * 9 + q * 3;
+                        if (e == 12) mc_centre_vertex(lv, i0, i1, i2, o);
+                        else mc_vertex(v, s0, s1, i0, i1, i2, MC33_EDGE[e], o);
+                    }
                 }
                 nt += k;
             }
@@ -587,7 +622,7 @@ oracle_result *sdf_oracle_generate(const int32_t *nodes, const double *params, c
     R->tris = (double *)malloc(sizeof(double) * 9 * R->cap);
     int m = batch + 1;
     float *vol = (float *)malloc(sizeof(float) * m * m * m);
-    float *loc = (float *)malloc(sizeof(float) * 9 * 5 * (size_t)batch * batch * batch);
+    float *loc = (float *)malloc(sizeof(float) * 9 * 12 * (size_t)batch * batch * batch);
     if (batch_end < 0 || batch_end > R->nbatches) batch_end = R->nbatches;
     for (int64_t b = batch_begin; b < batch_end; b++) {
         int ibx = (int)(b / ((int64_t)by * bz)), iby = (int)((b / bz) % by), ibz = (int)(b % bz);
@@ -607,7 +642,7 @@ oracle_result *sdf_oracle_generate(const int32_t *nodes, const double *params, c
             float mn = INFINITY, mx = -INFINITY;
             for (int64_t i = 0; i < (int64_t)lx * ly * lz; i++) { if (vol[i] < mn) mn = vol[i]; if (vol[i] > mx) mx = vol[i]; }
             if (lx >= 2 && ly >= 2 && lz >= 2 && !(0.0f < mn) && !(0.0f > mx))
-                k = sdf_oracle_marching_cubes(vol, lx, ly, lz, loc, (int64_t)5 * batch * batch * batch, &namb);
+                k = sdf_oracle_marching_cubes(vol, lx, ly, lz, loc, (int64_t)12 * batch * batch * batch, &namb);
         }
         R->n_ambiguous += namb;
         if (k == 0) { R->kinds[b] = 1; continue; }

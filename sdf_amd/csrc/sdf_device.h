@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "sdf_interp.h"
+#include "sdf_mc33.h"
 
 namespace sdfk {
 
@@ -26,6 +27,7 @@ struct McTables {   // uploaded once per context
     unsigned char ntri[256];   // triangles per sign configuration
     unsigned char amb[256];    // 1 when the configuration is ambiguous (classic table vs Lewiner)
     signed char tri[256][16];  // edge ids, 3 per triangle
+    signed char mc33[MC33_FLAT_SIZE];   // Lewiner's tables for the ambiguous configurations (sdf_mc33.h)
 };
 
 struct MeshCounters {   // zeroed before every k_mesh run
@@ -124,6 +126,24 @@ __device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0
     o[0] = (float)p0; o[1] = (float)p1; o[2] = (float)p2;
 }
 
+// triangle j of an ambiguous cell: re-runs the selection (cheaper than carrying the tiling through
+// the LDS work list for the few cells concerned), applies skimage's face flip for
+// gradient_direction='descent' and places the three vertices
+__device__ __noinline__ void mc33_triangle(const float *corner, int s0, int s1, int i0, int i1, int i2,
+                                           const signed char *tab, int j, float *o) {
+    double lv[8];
+    int off;
+    mc33_load_cell(corner, s0, s1, lv);
+    const int n = mc33_cell(lv, tab, &off);
+    if (j >= n) { for (int q = 0; q < 9; q++) o[q] = 0.0f; return; }
+    const signed char lew_edge[12] = {8, 5, 9, 4, 10, 7, 11, 6, 0, 1, 3, 2};   // MC33_EDGE
+    for (int q = 0; q < 3; q++) {
+        const int e = tab[off + 3 * j + 2 - q];
+        if (e == 12) mc33_centre_vertex(lv, i0, i1, i2, o + 3 * q);
+        else mc_vertex(corner, s0, s1, i0, i1, i2, lew_edge[e], o + 3 * q);
+    }
+}
+
 template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
     typedef Vec<T, NS> V;
@@ -199,8 +219,16 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 for (int i2 = 0; i2 < c2; i2++) {
                     const unsigned next = plane_bits(row + i2 + 1, lyz, lz);
                     const unsigned e = ntri_lds[spread4(prev) | (spread4(next) << 1)];
-                    n += (int)(e & 7u);
-                    if (e) { mask |= 1u << i2; my_amb += (int)(e >> 7); }
+                    if (e & 128u) {   // ambiguous configuration: Lewiner's tests pick the tiling (rare)
+                        double lv[8];
+                        int off;
+                        mc33_load_cell(row + i2, lyz, lz, lv);
+                        n += mc33_cell(lv, a.mc->mc33, &off);
+                        my_amb++;
+                    } else {
+                        n += (int)(e & 7u);
+                    }
+                    if (e) mask |= 1u << i2;
                     prev = next;
                 }
             }
@@ -245,8 +273,16 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     const int i2 = __ffs((int)m) - 1;
                     m &= m - 1u;
                     const unsigned cfg = spread4(plane_bits(row + i2, lyz, lz)) | (spread4(plane_bits(row + i2 + 1, lyz, lz)) << 1);
-                    const int n = (int)(ntri_lds[cfg] & 7u);
-                    const unsigned e = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 11) | (cfg << 3);
+                    const unsigned en = ntri_lds[cfg];
+                    int n = (int)(en & 7u);
+                    if (en & 128u) {
+                        double lv[8];
+                        int off;
+                        mc33_load_cell(row + i2, lyz, lz, lv);
+                        n = mc33_cell(lv, a.mc->mc33, &off);
+                    }
+                    // entry: cell (15 bits) | ambiguous (1) | configuration (8) | triangle in cell (4)
+                    const unsigned e = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((en & 128u) << 5) | (cfg << 4);
                     for (int j = 0; j < n; j++, pos++)
                         if (pos >= 0 && pos < cn) list[pos] = e | (unsigned)j;
                 }
@@ -256,14 +292,18 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             float *dst0 = a.arena + (base + (unsigned long long)lo) * 9ull;
             for (int t = tid; t < cn; t += BLOCK) {
                 const unsigned e = list[t];
-                const int j = (int)(e & 7u), cfg = (int)((e >> 3) & 255u), cell = (int)(e >> 11);
+                const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
                 const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
                 const float *corner = vol + i0 * lyz + i1 * lz + i2;
-                const signed char *tt = tri_tab + cfg * 16 + 3 * j;
                 float o[9];
-                mc_vertex(corner, lyz, lz, i0, i1, i2, tt[0], o);
-                mc_vertex(corner, lyz, lz, i0, i1, i2, tt[1], o + 3);
-                mc_vertex(corner, lyz, lz, i0, i1, i2, tt[2], o + 6);
+                if (e & 4096u) {
+                    mc33_triangle(corner, lyz, lz, i0, i1, i2, a.mc->mc33, j, o);
+                } else {
+                    const signed char *tt = tri_tab + cfg * 16 + 3 * j;
+                    mc_vertex(corner, lyz, lz, i0, i1, i2, tt[0], o);
+                    mc_vertex(corner, lyz, lz, i0, i1, i2, tt[1], o + 3);
+                    mc_vertex(corner, lyz, lz, i0, i1, i2, tt[2], o + 6);
+                }
                 float *dst = dst0 + (size_t)t * 9;
                 SDF_UNROLL
                 for (int q = 0; q < 9; q++) dst[q] = o[q];

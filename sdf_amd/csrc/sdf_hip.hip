@@ -170,7 +170,15 @@ __global__ __launch_bounds__(256) void k_mc_rows(const McTables *__restrict__ mc
     unsigned cnt = 0;
     for (int i2 = 0; i2 < c2; i2++) {
         const unsigned next = plane_bits(row + i2 + 1, s0, s1);
-        cnt += mc->ntri[spread4(prev) | (spread4(next) << 1)];
+        const unsigned cfg = spread4(prev) | (spread4(next) << 1);
+        if (mc->amb[cfg]) {
+            double lv[8];
+            int off;
+            mc33_load_cell(row + i2, s0, s1, lv);
+            cnt += (unsigned)mc33_cell(lv, mc->mc33, &off);
+        } else {
+            cnt += mc->ntri[cfg];
+        }
         prev = next;
     }
     row_count[t] = cnt;
@@ -207,6 +215,17 @@ __global__ __launch_bounds__(256) void k_mc_emit(const McTables *__restrict__ mc
         const unsigned next = plane_bits(row + i2 + 1, s0, s1);
         const unsigned cfg = spread4(prev) | (spread4(next) << 1);
         prev = next;
+        if (mc->amb[cfg]) {
+            double lv[8];
+            int off;
+            mc33_load_cell(row + i2, s0, s1, lv);
+            const int nt = mc33_cell(lv, mc->mc33, &off);
+            for (int j = 0; j < nt; j++, k++) {
+                if (k >= cap) return;
+                mc33_triangle(row + i2, s0, s1, i0, i1, i2, mc->mc33, j, out + k * 9ull);
+            }
+            continue;
+        }
         const int nt = mc->ntri[cfg];
         for (int j = 0; j < nt; j++, k++) {
             if (k >= cap) return;
@@ -374,6 +393,7 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     memcpy(t.ntri, MC_NTRI, 256);
     memcpy(t.amb, MC_AMBIGUOUS, 256);
     memcpy(t.tri, MC_TRI, sizeof(t.tri));
+    memcpy(t.mc33, MC33_FLAT, sizeof(t.mc33));
     if (c->mc.ensure(sizeof(t))) return 1;
     HIPCHK(hipMemcpy(c->mc.p, &t, sizeof(t), hipMemcpyHostToDevice));
     if (const char *e = getenv("SDF_MESH_SHAPE")) c->mesh_shape = atoi(e);

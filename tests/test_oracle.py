@@ -53,16 +53,25 @@ MC_NAMES = sorted(k[4:] for k in MC.files if k.startswith('vol_'))
 def test_marching_cubes_matches_skimage(name, oracle_lib):
     soup, namb = oracle_lib.marching_cubes(MC['vol_' + name])
     ref = MC['soup_' + name]
-    if namb == 0:
-        # no ambiguous cell: bit-identical soup, same order
-        assert soup.shape == ref.shape
-        assert np.array_equal(soup.view(np.uint32), ref.view(np.uint32))
-    else:
-        # ambiguous cells: skimage's Lewiner tiling may differ (documented limit); our vertex
-        # set is still a subset of skimage's (it only adds centre vertices in some tilings)
-        mine = {tuple(r) for r in soup.view(np.uint32).reshape(-1, 3).tolist()}
-        theirs = {tuple(r) for r in ref.view(np.uint32).reshape(-1, 3).tolist()}
-        assert mine <= theirs
+    # bit-identical soup in skimage's order, ambiguous (Lewiner-tested) cells included
+    assert soup.shape == ref.shape
+    assert np.array_equal(soup.view(np.uint32), ref.view(np.uint32))
+
+
+MC33 = np.load(os.path.join(GOLDEN, 'mc33_volumes.npz'))
+MC33_NAMES = sorted(k[4:] for k in MC33.files if k.startswith('vol_'))
+
+
+@pytest.mark.parametrize('name', MC33_NAMES)
+def test_marching_cubes_lewiner_cases_match_skimage(name, oracle_lib):
+    """noise / integer / saddle volumes that reach every Lewiner case, subcase and the centre
+    vertex (tools/make_golden_mc33.py): the soup must be skimage's bit for bit"""
+    soup, namb = oracle_lib.marching_cubes(MC33['vol_' + name])
+    ref = MC33['soup_' + name]
+    assert soup.shape == ref.shape
+    assert np.array_equal(soup.view(np.uint32), ref.view(np.uint32))
+    if name.startswith('noise'):
+        assert namb > 100
 
 
 GEN = sorted(glob.glob(os.path.join(GOLDEN, 'gen_*.npz')))
@@ -77,16 +86,7 @@ def test_generate_matches_reference(path, ns, oracle_lib):
     X, Y, Z, _ = core.grid_axes(bounds, d['step'].tolist())
     r = oracle_lib.generate(f, X, Y, Z, kw.get('batch_size', 32), kw.get('sparse', True))
     assert np.array_equal(r.kinds, d['kinds'])          # skipped / empty / nonempty per batch
-    if r.n_ambiguous == 0:
-        assert len(r.points) // 3 == int(d['ntri'])
-        assert hashlib.sha256(r.points.tobytes()).digest() == d['sha256'].tobytes()
-        if 'points' in d.files:
-            assert np.array_equal(r.points, d['points'])
-    else:
-        # Lewiner may tile ambiguous cells differently (documented limit): the
-        # triangle count may differ there, but every vertex we emit is one skimage emits too
-        assert abs(len(r.points) // 3 - int(d['ntri'])) <= 4 * r.n_ambiguous
-        if 'points' in d.files:
-            mine = {tuple(v) for v in r.points.tolist()}
-            theirs = {tuple(v) for v in d['points'].tolist()}
-            assert mine <= theirs
+    assert len(r.points) // 3 == int(d['ntri'])
+    assert hashlib.sha256(r.points.tobytes()).digest() == d['sha256'].tobytes()
+    if 'points' in d.files:
+        assert np.array_equal(r.points, d['points'])
