@@ -164,13 +164,19 @@ def main():
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     plain, special = tape.tape.flop_estimate()
     eval_vox = int(st['n_eval_voxels']) if world == 1 else int(st['n_eval_voxels'] // world)
+    # HBM traffic of k_mesh per launch from the PMC passes of tools/profile.sh (separate rocprofv3
+    # --pmc runs of this same command; FETCH_SIZE/WRITE_SIZE corrected as MI355X_MICROARCH.md says,
+    # see tools/summarize_prof.py); the newest committed summary is used
     traffic = None
-    prof = os.path.join(ROOT, 'profiles', 'r01_pmc_k_mesh.json')
-    if os.path.exists(prof) and args.model == 'example' and args.samples_log2 == 27 and world == 1:
-        try:
-            traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
+    if args.model == 'example' and args.samples_log2 == 27 and world == 1 and args.precision == 'f64':
+        import glob
+        for prof in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')), reverse=True):
+            try:
+                traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+            if traffic:
+                break
     roofline = {
         'kernel': 'k_mesh<%s>' % ('double' if args.precision == 'f64' else 'float'),
         'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

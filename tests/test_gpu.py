@@ -268,3 +268,40 @@ def test_full_size_config2_properties(ns, eng):
     # Euler characteristic of a closed orientable surface is even (genus-5 solid here: 2 - 2*5)
     V, E, F = len(verts), len(directed) // 2, len(tri)
     assert V - E + F == 2 - 2 * 5
+
+
+# BASELINE.json configs at their full sizes: batch classification and triangle counts the
+# UNMODIFIED reference produced in the build container (measured by running
+# it; the soups themselves are too large to commit).  Bounds come from the device `_estimate_bounds`.
+FULL_SIZE = [
+    # fixture, samples, (batches, skipped, empty, nonempty), triangles
+    ('ex_example', 2 ** 22, (216, 44, 60, 112), 291028),
+    ('ex_example', 2 ** 27, (4096, 2352, 120, 1624), 2945152),
+    ('ex_gearlike', 2 ** 30, (33856, 26754, 2098, 5004), 10204096),
+    ('ex_blobby', 2 ** 30, (32768, 30136, 608, 2024), 4048520),
+    ('ex_weave', 2 ** 24, (578, 162, 32, 384), 836368),
+]
+
+
+@pytest.mark.parametrize('name,samples,counts,tris', FULL_SIZE, ids=['%s-2^%d' % (n[3:], s.bit_length() - 1) for n, s, _, _ in FULL_SIZE])
+def test_full_size_configs_match_reference_counts(name, samples, counts, tris, ns, eng):
+    f = fixtures.build(name, ns)
+    bounds = core._estimate_bounds(f)
+    X, Y, Z, _ = core.grid_axes(bounds, samples=samples)
+    mesh = eng.generate(f, X, Y, Z, 32, True)
+    st = mesh.stats()
+    assert (st['batches'], st['skipped'], st['empty'], st['nonempty']) == counts
+    assert st['triangles'] == tris
+    # size-independent properties of the soup: inside the sampled box, finite, reference order
+    pts = mesh.points()
+    kinds = mesh.kinds()
+    mesh.close()
+    assert pts.shape == (3 * tris, 3) and np.isfinite(pts).all()
+    lo = np.array([X[0], Y[0], Z[0]]); hi = np.array([X[-1], Y[-1], Z[-1]])
+    assert (pts >= lo).all() and (pts <= hi).all()
+    assert int((kinds == 2).sum()) == counts[3]
+    # batches are emitted in X-major batch order: the x batch index of the triangle centroids
+    # never decreases along the soup
+    cx = pts[:, 0].reshape(-1, 3).mean(axis=1)
+    bi = np.minimum(((cx - X[0]) / ((X[1] - X[0]) * 32)).astype(np.int64), (len(X) - 1) // 32)
+    assert (np.diff(bi) >= 0).all()
