@@ -91,12 +91,15 @@ def main():
 
     def one_step():
         if world == 1:
-            mesh = eng.generate(tape, X, Y, Z, 32, True)
-            t = mesh.n_triangles
+            # the output buffer is sized from the previous step (first step: a guess); the ordered
+            # gather into it is part of the same submission; if it does not fit it is emitted again
             buf = state.get('buf')
-            if buf is None or buf.numel() < t * 9:
-                buf = state['buf'] = torch.empty(max(t, 1) * 9, dtype=torch.float64, device=dev)
-            if t:
+            if buf is None:
+                buf = state['buf'] = torch.empty(9 * (1 << 22), dtype=torch.float64, device=dev)
+            mesh = eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9)
+            t = mesh.n_triangles
+            if not mesh.emitted:
+                buf = state['buf'] = torch.empty(max(t + t // 8, 1) * 9, dtype=torch.float64, device=dev)
                 mesh.emit_device(buf.data_ptr())
             state['stats'] = mesh.stats()
             state['tris'] = t

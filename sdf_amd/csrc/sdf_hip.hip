@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -132,12 +133,17 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned int *__restrict__ 
 
 // ordered gather + float64 world transform: out[final + i] = f64(local) * scale + offset
 // (reference sdf/core.py:58-60).  One workgroup per work item.
-__global__ __launch_bounds__(256) void k_gather(GridDesc g, const int *__restrict__ worklist, int w0,
+// The work range and the total come from the device-side counters, so the kernel can be enqueued
+// right behind k_scan without the host knowing them; it does nothing when the soup does not fit
+// `cap_out` triangles or the meshing pass overflowed its arena (the host sees both in the counters).
+__global__ __launch_bounds__(256) void k_gather(GridDesc g, const int *__restrict__ worklist,
+                                                const MeshCounters *__restrict__ ctr, unsigned long long cap_out,
                                                 const unsigned int *__restrict__ batch_count,
                                                 const unsigned long long *__restrict__ batch_base,
                                                 const unsigned long long *__restrict__ batch_final,
                                                 const float *__restrict__ arena, double *__restrict__ out) {
-    const int w = w0 + blockIdx.x;
+    const int w = ctr->work_begin + blockIdx.x;
+    if (w >= ctr->work_end || ctr->overflow || ctr->total > cap_out) return;
     const unsigned n = batch_count[w];
     if (!n) return;
     const int b = worklist[w];
@@ -274,33 +280,82 @@ static int fail(const std::string &m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
+// Device allocations are recycled through a small per-device free list: hipMalloc / hipFree cost
+// tens of microseconds each (and hipFree synchronises), which at ~1 ms per generate call was 10 %
+// of the step when every mesh allocated and freed its seven buffers.
+struct DevPool {
+    struct Blk { void *p; size_t bytes; int device; };
+    std::vector<Blk> free_list;
+    std::mutex mu;
+    void *take(size_t need, int device, size_t *got) {
+        std::lock_guard<std::mutex> g(mu);
+        int best = -1;
+        for (int i = 0; i < (int)free_list.size(); i++) {
+            const Blk &b = free_list[i];
+            if (b.device != device || b.bytes < need || b.bytes > std::max<size_t>(4 * need, 1 << 16)) continue;
+            if (best < 0 || b.bytes < free_list[best].bytes) best = i;
+        }
+        if (best < 0) return nullptr;
+        void *p = free_list[best].p;
+        *got = free_list[best].bytes;
+        free_list.erase(free_list.begin() + best);
+        return p;
+    }
+    void give(void *p, size_t bytes, int device) {
+        std::lock_guard<std::mutex> g(mu);
+        if (free_list.size() >= 48) {   // evict the oldest block
+            (void)hipFree(free_list.front().p);
+            free_list.erase(free_list.begin());
+        }
+        free_list.push_back({p, bytes, device});
+    }
+    void drop_device(int device) {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < free_list.size();) {
+            if (free_list[i].device == device) { (void)hipFree(free_list[i].p); free_list.erase(free_list.begin() + i); }
+            else i++;
+        }
+    }
+};
+static DevPool g_pool;
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    int device = -1;
     int ensure(size_t need) {
         if (need <= bytes) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
+        release();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
         size_t want = std::max(need, (size_t)256);
+        want = (want + 255) & ~(size_t)255;
+        size_t got = 0;
+        if (void *q = g_pool.take(want, dev, &got)) { p = q; bytes = got; device = dev; return 0; }
         hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {   // give the cached blocks back to the driver and retry once
+            g_pool.drop_device(dev);
+            e = hipMalloc(&p, want);
+        }
         if (e != hipSuccess) { p = nullptr; return fail(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
-        bytes = want;
+        bytes = want; device = dev;
         return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void release() { if (p) g_pool.give(p, bytes, device); p = nullptr; bytes = 0; }
 };
 
 struct sdf_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
     int n_cu = 256;
     size_t lds_max = 0;
-    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, counters, scratch_in, scratch_out, rows, rows_off, mc;
+    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, scratch_in, scratch_out, rows, rows_off, mc;
     int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
     std::vector<DevBuf> arena_pool;   // arenas handed back by destroyed meshes
+    std::vector<DevBuf> counter_pool; // 64-byte MeshCounters blocks handed back by destroyed meshes
 };
 
 struct sdf_tape {
@@ -319,8 +374,10 @@ struct sdf_mesh {
     sdf_stats st = {};
     GridDesc g = {};
     DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, arena, out;
+    DevBuf counters;               // this call's MeshCounters block (pooled in the context)
     int work_begin = 0, work_end = 0;
     bool emitted = false;
+    void *emitted_to = nullptr;    // caller buffer the soup was gathered into by sdf_generate_to_device
 };
 
 static bool tape_needs_full(const uint32_t *code, uint32_t n_words, const double *consts) {
@@ -407,9 +464,11 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->axes, &c->kinds, &c->worklist, &c->batch_count, &c->batch_base, &c->batch_final, &c->counters, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof})
+    for (DevBuf *b : {&c->axes, &c->kinds, &c->worklist, &c->batch_count, &c->batch_base, &c->batch_final, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof})
         b->release();
     for (auto &b : c->arena_pool) b.release();
+    for (auto &b : c->counter_pool) b.release();
+    g_pool.drop_device(c->device);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -603,7 +662,7 @@ static int launch_mesh(sdf_tape *t, int precision, MeshArgs &a, int grid, int bs
 }
 
 static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
-                         int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision) {
+                         int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out) {
     sdf_ctx *c = t->ctx;
     GridDesc &g = m->g;
     g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
@@ -617,15 +676,17 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
 
     if (m->axes.ensure((size_t)(nx + ny + nz) * 8) || m->kinds.ensure((size_t)nb) || m->worklist.ensure((size_t)nb * 4) ||
         m->batch_count.ensure((size_t)nb * 4) || m->batch_base.ensure((size_t)nb * 8) || m->batch_final.ensure((size_t)nb * 8) ||
-        c->counters.ensure(sizeof(MeshCounters)))
+        false)
         return 1;
+    if (!m->counters.p && !c->counter_pool.empty()) { m->counters = c->counter_pool.back(); c->counter_pool.pop_back(); }
+    if (m->counters.ensure(sizeof(MeshCounters))) return 1;
     double *dX = (double *)m->axes.p, *dY = dX + nx, *dZ = dY + ny;
     g.X = dX; g.Y = dY; g.Z = dZ;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->counters.p, 0, sizeof(MeshCounters), c->stream));
+    HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(MeshCounters), c->stream));
 
     // ---- prepass: skip test for every batch, then the ordered work list (+ this shard's slice) ----
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -636,7 +697,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
     }
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
-                       (MeshCounters *)c->counters.p, (long long)shard_index, (long long)shard_count);
+                       (MeshCounters *)m->counters.p, (long long)shard_index, (long long)shard_count);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
 
@@ -652,7 +713,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     if (t->hint_key == key && t->hint_total_tris) {
         cap = t->hint_total_tris + t->hint_total_tris / 4 + 4096;
     } else {
-        HIPCHK(hipMemcpyAsync(&h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         const unsigned long long nshard0 = (unsigned long long)std::max(h.work_end - h.work_begin, 1);
         cap = std::max<unsigned long long>(4096ull * nshard0, 1ull << 16);
@@ -662,12 +723,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (!m->arena.p && !c->arena_pool.empty()) { m->arena = c->arena_pool.back(); c->arena_pool.pop_back(); }
         if (m->arena.ensure((size_t)cap * 36)) return 1;
         cap = m->arena.bytes / 36;
-        if (attempt) HIPCHK(hipMemsetAsync(c->counters.p, 0, MESH_COUNTERS_RESET_BYTES, c->stream));
+        if (attempt) HIPCHK(hipMemsetAsync(m->counters.p, 0, MESH_COUNTERS_RESET_BYTES, c->stream));
         MeshArgs a;
         a.g = g; a.worklist = (const int *)m->worklist.p;
         a.kinds = (unsigned char *)m->kinds.p; a.batch_count = (unsigned *)m->batch_count.p;
         a.batch_base = (unsigned long long *)m->batch_base.p; a.arena = (float *)m->arena.p; a.arena_cap = cap;
-        a.ctr = (MeshCounters *)c->counters.p;
+        a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
         if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 64, c->stream));
@@ -676,12 +737,25 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (launch_mesh(t, precision, a, grid, bs)) return 1;
         HIPCHK(hipEventRecord(c->ev[4], c->stream));
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)m->batch_count.p,
-                           (unsigned long long *)m->batch_final.p, (MeshCounters *)c->counters.p);
+                           (unsigned long long *)m->batch_final.p, (MeshCounters *)m->counters.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        if (d_out && cap_out > 0) {   // the ordered gather rides in the same submission (no host round trip)
+            HIPCHK(hipEventRecord(c->ev[6], c->stream));
+            hipLaunchKernelGGL(k_gather, dim3(nb), dim3(256), 0, c->stream, g, (const int *)m->worklist.p,
+                               (const MeshCounters *)m->counters.p, (unsigned long long)cap_out, (const unsigned *)m->batch_count.p,
+                               (const unsigned long long *)m->batch_base.p, (const unsigned long long *)m->batch_final.p,
+                               (const float *)m->arena.p, (double *)d_out);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev[7], c->stream));
+        }
+        HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
         m->st.ms_mesh = ms;
+        if (d_out && cap_out > 0) {
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+            m->st.ms_emit = ms;
+        }
         if (c->prof.p) {
             unsigned long long pc[8];
             HIPCHK(hipMemcpy(pc, c->prof.p, 64, hipMemcpyDeviceToHost));
@@ -700,6 +774,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     m->st.n_skipped = nb - h.nwork;
     m->st.n_work_begin = m->work_begin; m->st.n_work_end = m->work_end;
     m->st.n_triangles = (int64_t)h.total;
+    m->emitted_to = (d_out && cap_out > 0 && h.total <= (unsigned long long)cap_out) ? d_out : nullptr;
     m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
     m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
@@ -716,8 +791,9 @@ extern "C" {
 
 int sdf_mesh_destroy(sdf_mesh *m);
 
-int sdf_generate(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
-                 int sparse, int64_t shard_index, int64_t shard_count, int precision, sdf_mesh **out) {
+static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
+                          int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out,
+                          sdf_mesh **out) {
     if (!t || !X || !Y || !Z || !out) return fail("sdf_generate: NULL argument");
     *out = nullptr;
     if (bs < 1 || bs > 32) return fail("sdf_generate: batch_size must be in 1..32 (the (batch_size+1)^3 float32 tile lives in LDS)");
@@ -728,13 +804,28 @@ int sdf_generate(sdf_tape *t, const double *X, int nx, const double *Y, int ny, 
     HIPCHK(hipSetDevice(c->device));
     sdf_mesh *m = new sdf_mesh();
     m->ctx = c;
-    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision)) {
+    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out)) {
         const std::string keep = g_err;
         sdf_mesh_destroy(m);
         g_err = keep;
         return 1;
     }
     *out = m;
+    return 0;
+}
+
+int sdf_generate(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
+                 int sparse, int64_t shard_index, int64_t shard_count, int precision, sdf_mesh **out) {
+    return generate_entry(t, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, nullptr, 0, out);
+}
+
+int sdf_generate_to_device(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
+                           int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out,
+                           int64_t cap_tris, int *emitted, sdf_mesh **out) {
+    if (emitted) *emitted = 0;
+    if (!d_out || cap_tris <= 0) return fail("sdf_generate_to_device: output buffer is NULL or empty");
+    if (generate_entry(t, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_tris, out)) return 1;
+    if (emitted) *emitted = ((*out)->emitted_to == d_out || (*out)->st.n_triangles == 0) ? 1 : 0;
     return 0;
 }
 
@@ -753,9 +844,10 @@ int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
     HIPCHK(hipSetDevice(c->device));
     const int nshard = m->work_end - m->work_begin;
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
-    hipLaunchKernelGGL(k_gather, dim3(nshard), dim3(256), 0, c->stream, m->g, (const int *)m->worklist.p, m->work_begin,
-                       (const unsigned *)m->batch_count.p, (const unsigned long long *)m->batch_base.p,
-                       (const unsigned long long *)m->batch_final.p, (const float *)m->arena.p, (double *)d_out);
+    hipLaunchKernelGGL(k_gather, dim3(nshard), dim3(256), 0, c->stream, m->g, (const int *)m->worklist.p,
+                       (const MeshCounters *)m->counters.p, ~0ull, (const unsigned *)m->batch_count.p,
+                       (const unsigned long long *)m->batch_base.p, (const unsigned long long *)m->batch_final.p,
+                       (const float *)m->arena.p, (double *)d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[4], c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -820,6 +912,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
         else m->arena.release();
         m->arena.p = nullptr;
     }
+    if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
     for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->batch_count, &m->batch_base, &m->batch_final, &m->out}) b->release();
     delete m;
     return 0;

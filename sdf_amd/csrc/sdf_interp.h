@@ -203,7 +203,7 @@ template <typename T, bool FULL, int N> SDF_DEV Vec<T, N> ease_apply(int id, con
 template <typename T, int N> SDF_DEV Vec<T, N> post_combine(uint32_t post, const Vec<T, N> &d1, const Vec<T, N> &d2, T K) {
     Vec<T, N> h, m;
     switch (post) {   // wave-uniform
-    case POST_SET: return d2;
+    case POST_SET: return real_move(d2);   // acc and the leaf value keep their own registers (see real_move)
     case POST_UNION: return np_min(d1, d2);
     case POST_DIFF: return np_max(d1, -d2);
     case POST_INTER: return np_max(d1, d2);
@@ -285,26 +285,32 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
 #define SDF_DSET_(R) DS.R = _val
 #define SDF_PGET_(R) _px = PSx.R; _py = PSy.R; _pz = PSz.R
 #define SDF_PSET_(R) PSx.R = _px; PSy.R = _py; PSz.R = _pz
-#define DGET(OUT, s) do { V _dst; SDF_RF_PICK(ND, s, SDF_DGET_); OUT = _dst; } while (0)
-#define DSET(s, ...) do { const V _val = (__VA_ARGS__); SDF_RF_PICK(ND, s, SDF_DSET_); } while (0)
-#define PGET(s, X, Y, Z) do { V _px, _py, _pz; SDF_RF_PICK(NP, s, SDF_PGET_); X = _px; Y = _py; Z = _pz; } while (0)
-#define PSET(s, X, Y, Z) do { const V _px = (X), _py = (Y), _pz = (Z); SDF_RF_PICK(NP, s, SDF_PSET_); } while (0)
+// copies BETWEEN state variables go through late_bind (sdf_vec.h): a plain copy would let the
+// register coalescer merge e.g. a PS slot with the current point, which then costs every op a move
+#define DGET(OUT, s) do { V _dst; SDF_RF_PICK(ND, s, SDF_DGET_); late_bind(_dst); OUT = _dst; } while (0)
+#define DSET(s, ...) do { V _val = (__VA_ARGS__); late_bind(_val); SDF_RF_PICK(ND, s, SDF_DSET_); } while (0)
+#define PGET(s, X, Y, Z) do { V _px, _py, _pz; SDF_RF_PICK(NP, s, SDF_PGET_); late_bind(_px, _py, _pz); X = _px; Y = _py; Z = _pz; } while (0)
+#define PSET(s, X, Y, Z) do { V _px = (X), _py = (Y), _pz = (Z); late_bind(_px, _py, _pz); SDF_RF_PICK(NP, s, SDF_PSET_); } while (0)
 
     // The next instruction's words are requested before the current one executes, so their
     // scalar-cache latency overlaps this instruction's arithmetic (the host pads the code with a
     // second END so the look-ahead of END itself stays inside the buffer).  The loop is a plain
     // do-while with one latch: END sets `done` like any other op instead of leaving from the
     // middle, which keeps the control-flow graph around the jump table reducible and copy-free.
-    uint32_t w0 = __builtin_amdgcn_readfirstlane(code[0]);
-    uint32_t coff = __builtin_amdgcn_readfirstlane(code[1]);
-    uint32_t pc = 2;
+    // (the two words of an instruction travel as ONE loop-carried 64-bit value that is taken apart
+    // at the top of the next pass: a separately carried `coff` made the compiler copy it right
+    // after the load, i.e. wait for the load it had just issued)
+    const unsigned long long *code64 = reinterpret_cast<const unsigned long long *>(code);
+    unsigned long long nw = code64[0];
+    uint32_t pc = 1;
     bool done = false;
     do {
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane((uint32_t)nw);
+        const uint32_t coff = __builtin_amdgcn_readfirstlane((uint32_t)(nw >> 32));
         const uint32_t op = w0 & 255u, post = (w0 >> 8) & 255u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
         const T *c = consts + coff + 1;          // c[-1] is K
-        w0 = __builtin_amdgcn_readfirstlane(code[pc]);
-        coff = __builtin_amdgcn_readfirstlane(code[pc + 1]);
-        pc += 2;
+        nw = code64[pc];
+        pc += 1;
         // Dispatch: ONE indirect jump through a table of s_branch instructions (the compiler only
         // offers a compare-and-branch tree for `switch`, and every taken branch costs an instruction
         // buffer refill).  s_getpc returns the address A of the instruction after it; the table
@@ -483,9 +489,10 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
         L_SCALE:      // d3.py:335-345
             x = x / c[0]; y = y / c[1]; z = z / c[2]; goto next;
         L_ROTATE: {   // d3.py:347-360: p @ M, M row-major
-            const V nx = dot3(x, y, z, c[0], c[3], c[6]);
-            const V ny = dot3(x, y, z, c[1], c[4], c[7]);
-            const V nz = dot3(x, y, z, c[2], c[5], c[8]);
+            V nx = dot3(x, y, z, c[0], c[3], c[6]);
+            V ny = dot3(x, y, z, c[1], c[4], c[7]);
+            V nz = dot3(x, y, z, c[2], c[5], c[8]);
+            late_bind(nx, ny, nz);
             x = nx; y = ny; z = nz; goto next; }
         L_ELONGATE: {  // d3.py:396-405
             const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1], qz = m_fabs(z) - c[2];
@@ -518,15 +525,17 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
         L_TRANSLATE2: x = x - c[0]; y = y - c[1]; goto next;   // d2.py:211-215
         L_SCALE2: x = x / c[0]; y = y / c[1]; goto next;       // d2.py:217-227
         L_ROTATE2: {  // d2.py:229-240
-            const V nx = dot2(x, y, c[0], c[2]), ny = dot2(x, y, c[1], c[3]);
+            V nx = dot2(x, y, c[0], c[2]), ny = dot2(x, y, c[1], c[3]);
+            late_bind(nx, ny);
             x = nx; y = ny; goto next; }
         L_ELONGATE2: {  // d2.py:249-257
             const V qx = m_fabs(x) - c[0], qy = m_fabs(y) - c[1];
             DSET(sa, np_min(np_max(qx, qy), T(0)));
             x = np_max(qx, T(0)); y = np_max(qy, T(0)); goto next; }
         L_REVOLVE: {  // d2.py:280-286
-            const V nx = len2(x, y) - c[0];
-            y = z; x = nx; z = V(T(0)); goto next; }
+            V nx = len2(x, y) - c[0], ny = z;
+            late_bind(nx, ny);
+            y = ny; x = nx; z = V(T(0)); goto next; }
         L_SETZ0: z = V(T(0)); goto next;                        // d3.py:513
         L_SAVE_P: PSET(sa, x, y, z); goto next;
         L_LOAD_P: PGET(sa, x, y, z); goto next;
@@ -558,11 +567,13 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             acc = vsel(A <= T(0), B, A); goto next; }
         L_TWIST: if constexpr (FULL) {  // d3.py:407-419
             const V cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
-            const V nx = cc * x - s * y, ny = s * x + cc * y;
+            V nx = cc * x - s * y, ny = s * x + cc * y;
+            late_bind(nx, ny);
             x = nx; y = ny; } goto next;
         L_BEND: if constexpr (FULL) {   // d3.py:421-433
             const V cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
-            const V nx = cc * x - s * y, ny = s * x + cc * y;
+            V nx = cc * x - s * y, ny = s * x + cc * y;
+            late_bind(nx, ny);
             x = nx; y = ny; } goto next;
         L_BEND_RADIAL: if constexpr (FULL) {  // d3.py:447-457
             const V r = m_hypot(x, y);
@@ -573,8 +584,9 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const V d = m_hypot(x, y) - c[9];
             const V a = m_atan2(y, x);
             const V tt = ease_apply<T, FULL, NS>((int)c[10], (a + pi) / (T(2) * pi));
-            x = c[0] + c[3] * tt + c[6] * d;
-            y = c[1] + c[4] * tt + c[7] * d; } goto next;
+            V nx = c[0] + c[3] * tt + c[6] * d, ny = c[1] + c[4] * tt + c[7] * d;
+            late_bind(nx, ny);
+            x = nx; y = ny; } goto next;
         L_CIRC_PREP: if constexpr (FULL) {  // d3.py:379-392: PS[sa] = (d, a, z)
             PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); } goto next;
         L_CIRC_SET: if constexpr (FULL) {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
@@ -589,6 +601,7 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
         }
         fold:
         acc = post_combine(post, acc, v, c[-1]);
+        late_bind(acc);
         next:;
     } while (!done);
     return acc;

@@ -84,6 +84,34 @@ template <typename T, int N> SDF_DEV Vec<T, N> vsel_s(const Mask<N> &c, T a, T b
     Vec<T, N> r; SDF_UNROLL for (int i = 0; i < N; i++) r.v[i] = c.m[i] ? a : b; return r;
 }
 
+// "Late binding" of new machine state.  When an op computes the new point from the old one
+// (rotate: every output needs every input), the new values are born while the old ones are still
+// live, so the register coalescer cannot give the loop-carried state ONE home register and pays
+// copies in EVERY op of the interpreter instead.  The empty asm re-defines the values after the
+// last use of the old state (it depends on all of them at once), which confines the copies to
+// the op that needs them.
+template <typename T, int N> SDF_DEV void late_bind(Vec<T, N> &a) {
+    SDF_UNROLL for (int i = 0; i < N; i++) asm volatile("" : "+v"(a.v[i]));
+}
+template <typename T> SDF_DEV void late_bind(Vec<T, 1> &a, Vec<T, 1> &b) { asm volatile("" : "+v"(a.v[0]), "+v"(b.v[0])); }
+template <typename T> SDF_DEV void late_bind(Vec<T, 2> &a, Vec<T, 2> &b) {
+    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(b.v[0]), "+v"(b.v[1]));
+}
+template <typename T> SDF_DEV void late_bind(Vec<T, 1> &a, Vec<T, 1> &b, Vec<T, 1> &c) {
+    asm volatile("" : "+v"(a.v[0]), "+v"(b.v[0]), "+v"(c.v[0]));
+}
+template <typename T> SDF_DEV void late_bind(Vec<T, 2> &a, Vec<T, 2> &b, Vec<T, 2> &c) {
+    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(c.v[0]), "+v"(c.v[1]));
+}
+
+// A copy the register coalescer cannot see through (an explicit v_mov): used where a value moves
+// from one piece of machine state to another and the two must keep their own home registers.
+SDF_DEV double real_move(double x) { double r; asm volatile("v_mov_b64 %0, %1" : "=v"(r) : "v"(x)); return r; }
+SDF_DEV float real_move(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+template <typename T, int N> SDF_DEV Vec<T, N> real_move(const Vec<T, N> &a) {
+    Vec<T, N> r; SDF_UNROLL for (int i = 0; i < N; i++) r.v[i] = real_move(a.v[i]); return r;
+}
+
 // element-wise application of a scalar function
 #define SDF_VEC_MAP1(NAME, EXPR)                                                 \
     template <typename T, int N> SDF_DEV Vec<T, N> NAME(const Vec<T, N> &a) {    \

@@ -64,6 +64,9 @@ ABI = {
     'sdf_generate': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int,
                                     ctypes.POINTER(_vp)]),
+    'sdf_generate_to_device': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _vp, _c_i64,
+                                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_vp)]),
     'sdf_mesh_stats': (ctypes.c_int, [_vp, ctypes.POINTER(SdfStats)]),
     'sdf_mesh_triangles': (_c_i64, [_vp]),
     'sdf_mesh_emit_device': (ctypes.c_int, [_vp, _vp]),
@@ -257,15 +260,26 @@ class Engine:
                 return out[:nt.value].reshape(-1, 3)
             cap = nt.value
 
-    def generate(self, sdf, X, Y, Z, batch_size=32, sparse=True, shard=(0, 1)):
+    def generate(self, sdf, X, Y, Z, batch_size=32, sparse=True, shard=(0, 1), out_ptr=None, out_cap=0):
+        """mesh the grid X x Y x Z.  With out_ptr / out_cap (device memory for 9 * out_cap float64)
+        the ordered soup is gathered into it inside the same submission (`mesh.emitted` tells
+        whether it fitted); otherwise it stays in the mesh until `points()` / `emit_device()`."""
         dt = self.tape_for(sdf)
         X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
         h = _vp()
-        _check(self.lib, self.lib.sdf_generate(dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y),
-                                               _dp(Z, _f64p), len(Z), int(batch_size), 1 if sparse else 0,
-                                               int(shard[0]), int(shard[1]), self.precision, ctypes.byref(h)))
+        emitted = ctypes.c_int(0)
+        if out_ptr:
+            _check(self.lib, self.lib.sdf_generate_to_device(
+                dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y), _dp(Z, _f64p), len(Z), int(batch_size),
+                1 if sparse else 0, int(shard[0]), int(shard[1]), self.precision, _vp(out_ptr), int(out_cap),
+                ctypes.byref(emitted), ctypes.byref(h)))
+        else:
+            _check(self.lib, self.lib.sdf_generate(dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y),
+                                                   _dp(Z, _f64p), len(Z), int(batch_size), 1 if sparse else 0,
+                                                   int(shard[0]), int(shard[1]), self.precision, ctypes.byref(h)))
         m = Mesh(self, h)
         m._tape = dt          # keep the device tape alive as long as the mesh
+        m.emitted = bool(emitted.value)
         return m
 
 

@@ -38,6 +38,11 @@ def oracle_lib():
 @pytest.fixture(scope='session')
 def eng():
     """the HIP engine; GPU tests fail (not skip) if the extension is missing or no device"""
+    try:                      # torch bundles its own HIP runtime: when a test uses both, torch's
+        import torch          # must be the one that initialises first (see INTEGRATION.md)
+        torch.cuda.is_available()
+    except Exception:
+        pass
     from sdf_amd import engine
     return engine.get_engine(0)
 

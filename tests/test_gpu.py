@@ -305,3 +305,31 @@ def test_full_size_configs_match_reference_counts(name, samples, counts, tris, n
     cx = pts[:, 0].reshape(-1, 3).mean(axis=1)
     bi = np.minimum(((cx - X[0]) / ((X[1] - X[0]) * 32)).astype(np.int64), (len(X) - 1) // 32)
     assert (np.diff(bi) >= 0).all()
+
+
+def test_generate_to_device_matches_host_path(ns, eng):
+    """sdf_generate_to_device: the in-chain gather into caller device memory gives the same soup as
+    the two-step path; a buffer that is too small is reported, not overrun"""
+    import torch
+    f = fixtures.build('ex_example', ns)
+    d = np.load(os.path.join(GOLDEN, 'gen_example_s17.npz'))
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
+    ref = eng.generate(f, X, Y, Z)
+    want = ref.points()
+    ref.close()
+    t = len(want) // 3
+    buf = torch.full((9 * (t + 5),), -7.0, dtype=torch.float64, device='cuda:0')
+    m = eng.generate(f, X, Y, Z, out_ptr=buf.data_ptr(), out_cap=t + 5)
+    assert m.emitted and m.n_triangles == t
+    eng.synchronize()
+    got = buf.cpu().numpy()
+    assert np.array_equal(got[:9 * t].reshape(-1, 3), want)
+    assert (got[9 * t:] == -7.0).all()
+    m.close()
+    small = torch.full((9 * (t - 1),), -7.0, dtype=torch.float64, device='cuda:0')
+    m = eng.generate(f, X, Y, Z, out_ptr=small.data_ptr(), out_cap=t - 1)
+    assert not m.emitted and m.n_triangles == t
+    eng.synchronize()
+    assert (small.cpu().numpy() == -7.0).all()
+    assert np.array_equal(m.points(), want)
+    m.close()
