@@ -407,9 +407,11 @@ static int validate_tape(const uint32_t *code, uint32_t n_words, uint32_t n_cons
     if (n_p > SDF_NP_SLOTS || n_d > SDF_ND_SLOTS) return fail("tape: model needs more register slots than this build provides");
     if ((code[n_words - 2] & 255u) != OP_END) return fail("tape: missing END");
     for (uint32_t i = 0; i < n_words; i += 2) {
-        const uint32_t w0 = code[i], op = w0 & 255u, post = (w0 >> 8) & 255u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
+        const uint32_t w0 = code[i], op = w0 & 255u, post = (w0 >> 8) & 7u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
         if (op >= OP_COUNT) return fail("tape: unknown opcode");
         if (post > POST_BLEND) return fail("tape: unknown post-combine");
+        if (w0 & 0x0800u) return fail("tape: reserved bit set");
+        if ((w0 & 0x8000u) && ((w0 >> 12) & 7u) >= n_p) return fail("tape: reload slot out of range");
         if (sa >= SDF_NP_SLOTS || sb >= SDF_NP_SLOTS) return fail("tape: slot out of range");
         if (code[i + 1] >= n_consts) return fail("tape: constant offset out of range");
         if (op == OP_END && i != n_words - 2) return fail("tape: END before the last instruction");

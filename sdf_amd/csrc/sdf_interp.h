@@ -307,10 +307,13 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
     do {
         const uint32_t w0 = __builtin_amdgcn_readfirstlane((uint32_t)nw);
         const uint32_t coff = __builtin_amdgcn_readfirstlane((uint32_t)(nw >> 32));
-        const uint32_t op = w0 & 255u, post = (w0 >> 8) & 255u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
+        const uint32_t op = w0 & 255u, post = (w0 >> 8) & 7u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
         const T *c = consts + coff + 1;          // c[-1] is K
         nw = code64[pc];
         pc += 1;
+        // reload prefix (tape.py peephole): restore the point from a PS slot first -- what a LOAD_P
+        // instruction in front of this one would do, without its dispatch
+        if (w0 & 0x8000u) { const uint32_t rs = (w0 >> 12) & 7u; PGET(rs, x, y, z); }
         // Dispatch: ONE indirect jump through a table of s_branch instructions (the compiler only
         // offers a compare-and-branch tree for `switch`, and every taken branch costs an instruction
         // buffer refill).  s_getpc returns the address A of the instruction after it; the table

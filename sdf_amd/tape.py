@@ -56,6 +56,12 @@ OP_NAMES = _MACHINE
 POST = {'SET': 0, 'UNION': 1, 'DIFF': 2, 'INTER': 3, 'SUNION': 4, 'SDIFF': 5, 'SINTER': 6, 'BLEND': 7}
 POST_NAMES = list(POST)
 
+# word 0 of an instruction:  op[0:8] | post[8:11] | reload slot[12:15] | reload flag[15] | a[16:24] | b[24:32]
+# "reload": restore the current point from PS[slot] BEFORE executing the instruction.  It is what a
+# LOAD_P in front of the instruction would do, without paying a dispatch for it (see peephole()).
+RELOAD_FLAG = 1 << 15
+RELOAD_SHIFT = 12
+
 # hard limits of the default kernel build (csrc/sdf_interp.h NP_SLOTS / ND_SLOTS)
 MAX_P_SLOTS = 8
 MAX_D_SLOTS = 8
@@ -101,8 +107,9 @@ class Tape:
         out = []
         for i in range(self.n_instr):
             w0, w1 = int(self.code[2 * i]), int(self.code[2 * i + 1])
-            out.append('%3d  %-14s post=%-6s a=%d b=%d c@%d' % (
-                i, OP_NAMES[w0 & 255], POST_NAMES[(w0 >> 8) & 255], (w0 >> 16) & 255, w0 >> 24, w1))
+            pre = 'p<-PS[%d]; ' % ((w0 >> RELOAD_SHIFT) & 7) if w0 & RELOAD_FLAG else ''
+            out.append('%3d  %s%-14s post=%-6s a=%d b=%d c@%d' % (
+                i, pre, OP_NAMES[w0 & 255], POST_NAMES[(w0 >> 8) & 7], (w0 >> 16) & 255, w0 >> 24, w1))
         return '\n'.join(out)
 
     def flop_estimate(self):
@@ -113,10 +120,10 @@ class Tape:
             a, b = _FLOPS.get(name, (4, 0))
             plain += a
             special += b
-            if (int(self.code[2 * i]) >> 8) & 255 >= 4:
+            if (int(self.code[2 * i]) >> 8) & 7 >= 4:
                 plain += 12
                 special += 1
-            elif (int(self.code[2 * i]) >> 8) & 255:
+            elif (int(self.code[2 * i]) >> 8) & 7:
                 plain += 1
         return plain, special
 
@@ -329,6 +336,61 @@ class _Lowering:
         return dirty
 
 
+def peephole(code):
+    """dispatch-count reduction on a lowered tape (list of u32 words, 2 per instruction); the
+    arithmetic per sample is unchanged, so results stay bit-identical:
+
+    * `SAVE_P a; SAVE_P b` back to back store the same point twice: the second store is dropped and
+      later `LOAD_P b` read slot a instead (slot lifetimes nest, a outlives b);
+    * `LOAD_P s` is folded into the NEXT instruction as its reload prefix.
+    """
+    ins = [[int(code[i]), int(code[i + 1])] for i in range(0, len(code), 2)]
+    op = lambda w: w & 255
+    sa = lambda w: (w >> 16) & 255
+    # 1. duplicate saves.  Slots written by SAVE_P are read by LOAD_P (a) and REP_SET (a).
+    writers = (OP['SAVE_P'], OP['REP_PREP'], OP['CIRC_PREP'])
+    readers = (OP['LOAD_P'], OP['REP_SET'])
+
+    def dedupe(ins):
+        out, alias = [], {}
+        for k, (w0, w1) in enumerate(ins):
+            o, s = op(w0), sa(w0)
+            if o in writers:
+                for bslot in [x for x, tgt in alias.items() if tgt == s]:
+                    # slot s is rewritten: an alias to it may only be dropped if it is dead, i.e.
+                    # not read again before it is written again
+                    for v0, _ in ins[k + 1:]:
+                        if sa(v0) == bslot and op(v0) in readers:
+                            return None
+                        if sa(v0) == bslot and op(v0) in writers:
+                            break
+                    del alias[bslot]
+                alias.pop(s, None)
+                if o == OP['SAVE_P'] and out and op(out[-1][0]) == OP['SAVE_P']:
+                    alias[s] = sa(out[-1][0])      # (out[-1] is never itself an alias: aliases are dropped)
+                    continue
+            elif o in readers and s in alias:
+                w0 = (w0 & ~(255 << 16)) | (alias[s] << 16)
+            out.append([w0, w1])
+        return out
+
+    ins = dedupe(ins) or ins
+    # 2. LOAD_P -> reload prefix of the following instruction
+    out, pending = [], None
+    for w0, w1 in ins:
+        if op(w0) == OP['LOAD_P'] and not (w0 & RELOAD_FLAG) and sa(w0) < 8:
+            pending = sa(w0)          # a LOAD_P directly behind another one makes the first dead
+            continue
+        if pending is not None:
+            if op(w0) == OP['END']:
+                pending = None        # restoring the point just before the end has no effect
+            else:
+                w0 |= RELOAD_FLAG | (pending << RELOAD_SHIFT)
+                pending = None
+        out.append([w0, w1])
+    return [w for pair in out for w in pair]
+
+
 def lower(obj, dim=None):
     """lower an SDF2/SDF3/Node to a :class:`Tape`"""
     root = unwrap(obj)
@@ -339,5 +401,5 @@ def lower(obj, dim=None):
     lw.value(root, dim)
     lw.emit('END')
     assert lw.pdepth == 0 and lw.ddepth == 0
-    return Tape(np.array(lw.code, dtype=np.uint32), np.array(lw.consts, dtype=np.float64),
+    return Tape(np.array(peephole(lw.code), dtype=np.uint32), np.array(lw.consts, dtype=np.float64),
                 lw.pmax, lw.dmax, dim)
