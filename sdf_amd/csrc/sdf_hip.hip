@@ -388,7 +388,7 @@ static bool tape_needs_full(const uint32_t *code, uint32_t n_words, const double
     };
     for (uint32_t i = 0; i + 1 < n_words; i += 2) {
         const uint32_t op = code[i] & 255u;
-        const double *c = consts + code[i + 1] + 1;
+        const double *c = consts + (code[i + 1] & 0xFFFFFFu) + 1;
         switch (op) {
         case OP_TWIST: case OP_BEND: case OP_BEND_RADIAL: case OP_WRAP_AROUND: case OP_CIRC_PREP: case OP_CIRC_SET:
         case OP_TRANS_RAD_PRE:
@@ -407,13 +407,15 @@ static int validate_tape(const uint32_t *code, uint32_t n_words, uint32_t n_cons
     if (n_p > SDF_NP_SLOTS || n_d > SDF_ND_SLOTS) return fail("tape: model needs more register slots than this build provides");
     if ((code[n_words - 2] & 255u) != OP_END) return fail("tape: missing END");
     for (uint32_t i = 0; i < n_words; i += 2) {
-        const uint32_t w0 = code[i], op = w0 & 255u, post = (w0 >> 8) & 7u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
+        const uint32_t w0 = code[i], w1 = code[i + 1], op = w0 & 255u, post = (w0 >> 8) & 7u, sa = w0 >> 24, sb = w1 >> 24;
         if (op >= OP_COUNT) return fail("tape: unknown opcode");
         if (post > POST_BLEND) return fail("tape: unknown post-combine");
-        if (w0 & 0x0800u) return fail("tape: reserved bit set");
-        if ((w0 & 0x8000u) && ((w0 >> 12) & 7u) >= n_p) return fail("tape: reload slot out of range");
+        if (w0 & 0x800000u) return fail("tape: reserved bit set");
+        if ((w0 & 0x000800u) && ((w0 >> 12) & 7u) >= std::max(n_p, 1u)) return fail("tape: reload slot out of range");
+        if ((w0 & 0x008000u) && ((w0 >> 16) & 7u) >= std::max(n_p, 1u)) return fail("tape: save slot out of range");
+        if ((w0 & 0x080000u) && ((w0 >> 20) & 7u) >= std::max(n_d, 1u)) return fail("tape: push slot out of range");
         if (sa >= SDF_NP_SLOTS || sb >= SDF_NP_SLOTS) return fail("tape: slot out of range");
-        if (code[i + 1] >= n_consts) return fail("tape: constant offset out of range");
+        if ((w1 & 0xFFFFFFu) >= n_consts) return fail("tape: constant offset out of range");
         if (op == OP_END && i != n_words - 2) return fail("tape: END before the last instruction");
     }
     return 0;

@@ -287,10 +287,19 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
 #define SDF_PSET_(R) PSx.R = _px; PSy.R = _py; PSz.R = _pz
 // copies BETWEEN state variables go through late_bind (sdf_vec.h): a plain copy would let the
 // register coalescer merge e.g. a PS slot with the current point, which then costs every op a move
-#define DGET(OUT, s) do { V _dst; SDF_RF_PICK(ND, s, SDF_DGET_); late_bind(_dst); OUT = _dst; } while (0)
+#define SDF_PRELOAD_(R) move_into(x, PSx.R); move_into(y, PSy.R); move_into(z, PSz.R)
+#define SDF_PSAVE_(R) move_into(PSx.R, x); move_into(PSy.R, y); move_into(PSz.R, z)
+#define SDF_DPUSH_(R) move_into(DS.R, acc)
+#define SDF_DGETM_(R) _dst = real_move(DS.R)
+#define SDF_PGETM_(R) _px = real_move(PSx.R); _py = real_move(PSy.R); _pz = real_move(PSz.R)
+// reads of a slot into live state are explicit moves (real_move); writes of COMPUTED values are
+// late-bound (no instruction), writes of live state (SAVE_P, PUSH_D) are explicit moves
+#define DGET(OUT, s) do { V _dst; SDF_RF_PICK(ND, s, SDF_DGETM_); OUT = _dst; } while (0)
 #define DSET(s, ...) do { V _val = (__VA_ARGS__); late_bind(_val); SDF_RF_PICK(ND, s, SDF_DSET_); } while (0)
-#define PGET(s, X, Y, Z) do { V _px, _py, _pz; SDF_RF_PICK(NP, s, SDF_PGET_); late_bind(_px, _py, _pz); X = _px; Y = _py; Z = _pz; } while (0)
+#define DSETM(s, A) do { const V _val = real_move(A); SDF_RF_PICK(ND, s, SDF_DSET_); } while (0)
+#define PGET(s, X, Y, Z) do { V _px, _py, _pz; SDF_RF_PICK(NP, s, SDF_PGETM_); X = _px; Y = _py; Z = _pz; } while (0)
 #define PSET(s, X, Y, Z) do { V _px = (X), _py = (Y), _pz = (Z); late_bind(_px, _py, _pz); SDF_RF_PICK(NP, s, SDF_PSET_); } while (0)
+#define PSETM(s, X, Y, Z) do { const V _px = real_move(X), _py = real_move(Y), _pz = real_move(Z); SDF_RF_PICK(NP, s, SDF_PSET_); } while (0)
 
     // The next instruction's words are requested before the current one executes, so their
     // scalar-cache latency overlaps this instruction's arithmetic (the host pads the code with a
@@ -305,15 +314,21 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
     uint32_t pc = 1;
     bool done = false;
     do {
+        // word 0: op[0:8] post[8:11] RL[11] slot[12:15] SV[15] slot[16:19] PD[19] slot[20:23] a[24:32]
+        // word 1: constant offset[0:24] b[24:32]                                  (sdf_amd/tape.py)
         const uint32_t w0 = __builtin_amdgcn_readfirstlane((uint32_t)nw);
-        const uint32_t coff = __builtin_amdgcn_readfirstlane((uint32_t)(nw >> 32));
-        const uint32_t op = w0 & 255u, post = (w0 >> 8) & 7u, sa = (w0 >> 16) & 255u, sb = w0 >> 24;
-        const T *c = consts + coff + 1;          // c[-1] is K
+        const uint32_t w1 = __builtin_amdgcn_readfirstlane((uint32_t)(nw >> 32));
+        const uint32_t op = w0 & 255u, post = (w0 >> 8) & 7u, sa = w0 >> 24, sb = w1 >> 24;
+        const T *c = consts + (w1 & 0xFFFFFFu) + 1;          // c[-1] is K
         nw = code64[pc];
         pc += 1;
-        // reload prefix (tape.py peephole): restore the point from a PS slot first -- what a LOAD_P
-        // instruction in front of this one would do, without its dispatch
-        if (w0 & 0x8000u) { const uint32_t rs = (w0 >> 12) & 7u; PGET(rs, x, y, z); }
+        // prefixes (tape.py peephole): the bookkeeping a LOAD_P / SAVE_P / PUSH_D instruction in
+        // front of this one would do, without paying a dispatch for it
+        if (w0 & 0x0FF800u) {   // (in-place moves: the path without prefixes pays nothing at the merge)
+            if (w0 & 0x000800u) { const uint32_t s = (w0 >> 12) & 7u; SDF_RF_PICK(NP, s, SDF_PRELOAD_); }
+            if (w0 & 0x008000u) { const uint32_t s = (w0 >> 16) & 7u; SDF_RF_PICK(NP, s, SDF_PSAVE_); }
+            if (w0 & 0x080000u) { const uint32_t s = (w0 >> 20) & 7u; SDF_RF_PICK(ND, s, SDF_DPUSH_); }
+        }
         // Dispatch: ONE indirect jump through a table of s_branch instructions (the compiler only
         // offers a compare-and-branch tree for `switch`, and every taken branch costs an instruction
         // buffer refill).  s_getpc returns the address A of the instruction after it; the table
@@ -540,10 +555,10 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             late_bind(nx, ny);
             y = ny; x = nx; z = V(T(0)); goto next; }
         L_SETZ0: z = V(T(0)); goto next;                        // d3.py:513
-        L_SAVE_P: PSET(sa, x, y, z); goto next;
+        L_SAVE_P: PSETM(sa, x, y, z); goto next;
         L_LOAD_P: PGET(sa, x, y, z); goto next;
         // ---------------- distance ops ----------------
-        L_PUSH_D: DSET(sa, acc); goto next;
+        L_PUSH_D: DSETM(sa, acc); goto next;
         L_NEG: acc = -acc; goto next;                            // dn.py:60-63
         L_ADDC: acc = acc + c[0]; goto next;                     // dn.py:70-73
         L_SUBC: acc = acc - c[0]; goto next;                     // dn.py:65-68
@@ -605,15 +620,21 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
         fold:
         acc = post_combine(post, acc, v, c[-1]);
         late_bind(acc);
-        next:;
+        next:
+        // the prefetched words are first touched HERE (the empty asm consumes them), i.e. the wait
+        // for the scalar load issued at the top of this pass sits behind the op it overlapped with;
+        // without it the compiler moves the loop-carried copy right behind the load
+        asm volatile("" : "+s"(nw));
     } while (!done);
     return acc;
 }
 
 #undef DGET
 #undef DSET
+#undef DSETM
 #undef PGET
 #undef PSET
+#undef PSETM
 
 // one sample per lane, the largest register files: the variant the non-hot kernels use
 template <typename T, bool FULL>

@@ -112,6 +112,14 @@ template <typename T, int N> SDF_DEV Vec<T, N> real_move(const Vec<T, N> &a) {
     Vec<T, N> r; SDF_UNROLL for (int i = 0; i < N; i++) r.v[i] = real_move(a.v[i]); return r;
 }
 
+// dst = src as an explicit move INTO dst's register ("+v": the result is tied to dst's old home),
+// so a conditional state update merges with the not-taken path without any copy there
+SDF_DEV void move_into(double &dst, double src) { asm volatile("v_mov_b64 %0, %1" : "+v"(dst) : "v"(src)); }
+SDF_DEV void move_into(float &dst, float src) { asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src)); }
+template <typename T, int N> SDF_DEV void move_into(Vec<T, N> &dst, const Vec<T, N> &src) {
+    SDF_UNROLL for (int i = 0; i < N; i++) move_into(dst.v[i], src.v[i]);
+}
+
 // element-wise application of a scalar function
 #define SDF_VEC_MAP1(NAME, EXPR)                                                 \
     template <typename T, int N> SDF_DEV Vec<T, N> NAME(const Vec<T, N> &a) {    \

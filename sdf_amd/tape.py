@@ -56,11 +56,21 @@ OP_NAMES = _MACHINE
 POST = {'SET': 0, 'UNION': 1, 'DIFF': 2, 'INTER': 3, 'SUNION': 4, 'SDIFF': 5, 'SINTER': 6, 'BLEND': 7}
 POST_NAMES = list(POST)
 
-# word 0 of an instruction:  op[0:8] | post[8:11] | reload slot[12:15] | reload flag[15] | a[16:24] | b[24:32]
-# "reload": restore the current point from PS[slot] BEFORE executing the instruction.  It is what a
-# LOAD_P in front of the instruction would do, without paying a dispatch for it (see peephole()).
-RELOAD_FLAG = 1 << 15
-RELOAD_SHIFT = 12
+# An instruction is two u32 words:
+#   word 0:  op[0:8] | post[8:11] | RL[11] rl_slot[12:15] | SV[15] sv_slot[16:19] | PD[19] pd_slot[20:23] | a[24:32]
+#   word 1:  const offset[0:24] | b[24:32]
+# RL / SV / PD are PREFIXES executed before the op, in this order (see peephole()):
+#   RL: p = PS[rl_slot]      (what a LOAD_P in front of the instruction would do)
+#   SV: PS[sv_slot] = p      (SAVE_P)
+#   PD: DS[pd_slot] = acc    (PUSH_D)
+# so the bookkeeping ops ride on their neighbours instead of paying a dispatch each.
+A_SHIFT = 24
+B_SHIFT = 24
+COFF_MASK = (1 << 24) - 1
+RL_FLAG, RL_SHIFT = 1 << 11, 12
+SV_FLAG, SV_SHIFT = 1 << 15, 16
+PD_FLAG, PD_SHIFT = 1 << 19, 20
+PREFIX_MASK = 0x00FFF800
 
 # hard limits of the default kernel build (csrc/sdf_interp.h NP_SLOTS / ND_SLOTS)
 MAX_P_SLOTS = 8
@@ -107,9 +117,15 @@ class Tape:
         out = []
         for i in range(self.n_instr):
             w0, w1 = int(self.code[2 * i]), int(self.code[2 * i + 1])
-            pre = 'p<-PS[%d]; ' % ((w0 >> RELOAD_SHIFT) & 7) if w0 & RELOAD_FLAG else ''
+            pre = ''
+            if w0 & RL_FLAG:
+                pre += 'p<-PS[%d]; ' % ((w0 >> RL_SHIFT) & 7)
+            if w0 & SV_FLAG:
+                pre += 'PS[%d]<-p; ' % ((w0 >> SV_SHIFT) & 7)
+            if w0 & PD_FLAG:
+                pre += 'DS[%d]<-acc; ' % ((w0 >> PD_SHIFT) & 7)
             out.append('%3d  %s%-14s post=%-6s a=%d b=%d c@%d' % (
-                i, pre, OP_NAMES[w0 & 255], POST_NAMES[(w0 >> 8) & 7], (w0 >> 16) & 255, w0 >> 24, w1))
+                i, pre, OP_NAMES[w0 & 255], POST_NAMES[(w0 >> 8) & 7], w0 >> A_SHIFT, w1 >> B_SHIFT, w1 & COFF_MASK))
         return '\n'.join(out)
 
     def flop_estimate(self):
@@ -140,9 +156,9 @@ class _Lowering:
         off = len(self.consts)
         self.consts.append(float(K))
         self.consts.extend(float(c) for c in consts)
-        assert 0 <= a < 256 and 0 <= b < 256
-        self.code.append(OP[op] | (POST[post] << 8) | (a << 16) | (b << 24))
-        self.code.append(off)
+        assert 0 <= a < 256 and 0 <= b < 256 and off <= COFF_MASK
+        self.code.append(OP[op] | (POST[post] << 8) | (a << A_SHIFT))
+        self.code.append(off | (b << B_SHIFT))
 
     def palloc(self):
         s = self.pdepth
@@ -341,12 +357,13 @@ def peephole(code):
     arithmetic per sample is unchanged, so results stay bit-identical:
 
     * `SAVE_P a; SAVE_P b` back to back store the same point twice: the second store is dropped and
-      later `LOAD_P b` read slot a instead (slot lifetimes nest, a outlives b);
-    * `LOAD_P s` is folded into the NEXT instruction as its reload prefix.
+      later readers of slot b read slot a instead (slot lifetimes nest, a outlives b);
+    * LOAD_P / SAVE_P / PUSH_D are folded into the NEXT instruction as its RL / SV / PD prefixes
+      whenever the fixed prefix order (RL, SV, PD, then the op) reproduces the original order.
     """
     ins = [[int(code[i]), int(code[i + 1])] for i in range(0, len(code), 2)]
     op = lambda w: w & 255
-    sa = lambda w: (w >> 16) & 255
+    sa = lambda w: w >> A_SHIFT
     # 1. duplicate saves.  Slots written by SAVE_P are read by LOAD_P (a) and REP_SET (a).
     writers = (OP['SAVE_P'], OP['REP_PREP'], OP['CIRC_PREP'])
     readers = (OP['LOAD_P'], OP['REP_SET'])
@@ -370,23 +387,57 @@ def peephole(code):
                     alias[s] = sa(out[-1][0])      # (out[-1] is never itself an alias: aliases are dropped)
                     continue
             elif o in readers and s in alias:
-                w0 = (w0 & ~(255 << 16)) | (alias[s] << 16)
+                w0 = (w0 & ~(255 << A_SHIFT)) | (alias[s] << A_SHIFT)
             out.append([w0, w1])
         return out
 
     ins = dedupe(ins) or ins
-    # 2. LOAD_P -> reload prefix of the following instruction
-    out, pending = [], None
+    # 2. bookkeeping ops -> prefixes of the following instruction
+    out = []
+    rl = sv = pd = None            # pending prefixes (slot numbers)
+    pending_src = []               # the original instructions the pending prefixes came from
+
+    def flush_standalone():
+        nonlocal rl, sv, pd, pending_src
+        out.extend(pending_src)
+        rl = sv = pd = None
+        pending_src = []
+
     for w0, w1 in ins:
-        if op(w0) == OP['LOAD_P'] and not (w0 & RELOAD_FLAG) and sa(w0) < 8:
-            pending = sa(w0)          # a LOAD_P directly behind another one makes the first dead
-            continue
-        if pending is not None:
-            if op(w0) == OP['END']:
-                pending = None        # restoring the point just before the end has no effect
+        o, s = op(w0), sa(w0)
+        if s < 8 and not (w0 & PREFIX_MASK):
+            if o == OP['LOAD_P']:
+                if sv is not None:
+                    flush_standalone()          # SAVE then LOAD cannot be expressed as RL-then-SV
+                elif rl is not None:
+                    pending_src = [x for x in pending_src if op(x[0]) != OP['LOAD_P']]   # first reload is dead
+                rl = s
+                pending_src.append([w0, w1])
+                continue
+            if o == OP['SAVE_P']:
+                if sv is not None:
+                    flush_standalone()
+                sv = s
+                pending_src.append([w0, w1])
+                continue
+            if o == OP['PUSH_D']:
+                if pd is not None:
+                    flush_standalone()
+                pd = s
+                pending_src.append([w0, w1])
+                continue
+        if pending_src:
+            if o == OP['END']:
+                flush_standalone()              # keep them as instructions in front of END
             else:
-                w0 |= RELOAD_FLAG | (pending << RELOAD_SHIFT)
-                pending = None
+                if rl is not None:
+                    w0 |= RL_FLAG | (rl << RL_SHIFT)
+                if sv is not None:
+                    w0 |= SV_FLAG | (sv << SV_SHIFT)
+                if pd is not None:
+                    w0 |= PD_FLAG | (pd << PD_SHIFT)
+                rl = sv = pd = None
+                pending_src = []
         out.append([w0, w1])
     return [w for pair in out for w in pair]
 
