@@ -61,6 +61,7 @@ struct MeshArgs {
     float *arena;                  // 9 floats per triangle
     unsigned long long arena_cap;  // triangles
     MeshCounters *ctr;
+    int bits_off;                  // byte offset of the sign-bit volume in dynamic LDS
     int list_off;                  // byte offset of the triangle work list in dynamic LDS
     int list_cap;                  // its capacity in entries
     unsigned long long *prof;      // NULL, or 8 phase cycle counters (SDF_MESH_PROF=1 diagnostics)
@@ -106,6 +107,16 @@ __device__ __forceinline__ unsigned plane_bits(const float *v, int s0, int s1) {
 }
 // plane bit j -> configuration bit 2j (o2 = 0) ; shift left by one for o2 = 1
 __device__ __forceinline__ unsigned spread4(unsigned s) { return (s & 1u) | ((s & 2u) << 1) | ((s & 4u) << 2) | ((s & 8u) << 3); }
+
+// sign configuration of the cell at column i2 of a cell row from the four row bit strings
+// (q = 2 * o0 + o1): bit c = 4 * o0 + 2 * o1 + o2 of the configuration = bit (i2 + o2) of row q
+__device__ __forceinline__ unsigned cell_config(const unsigned long long *rb, int i2) {
+    unsigned cfg = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) cfg |= ((unsigned)(rb[q] >> i2) & 3u) << (2 * q);
+    // rows give bit pairs (o2 = 0 in bit 0, o2 = 1 in bit 1) at position 2q: already c = 2q + o2
+    return cfg;
+}
 
 // One marching-cubes vertex on edge e of the cell at (i0,i1,i2); v points at the cell's corner 0
 // in a volume with strides (s0, s1, 1).  skimage's placement: with w = 1/(eps+|v|),
@@ -154,6 +165,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     unsigned char *ntri_lds = smem + MESH_LDS_NTRI;                 // 256 B: ntri | ambiguous << 7
     double *axes = reinterpret_cast<double *>(smem + MESH_LDS_AXES);  // 3 * 33 doubles (X, Y, Z of the tile)
     float *vol = reinterpret_cast<float *>(smem + MESH_LDS_VOL);    // (bs+1)^3 floats
+    unsigned long long *bits = reinterpret_cast<unsigned long long *>(smem + a.bits_off);   // 1 bit per sample: value > 0
     unsigned *list = reinterpret_cast<unsigned *>(smem + a.list_off);
     const int tid = threadIdx.x;
     const GridDesc g = a.g;
@@ -194,9 +206,15 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             SDF_UNROLL
             for (int k = 0; k < NS; k++) {
                 const int i = i0 + k * BLOCK + tid;
-                if (i < nvox) vol[i] = (float)val.v[k];
+                const float f = (float)val.v[k];
+                if (i < nvox) vol[i] = f;
+                // the wave's 64 consecutive samples -> one word of the sign-bit volume (the marching
+                // phases classify cells from these bits instead of re-reading 8 floats per cell)
+                const unsigned long long m = __ballot(i < nvox && f > 0.0f);
+                if ((tid & 63) == 0 && i < nvox) bits[i >> 6] = m;
             }
         }
+        if (tid < 2) bits[((nvox + 63) >> 6) + tid] = 0ull;   // the row extraction reads one word ahead
         __syncthreads();
         SDF_PROF(1);
 
@@ -206,30 +224,42 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         const float inv_c1 = 1.0f / (float)max(c1, 1);
         int row_tris[RPT], row_off[RPT];
         unsigned row_mask[RPT];
+        unsigned long long row_bits[RPT][4];   // sign bits of the four sample rows (o0, o1) of a cell row
         int total = 0, my_amb = 0;
         SDF_UNROLL
         for (int k = 0; k < RPT; k++) {
             const int r = tid + k * BLOCK;
             int n = 0;
             unsigned mask = 0;
+            SDF_UNROLL for (int q = 0; q < 4; q++) row_bits[k][q] = 0ull;
             if (r < nrows) {
                 const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
-                const float *row = vol + i0 * lyz + i1 * lz;
-                unsigned prev = plane_bits(row, lyz, lz);
-                for (int i2 = 0; i2 < c2; i2++) {
-                    const unsigned next = plane_bits(row + i2 + 1, lyz, lz);
-                    const unsigned e = ntri_lds[spread4(prev) | (spread4(next) << 1)];
+                SDF_UNROLL
+                for (int q = 0; q < 4; q++) {   // q = 2 * o0 + o1
+                    const int o = (i0 + (q >> 1)) * lyz + (i1 + (q & 1)) * lz;
+                    const unsigned long long w0 = bits[o >> 6], w1 = bits[(o >> 6) + 1];
+                    const int sh = o & 63;
+                    row_bits[k][q] = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+                }
+                // a cell (columns i2, i2 + 1) has a surface unless its 8 bits are all equal
+                const unsigned long long any = row_bits[k][0] | row_bits[k][1] | row_bits[k][2] | row_bits[k][3];
+                const unsigned long long all = row_bits[k][0] & row_bits[k][1] & row_bits[k][2] & row_bits[k][3];
+                const unsigned long long ones = all & (all >> 1), zeros = ~any & ~(any >> 1);
+                mask = (unsigned)(~(ones | zeros)) & (c2 >= 32 ? 0xFFFFFFFFu : ((1u << c2) - 1u));
+                unsigned m = mask;
+                while (m) {
+                    const int i2 = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const unsigned e = ntri_lds[cell_config(row_bits[k], i2)];
                     if (e & 128u) {   // ambiguous configuration: Lewiner's tests pick the tiling (rare)
                         double lv[8];
                         int off;
-                        mc33_load_cell(row + i2, lyz, lz, lv);
+                        mc33_load_cell(vol + i0 * lyz + i1 * lz + i2, lyz, lz, lv);
                         n += mc33_cell(lv, a.mc->mc33, &off);
                         my_amb++;
                     } else {
                         n += (int)(e & 7u);
                     }
-                    if (e) mask |= 1u << i2;
-                    prev = next;
                 }
             }
             row_tris[k] = n; row_mask[k] = mask;
@@ -272,7 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 while (m) {
                     const int i2 = __ffs((int)m) - 1;
                     m &= m - 1u;
-                    const unsigned cfg = spread4(plane_bits(row + i2, lyz, lz)) | (spread4(plane_bits(row + i2 + 1, lyz, lz)) << 1);
+                    const unsigned cfg = cell_config(row_bits[k], i2);
                     const unsigned en = ntri_lds[cfg];
                     int n = (int)(en & 7u);
                     if (en & 128u) {

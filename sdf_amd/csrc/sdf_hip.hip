@@ -642,8 +642,11 @@ int sdf_marching_cubes_host(sdf_ctx *c, const float *h_vol, int n0, int n1, int 
 static int launch_mesh(sdf_tape *t, int precision, MeshArgs &a, int grid, int bs) {
     sdf_ctx *c = t->ctx;
     const size_t tile = (size_t)(bs + 1) * (bs + 1) * (bs + 1) * 4;
-    const size_t list_off = (MESH_LDS_VOL + tile + 15) & ~(size_t)15;
+    const size_t bits_off = (MESH_LDS_VOL + tile + 15) & ~(size_t)15;
+    const size_t nvox = (size_t)(bs + 1) * (bs + 1) * (bs + 1);
+    const size_t list_off = (bits_off + ((nvox + 63) / 64 + 2) * 8 + 15) & ~(size_t)15;
     if (list_off + 4096 > c->lds_max) return fail("sdf_generate: device LDS too small for this batch size");
+    a.bits_off = (int)bits_off;
     const size_t list_cap = std::min<size_t>((c->lds_max - list_off) / 4, 16384);
     a.list_off = (int)list_off; a.list_cap = (int)list_cap;
     const size_t lds = list_off + list_cap * 4;
