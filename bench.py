@@ -67,12 +67,20 @@ def main():
         raise SystemExit('--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
 
     import torch
+    # debugging aids for boxes with ONE GPU: SDF_BENCH_ONE_DEVICE=1 puts every rank on device 0,
+    # SDF_BENCH_BACKEND=gloo exchanges through host memory (RCCL refuses two ranks on one device)
+    backend = os.environ.get('SDF_BENCH_BACKEND', 'nccl')
+    if os.environ.get('SDF_BENCH_ONE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     td = None
     if world > 1:
         import torch.distributed as td
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
 
     from sdf_amd import core, engine, dist
     eng = engine.get_engine(local_rank)
@@ -86,6 +94,7 @@ def main():
     X, Y, Z, step = core.grid_axes(bounds, samples=2 ** args.samples_log2)
     grid_voxels = len(X) * len(Y) * len(Z)
     dev = torch.device('cuda', local_rank)
+    comm_dev = dev if backend == 'nccl' else torch.device('cpu')
 
     state = {}
 
@@ -105,7 +114,7 @@ def main():
             state['tris'] = t
             mesh.close()
         else:
-            soup, st = dist.generate_sharded_device(eng, tape, X, Y, Z, 32, True, device=dev)
+            soup, st = dist.generate_sharded_device(eng, tape, X, Y, Z, 32, True, device=comm_dev)
             state['buf'] = soup
             state['stats'] = st
             state['tris'] = st['triangles']
@@ -128,7 +137,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if td is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
 

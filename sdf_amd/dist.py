@@ -66,6 +66,13 @@ def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None,
         backend = td.get_backend(group)
         device = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
 
+    # torch allocations / fills and the collectives run on torch's current stream: the engine
+    # adopts it for this call so its kernels are ordered with them (its own stream otherwise races
+    # with e.g. the zero-fill of the padded exchange buffer)
+    adopted = False
+    if device.type == 'cuda' and hasattr(eng, 'set_stream'):
+        eng.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        adopted = True
     mesh = eng.generate(tape, X, Y, Z, batch_size, sparse, shard=(r, world))
     try:
         st = mesh.stats()
@@ -95,6 +102,8 @@ def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None,
             soup = torch.empty(0, dtype=torch.float64, device=device)
     finally:
         mesh.close()
+        if adopted:
+            eng.set_stream(0)
 
     merged = dict(st)
     merged['empty'] = merged['n_empty'] = int(allc[:, 1].sum())

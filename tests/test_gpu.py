@@ -333,3 +333,35 @@ def test_generate_to_device_matches_host_path(ns, eng):
     assert (small.cpu().numpy() == -7.0).all()
     assert np.array_equal(m.points(), want)
     m.close()
+
+
+def test_sharded_generate_over_rccl_single_rank(ns, eng):
+    """the multi-GPU code path (sdf_amd/dist.py: device-resident soup, RCCL all-gather) with a
+    one-rank `nccl` process group: must reproduce the plain path bit for bit"""
+    import socket
+    import torch
+    import torch.distributed as td
+    from sdf_amd import dist
+    f = fixtures.build('ex_example', ns)
+    d = np.load(os.path.join(GOLDEN, 'gen_example_s17.npz'))
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
+    ref = eng.generate(f, X, Y, Z)
+    want = ref.points()
+    ref.close()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    td.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        soup, st = dist.generate_sharded_device(eng, eng.tape_for(f), X, Y, Z, 32, True, device=torch.device('cuda', 0))
+        torch.cuda.synchronize()
+        got = soup.cpu().numpy().reshape(-1, 3)
+        assert st['triangles'] == len(want) // 3
+        assert np.array_equal(got, want)
+        pts = f.generate(bounds=tuple(map(tuple, d['bounds'])), step=d['step'].tolist(), verbose=False)
+        assert np.array_equal(pts, want)          # core.generate takes the sharded route when dist is up
+    finally:
+        td.destroy_process_group()
