@@ -53,6 +53,8 @@ SDF_OUTLINE double o_fmod(double x, double y) { return fmod(x, y); }
 SDF_OUTLINE float o_fmod(float x, float y) { return fmodf(x, y); }
 SDF_OUTLINE double o_pow2(double x) { return pow(2.0, x); }
 SDF_OUTLINE float o_pow2(float x) { return powf(2.0f, x); }
+SDF_OUTLINE void o_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+SDF_OUTLINE void o_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
 SDF_DEV double m_sin(double x) { return o_sin(x); }
 SDF_DEV float m_sin(float x) { return o_sin(x); }
 SDF_DEV double m_cos(double x) { return o_cos(x); }
@@ -92,6 +94,11 @@ SDF_VEC_MAP1(m_rint, m_rint(x))
 SDF_VEC_MAP1(m_sin, m_sin(x))
 SDF_VEC_MAP1(m_cos, m_cos(x))
 SDF_VEC_MAP1(m_pow2, m_pow2(x))
+// sin and cos of the same angle share the argument reduction (ocml sincos returns the same values
+// as its sin and cos)
+template <typename T, int N> SDF_DEV void m_sincos(const Vec<T, N> &a, Vec<T, N> &s, Vec<T, N> &c) {
+    SDF_UNROLL for (int i = 0; i < N; i++) o_sincos(a.v[i], &s.v[i], &c.v[i]);
+}
 SDF_VEC_MAP1(np_sign, s_sign(x))
 SDF_VEC_MAP2(m_atan2, m_atan2(x, y))
 SDF_VEC_MAP2(m_hypot, m_hypot(x, y))
@@ -584,12 +591,12 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             V A; DGET(A, sa); const V B = -acc;
             acc = vsel(A <= T(0), B, A); goto next; }
         L_TWIST: if constexpr (FULL) {  // d3.py:407-419
-            const V cc = m_cos(c[0] * z), s = m_sin(c[0] * z);
+            V cc, s; m_sincos(c[0] * z, s, cc);
             V nx = cc * x - s * y, ny = s * x + cc * y;
             late_bind(nx, ny);
             x = nx; y = ny; } goto next;
         L_BEND: if constexpr (FULL) {   // d3.py:421-433
-            const V cc = m_cos(c[0] * x), s = m_sin(c[0] * x);
+            V cc, s; m_sincos(c[0] * x, s, cc);
             V nx = cc * x - s * y, ny = s * x + cc * y;
             late_bind(nx, ny);
             x = nx; y = ny; } goto next;
@@ -610,7 +617,8 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
         L_CIRC_SET: if constexpr (FULL) {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
             V d, a0, z0; PGET(sa, d, a0, z0);
             const V ang = a0 - c[0];
-            x = m_cos(ang) * d; y = m_sin(ang) * d; z = z0; } goto next;
+            V sn, cs; m_sincos(ang, sn, cs);
+            x = cs * d; y = sn * d; z = z0; } goto next;
         L_TRANS_RAD_PRE: if constexpr (FULL) {  // d3.py:472-481
             const V r = m_hypot(x, y);
             DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); } goto next;
