@@ -365,3 +365,45 @@ def test_sharded_generate_over_rccl_single_rank(ns, eng):
         assert np.array_equal(pts, want)          # core.generate takes the sharded route when dist is up
     finally:
         td.destroy_process_group()
+
+
+EDGE_GRIDS = [
+    # (nx, ny, nz): ragged last batches (1-sample and 2-sample slices), single-batch and thin grids
+    (33, 33, 33), (34, 33, 65), (2, 2, 2), (1, 40, 40), (64, 1, 3), (97, 5, 34), (3, 3, 130),
+]
+
+
+@pytest.mark.parametrize('shape', EDGE_GRIDS, ids=['x'.join(map(str, s)) for s in EDGE_GRIDS])
+@pytest.mark.parametrize('sparse', [True, False])
+def test_ragged_and_degenerate_grids_match_oracle(shape, sparse, ns, oracle_lib, eng):
+    """the reference's batch slicing gives the last batch on an axis 1..33 samples (a 1-sample
+    slice makes skimage raise -> an 'empty' batch, reference sdf/core.py:53-56)"""
+    f = fixtures.build('ex_example', ns)
+    X = -0.9 + 1.8 * np.arange(shape[0]) / max(shape[0] - 1, 1)
+    Y = -0.9 + 1.8 * np.arange(shape[1]) / max(shape[1] - 1, 1)
+    Z = -0.9 + 1.8 * np.arange(shape[2]) / max(shape[2] - 1, 1)
+    mesh = eng.generate(f, X, Y, Z, 32, sparse)
+    pts, kinds, st = mesh.points(), mesh.kinds(), mesh.stats()
+    mesh.close()
+    o = oracle_lib.generate(f, X, Y, Z, 32, sparse)
+    assert np.array_equal(kinds, o.kinds)
+    assert pts.shape == o.points.shape and np.array_equal(pts, o.points)
+    assert st['n_eval_voxels'] == o.n_eval
+
+
+def test_no_surface_and_empty_inputs(ns, oracle_lib, eng):
+    f = fixtures.build('sphere', ns)
+    far = np.linspace(5.0, 6.0, 40)                       # entirely outside: every batch skipped
+    m = eng.generate(f, far, far, far, 32, True)
+    assert m.n_triangles == 0 and m.points().shape == (0, 3) and (m.kinds() == 0).all()
+    m.close()
+    m = eng.generate(f, far, far, far, 32, False)         # dense: sampled, no crossing -> 'empty'
+    assert m.n_triangles == 0 and (m.kinds() == 1).all()
+    m.close()
+    empty = np.zeros(0)
+    m = eng.generate(f, empty, far, far, 32, True)        # np.arange produced nothing on an axis
+    assert m.n_triangles == 0 and m.stats()['batches'] == 0
+    m.close()
+    assert eng.eval_points(f, np.zeros((0, 3))).shape == (0,)
+    assert eng.marching_cubes(np.ones((1, 5, 5))).shape == (0, 3)
+    assert eng.marching_cubes(np.ones((4, 4, 4))).shape == (0, 3)

@@ -27,6 +27,10 @@ MODELS = {
     'rotate_x4': ' | '.join('sphere(%g, (0.1, 0, 0)).rotate(%g, X)' % (1 - 0.05 * i, 0.3 * i + 0.1) for i in range(4)),
     'smooth_x4': 'union(' + ', '.join('sphere(%g, (%g, 0, 0))' % (1 - 0.05 * i, 0.3 * i) for i in range(4)) + ', k=0.2)',
     'example': '(sphere(1) & box(1.5)) - (cylinder(0.5).orient(X) | cylinder(0.5).orient(Y) | cylinder(0.5).orient(Z))',
+    'circ_array': 'cylinder(0.1).translate((0.8, 0, 0)).circular_array(12)',
+    'twist': 'box((0.6, 0.6, 1.8)).twist(1.5)',
+    'gearlike': """(sphere(2) & slab(z0=-0.5, z1=0.5).k(0.1)) - cylinder(1).k(0.1) - cylinder(0.25).circular_array(16, 2).k(0.1)""",
+    'blobby': """union(*[sphere(0.4, (0.6 * ((i * 7) % 5 - 2) / 2, 0.6 * ((i * 3) % 5 - 2) / 2, 0.6 * ((i * 5) % 5 - 2) / 2)) for i in range(7)], k=0.3)""",
 }
 
 CHILD = r'''
