@@ -96,11 +96,11 @@ int sdf_marching_cubes_host(sdf_ctx *ctx, const float *h_volume, int n0, int n1,
 int sdf_generate(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
                  int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,
                  sdf_mesh **out);
-/* The same, with the ordered gather (`points * scale + offset`, reference sdf/core.py:58-60, :141)
- * enqueued behind the meshing kernels into caller-owned DEVICE memory of 9*cap_tris doubles, so the
- * whole call costs one host synchronisation.  *emitted = 1 when the soup (sdf_mesh_triangles()
- * triangles) is in d_out; 0 when it did not fit -- the mesh is still valid, call
- * sdf_mesh_emit_device with a larger buffer. */
+/* The same, writing the ordered soup (`points * scale + offset`, reference sdf/core.py:58-60, :141)
+ * straight into caller-owned DEVICE memory of 9*cap_tris doubles.  *emitted = 1 when the soup
+ * (sdf_mesh_triangles() triangles) is in d_out; 0 when it did not fit: nothing is written past
+ * cap_tris, the contents of d_out are then unspecified, and the mesh holds the complete soup in
+ * library memory (the meshing pass was repeated) -- fetch it with sdf_mesh_emit_device/_host. */
 int sdf_generate_to_device(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
                            int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,
                            void *d_out, int64_t cap_tris, int *emitted, sdf_mesh **out);

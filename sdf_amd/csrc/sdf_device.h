@@ -11,8 +11,13 @@
 //                          wave-shuffle prefix scan turns the row counts into offsets
 //              3. compact  surface cells expand into a per-triangle work list in LDS
 //                          (cell, configuration, triangle-in-cell), in skimage's emission order
-//              4. emit     one lane per TRIANGLE: three edge interpolations from the LDS tile,
-//                          36 contiguous bytes per lane into the float32 arena (coalesced)
+//              4. emit     one lane per TRIANGLE: three edge interpolations from the LDS tile, the
+//                          float64 world transform `points * scale + offset` (core.py:58-60) and
+//                          72 contiguous bytes per lane straight into the ORDERED output soup.
+//                          The batch's place in the soup is the exclusive prefix of the triangle
+//                          counts of all earlier work items, obtained without a second pass by a
+//                          decoupled look-back over per-item status words (work items are handed
+//                          out in order, so every predecessor is already being worked on)
 //            (reference `_marching_cubes`, sdf/core.py:16-18, 54)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -31,13 +36,13 @@ struct McTables {   // uploaded once per context
 };
 
 struct MeshCounters {   // zeroed before every k_mesh run
-    unsigned long long tri_counter;   // next free triangle slot in the arena
+    unsigned long long tri_counter;   // (unused; kept for layout)
     unsigned long long n_eval;
     unsigned int work_counter;
     unsigned int overflow;
     unsigned int n_empty, n_nonempty;
     unsigned long long n_ambiguous;
-    unsigned long long total;         // written by k_scan
+    unsigned long long total;         // triangles of this shard (written by the workgroup of the last work item)
     // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
     // and this shard's slice of it, so k_mesh can start without a host round trip
     int nwork, work_begin, work_end, pad_;
@@ -56,10 +61,9 @@ struct MeshArgs {
     const McTables *mc;
     const int *worklist;           // its length and this shard's slice are in ctr (device side)
     unsigned char *kinds;          // per batch
-    unsigned int *batch_count;     // per work item: triangles
-    unsigned long long *batch_base;  // per work item: first triangle slot in the arena
-    float *arena;                  // 9 floats per triangle
-    unsigned long long arena_cap;  // triangles
+    unsigned long long *status;    // per work item: look-back word (flag << 62 | triangles), zeroed per run
+    double *out;                   // the ordered soup: 9 doubles per triangle, world coordinates
+    unsigned long long out_cap;    // triangles
     MeshCounters *ctr;
     int bits_off;                  // byte offset of the sign-bit volume in dynamic LDS
     int list_off;                  // byte offset of the triangle work list in dynamic LDS
@@ -135,6 +139,55 @@ __device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0
     double p0 = (double)(i0 + o0), p1 = (double)(i1 + o1), p2 = (double)(i2 + o2);
     if (axis == 0) p0 = (double)i0 + t; else if (axis == 1) p1 = (double)i1 + t; else p2 = (double)i2 + t;
     o[0] = (float)p0; o[1] = (float)p1; o[2] = (float)p2;
+}
+
+// ---- ordered allocation: exclusive prefix of the triangle counts over the work list -----------
+// status word of work item w: flag << 62 | value; flag 0 = nothing yet, 1 = value is the item's own
+// count ("aggregate"), 2 = value is the inclusive prefix up to and including w.  Decoupled look-back
+// (Merrill & Garland): publish the aggregate, then walk back 64 predecessors at a time, summing
+// aggregates until an inclusive prefix is met; publish the own inclusive prefix.  Work items are
+// taken from the counter in order, so every predecessor is held by a RUNNING workgroup: the walk
+// never waits on a workgroup that is itself waiting for a CU.  Words are exchanged with agent-scope
+// atomics (per-CU L1 and per-XCD L2 are not coherent for plain accesses); every spin is bounded.
+// Called by wave 0 of the workgroup (all 64 lanes); returns the exclusive prefix, or ~0 on timeout.
+#define MESH_FLAG_AGG (1ull << 62)
+#define MESH_FLAG_PFX (2ull << 62)
+#define MESH_VAL_MASK ((1ull << 62) - 1)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, d, 64), hi = __shfl_xor((unsigned)(v >> 32), d, 64);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long ordered_base(unsigned long long *status, int w, int w_begin, unsigned long long total) {
+    const int lane = threadIdx.x & 63;
+    if (w == w_begin) {
+        if (lane == 0) __hip_atomic_store(&status[w], MESH_FLAG_PFX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&status[w], MESH_FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long excl = 0;
+    int idx = w - 1;
+    for (unsigned spins = 0; spins < (1u << 24); spins++) {
+        const int j = idx - lane;
+        const unsigned long long sw = j >= w_begin ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                   : MESH_FLAG_PFX;   // in front of the shard: prefix 0
+        const unsigned flag = (unsigned)(sw >> 62);
+        const unsigned long long pending = __ballot(flag == 0), is_pfx = __ballot(flag == 2);
+        if (is_pfx) {
+            const int p = __ffsll((long long)is_pfx) - 1;                 // nearest predecessor with a prefix
+            if (pending & ((1ull << p) - 1ull)) { __builtin_amdgcn_s_sleep(1); continue; }
+            excl += wave_sum_u64(lane <= p ? (sw & MESH_VAL_MASK) : 0ull);
+            if (lane == 0) __hip_atomic_store(&status[w], MESH_FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return excl;
+        }
+        if (pending) { __builtin_amdgcn_s_sleep(1); continue; }
+        excl += wave_sum_u64(sw & MESH_VAL_MASK);
+        idx -= 64;
+    }
+    return ~0ull;
 }
 
 // triangle j of an ambiguous cell: re-runs the selection (cheaper than carrying the tiling through
@@ -267,25 +320,23 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             row_off[k] = total + block_exclusive_scan<BLOCK>(n, wave_sums, tot);
             total += tot;
         }
-        if (tid == 0) {
-            unsigned long long base = 0;
-            if (total) {
-                base = atomicAdd(&a.ctr->tri_counter, (unsigned long long)total);
-                if (base + (unsigned long long)total > a.arena_cap) atomicOr(&a.ctr->overflow, 1u);
-                atomicAdd(&a.ctr->n_nonempty, 1u);
-            } else {
-                atomicAdd(&a.ctr->n_empty, 1u);
+        // ---- ordered allocation (wave 0), then the per-batch bookkeeping ----
+        if (tid < 64) {
+            const unsigned long long excl = ordered_base(a.status, w, work_begin, (unsigned long long)total);
+            if (tid == 0) {
+                if (excl == ~0ull) atomicOr(&a.ctr->overflow, 2u);           // look-back timed out (never expected)
+                else if (excl + (unsigned long long)total > a.out_cap) atomicOr(&a.ctr->overflow, 1u);
+                atomicAdd(total ? &a.ctr->n_nonempty : &a.ctr->n_empty, 1u);
+                atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
+                if (w == work_end - 1 && excl != ~0ull) a.ctr->total = excl + (unsigned long long)total;
+                a.kinds[b] = total ? 2 : 1;
+                reinterpret_cast<unsigned long long *>(bcast + 2)[0] = excl;
             }
-            atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
-            a.batch_count[w] = (unsigned)total;
-            a.batch_base[w] = base;
-            a.kinds[b] = total ? 2 : 1;
-            reinterpret_cast<unsigned long long *>(bcast + 2)[0] = base;
         }
         if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
         __syncthreads();
         const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
-        const bool fits = base + (unsigned long long)total <= a.arena_cap;
+        const bool fits = base != ~0ull && base + (unsigned long long)total <= a.out_cap;
         SDF_PROF(2);
 
         // ---- 3 + 4. per-triangle work list in LDS, then one lane per triangle ----
@@ -319,7 +370,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
             __syncthreads();
             SDF_PROF(3);
-            float *dst0 = a.arena + (base + (unsigned long long)lo) * 9ull;
+            double *dst0 = a.out + (base + (unsigned long long)lo) * 9ull;
+            // points * scale + offset (reference sdf/core.py:58-60): scale = first axis step of the
+            // batch, offset = its first sample, per axis
+            const double of0 = axes[0], of1 = axes[33], of2 = axes[66];
+            const double sc0 = axes[1] - of0, sc1 = axes[34] - of1, sc2 = axes[67] - of2;
             for (int t = tid; t < cn; t += BLOCK) {
                 const unsigned e = list[t];
                 const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
@@ -334,9 +389,13 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     mc_vertex(corner, lyz, lz, i0, i1, i2, tt[1], o + 3);
                     mc_vertex(corner, lyz, lz, i0, i1, i2, tt[2], o + 6);
                 }
-                float *dst = dst0 + (size_t)t * 9;
+                double *dst = dst0 + (size_t)t * 9;
                 SDF_UNROLL
-                for (int q = 0; q < 9; q++) dst[q] = o[q];
+                for (int q = 0; q < 9; q += 3) {
+                    dst[q] = (double)o[q] * sc0 + of0;
+                    dst[q + 1] = (double)o[q + 1] * sc1 + of1;
+                    dst[q + 2] = (double)o[q + 2] * sc2 + of2;
+                }
             }
             __syncthreads();   // list / vol are reused
             SDF_PROF(4);

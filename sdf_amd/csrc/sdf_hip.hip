@@ -11,9 +11,8 @@
 //                                 into LDS (143,748 B of gfx950's 160 KiB), classifies the cells,
 //                                 block-scans the triangle counts and emits the batch-local
 //                                 float32 soup (reference `_worker`, sdf/core.py:45-56)
-//   k_scan                        exclusive scan of per-batch triangle counts (reference order)
-//   k_gather                      ordered gather + `points * scale + offset` in float64
-//                                 (reference sdf/core.py:58-60, :141)
+//                                 and writes the float64 world-space soup in reference order
+//                                 (`points * scale + offset`, reference sdf/core.py:58-60, :141)
 //   k_mc_rows / k_mc_emit         marching cubes of a caller-supplied volume (`_marching_cubes`)
 //   k_stl                         50-byte STL records (reference sdf/stl.py:4-24)
 #include <hip/hip_runtime.h>
@@ -111,54 +110,6 @@ __global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restric
         ctr->nwork = base;
         ctr->work_begin = (int)(((long long)base * shard_index) / shard_count);
         ctr->work_end = (int)(((long long)base * (shard_index + 1)) / shard_count);
-    }
-}
-
-// exclusive scan of batch_count[w0..w1) -> batch_final (triangle index in the ordered soup)
-__global__ __launch_bounds__(1024) void k_scan(const unsigned int *__restrict__ batch_count,
-                                               unsigned long long *__restrict__ batch_final, MeshCounters *ctr) {
-    const int w0 = ctr->work_begin, w1 = ctr->work_end;
-    __shared__ int wave_sums[16];
-    unsigned long long base = 0;
-    for (int start = w0; start < w1; start += 1024) {
-        const int w = start + threadIdx.x;
-        const int v = w < w1 ? (int)batch_count[w] : 0;
-        int tot;
-        const int pos = block_exclusive_scan<1024>(v, wave_sums, tot);
-        if (w < w1) batch_final[w] = base + (unsigned long long)pos;
-        base += (unsigned long long)tot;
-    }
-    if (threadIdx.x == 0) ctr->total = base;
-}
-
-// ordered gather + float64 world transform: out[final + i] = f64(local) * scale + offset
-// (reference sdf/core.py:58-60).  One workgroup per work item.
-// The work range and the total come from the device-side counters, so the kernel can be enqueued
-// right behind k_scan without the host knowing them; it does nothing when the soup does not fit
-// `cap_out` triangles or the meshing pass overflowed its arena (the host sees both in the counters).
-__global__ __launch_bounds__(256) void k_gather(GridDesc g, const int *__restrict__ worklist,
-                                                const MeshCounters *__restrict__ ctr, unsigned long long cap_out,
-                                                const unsigned int *__restrict__ batch_count,
-                                                const unsigned long long *__restrict__ batch_base,
-                                                const unsigned long long *__restrict__ batch_final,
-                                                const float *__restrict__ arena, double *__restrict__ out) {
-    const int w = ctr->work_begin + blockIdx.x;
-    if (w >= ctr->work_end || ctr->overflow || ctr->total > cap_out) return;
-    const unsigned n = batch_count[w];
-    if (!n) return;
-    const int b = worklist[w];
-    int ox, oy, oz, lx, ly, lz;
-    batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-    const double of[3] = {g.X[ox], g.Y[oy], g.Z[oz]};
-    const double sc[3] = {g.X[ox + 1] - g.X[ox], g.Y[oy + 1] - g.Y[oy], g.Z[oz + 1] - g.Z[oz]};
-    const float *src = arena + batch_base[w] * 9ull;
-    double *dst = out + batch_final[w] * 9ull;
-    const unsigned m = n * 9u;
-    for (unsigned i = threadIdx.x; i < m; i += blockDim.x) {
-        const unsigned ax = i % 3u;
-        const double s = ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2]);
-        const double o = ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]);
-        dst[i] = (double)src[i] * s + o;
     }
 }
 
@@ -350,11 +301,11 @@ struct sdf_ctx {
     hipEvent_t ev[8] = {};
     int n_cu = 256;
     size_t lds_max = 0;
-    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, scratch_in, scratch_out, rows, rows_off, mc;
+    DevBuf scratch_in, scratch_out, rows, rows_off, mc;
     int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
-    std::vector<DevBuf> arena_pool;   // arenas handed back by destroyed meshes
+    std::vector<DevBuf> arena_pool;   // soup buffers handed back by destroyed meshes
     std::vector<DevBuf> counter_pool; // 64-byte MeshCounters blocks handed back by destroyed meshes
 };
 
@@ -373,10 +324,9 @@ struct sdf_mesh {
     sdf_ctx *ctx = nullptr;
     sdf_stats st = {};
     GridDesc g = {};
-    DevBuf axes, kinds, worklist, batch_count, batch_base, batch_final, arena, out;
+    DevBuf axes, kinds, worklist, status, out;
     DevBuf counters;               // this call's MeshCounters block (pooled in the context)
     int work_begin = 0, work_end = 0;
-    bool emitted = false;
     void *emitted_to = nullptr;    // caller buffer the soup was gathered into by sdf_generate_to_device
 };
 
@@ -468,7 +418,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->axes, &c->kinds, &c->worklist, &c->batch_count, &c->batch_base, &c->batch_final, &c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof})
+    for (DevBuf *b : {&c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof})
         b->release();
     for (auto &b : c->arena_pool) b.release();
     for (auto &b : c->counter_pool) b.release();
@@ -682,8 +632,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     if (nb == 0) return 0;
 
     if (m->axes.ensure((size_t)(nx + ny + nz) * 8) || m->kinds.ensure((size_t)nb) || m->worklist.ensure((size_t)nb * 4) ||
-        m->batch_count.ensure((size_t)nb * 4) || m->batch_base.ensure((size_t)nb * 8) || m->batch_final.ensure((size_t)nb * 8) ||
-        false)
+        m->status.ensure((size_t)nb * 8))
         return 1;
     if (!m->counters.p && !c->counter_pool.empty()) { m->counters = c->counter_pool.back(); c->counter_pool.pop_back(); }
     if (m->counters.ensure(sizeof(MeshCounters))) return 1;
@@ -708,33 +657,43 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
 
-    // ---- meshing.  The whole chain (prepass -> k_mesh -> k_scan) is enqueued without a host round
-    // trip: the work-list length stays on the device.  The triangle arena is sized from the last
-    // call of this tape on the same grid (first call: from the work-list length, which costs one
-    // synchronisation); an overflow re-runs k_mesh once with the exact size. ----
+    // ---- meshing.  The whole chain (prepass -> k_mesh) is enqueued without a host round trip: the
+    // work-list length stays on the device and k_mesh writes the ordered float64 soup itself.  The
+    // soup goes into the caller's device buffer when one was given (sdf_generate_to_device),
+    // otherwise into a library buffer sized from the last call of this tape on the same grid (first
+    // call: from the work-list length, which costs one synchronisation).  A soup that does not fit
+    // is detected on the device (nothing is written past the capacity) and the pass is re-run into
+    // a library buffer of the exact size. ----
     const unsigned long long key = ((unsigned long long)nx << 42) ^ ((unsigned long long)ny << 21) ^ (unsigned long long)nz ^
                                    ((unsigned long long)shard_index << 56) ^ ((unsigned long long)shard_count << 48) ^
                                    ((unsigned long long)bs << 36) ^ (sparse ? 1ull << 63 : 0ull);
-    unsigned long long cap;
+    unsigned long long cap = 0;
     MeshCounters h;
-    if (t->hint_key == key && t->hint_total_tris) {
-        cap = t->hint_total_tris + t->hint_total_tris / 4 + 4096;
-    } else {
-        HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        const unsigned long long nshard0 = (unsigned long long)std::max(h.work_end - h.work_begin, 1);
-        cap = std::max<unsigned long long>(4096ull * nshard0, 1ull << 16);
+    bool to_caller = d_out && cap_out > 0;
+    if (!to_caller) {
+        if (t->hint_key == key && t->hint_total_tris) {
+            cap = t->hint_total_tris + t->hint_total_tris / 4 + 4096;
+        } else {
+            HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            const unsigned long long nshard0 = (unsigned long long)std::max(h.work_end - h.work_begin, 1);
+            cap = std::max<unsigned long long>(4096ull * nshard0, 1ull << 16);
+        }
     }
     float ms = 0;
     for (int attempt = 0;; attempt++) {
-        if (!m->arena.p && !c->arena_pool.empty()) { m->arena = c->arena_pool.back(); c->arena_pool.pop_back(); }
-        if (m->arena.ensure((size_t)cap * 36)) return 1;
-        cap = m->arena.bytes / 36;
-        if (attempt) HIPCHK(hipMemsetAsync(m->counters.p, 0, MESH_COUNTERS_RESET_BYTES, c->stream));
         MeshArgs a;
+        if (to_caller) {
+            a.out = (double *)d_out; a.out_cap = (unsigned long long)cap_out;
+        } else {
+            if (!m->out.p && !c->arena_pool.empty()) { m->out = c->arena_pool.back(); c->arena_pool.pop_back(); }
+            if (m->out.ensure((size_t)cap * 72)) return 1;
+            a.out = (double *)m->out.p; a.out_cap = m->out.bytes / 72;
+        }
+        if (attempt) HIPCHK(hipMemsetAsync(m->counters.p, 0, MESH_COUNTERS_RESET_BYTES, c->stream));
+        HIPCHK(hipMemsetAsync(m->status.p, 0, (size_t)nb * 8, c->stream));
         a.g = g; a.worklist = (const int *)m->worklist.p;
-        a.kinds = (unsigned char *)m->kinds.p; a.batch_count = (unsigned *)m->batch_count.p;
-        a.batch_base = (unsigned long long *)m->batch_base.p; a.arena = (float *)m->arena.p; a.arena_cap = cap;
+        a.kinds = (unsigned char *)m->kinds.p; a.status = (unsigned long long *)m->status.p;
         a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
@@ -743,26 +702,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipEventRecord(c->ev[3], c->stream));
         if (launch_mesh(t, precision, a, grid, bs)) return 1;
         HIPCHK(hipEventRecord(c->ev[4], c->stream));
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)m->batch_count.p,
-                           (unsigned long long *)m->batch_final.p, (MeshCounters *)m->counters.p);
-        HIPCHK(hipGetLastError());
-        if (d_out && cap_out > 0) {   // the ordered gather rides in the same submission (no host round trip)
-            HIPCHK(hipEventRecord(c->ev[6], c->stream));
-            hipLaunchKernelGGL(k_gather, dim3(nb), dim3(256), 0, c->stream, g, (const int *)m->worklist.p,
-                               (const MeshCounters *)m->counters.p, (unsigned long long)cap_out, (const unsigned *)m->batch_count.p,
-                               (const unsigned long long *)m->batch_base.p, (const unsigned long long *)m->batch_final.p,
-                               (const float *)m->arena.p, (double *)d_out);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(c->ev[7], c->stream));
-        }
         HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
         m->st.ms_mesh = ms;
-        if (d_out && cap_out > 0) {
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
-            m->st.ms_emit = ms;
-        }
         if (c->prof.p) {
             unsigned long long pc[8];
             HIPCHK(hipMemcpy(pc, c->prof.p, 64, hipMemcpyDeviceToHost));
@@ -770,18 +713,20 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                     ms, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5]);
         }
         m->st.n_retries = attempt;
+        if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
         if (h.overflow) {
-            if (attempt >= 3) return fail("sdf_generate: triangle arena overflow persists");
-            cap = h.tri_counter + h.tri_counter / 8 + 1024;   // exact need is known now
+            if (attempt >= 3) return fail("sdf_generate: soup buffer overflow persists");
+            to_caller = false;                       // the exact need is known now: h.total
+            cap = h.total + 1024;
             continue;
         }
+        m->emitted_to = to_caller ? d_out : nullptr;
         break;
     }
     m->work_begin = h.work_begin; m->work_end = h.work_end;
     m->st.n_skipped = nb - h.nwork;
     m->st.n_work_begin = m->work_begin; m->st.n_work_end = m->work_end;
     m->st.n_triangles = (int64_t)h.total;
-    m->emitted_to = (d_out && cap_out > 0 && h.total <= (unsigned long long)cap_out) ? d_out : nullptr;
     m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
     m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
@@ -844,18 +789,16 @@ int sdf_mesh_stats(sdf_mesh *m, sdf_stats *out) {
 
 int64_t sdf_mesh_triangles(sdf_mesh *m) { return m ? m->st.n_triangles : 0; }
 
+// where the soup of a mesh lives: the caller's buffer of sdf_generate_to_device, or the library's
+static const void *mesh_soup(const sdf_mesh *m) { return m->emitted_to ? m->emitted_to : m->out.p; }
+
 int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
     if (!m || !d_out) return fail("sdf_mesh_emit_device: NULL argument");
     sdf_ctx *c = m->ctx;
-    if (m->st.n_triangles == 0) return 0;
+    if (m->st.n_triangles == 0 || d_out == mesh_soup(m)) return 0;
     HIPCHK(hipSetDevice(c->device));
-    const int nshard = m->work_end - m->work_begin;
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
-    hipLaunchKernelGGL(k_gather, dim3(nshard), dim3(256), 0, c->stream, m->g, (const int *)m->worklist.p,
-                       (const MeshCounters *)m->counters.p, ~0ull, (const unsigned *)m->batch_count.p,
-                       (const unsigned long long *)m->batch_base.p, (const unsigned long long *)m->batch_final.p,
-                       (const float *)m->arena.p, (double *)d_out);
-    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d_out, mesh_soup(m), (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[4], c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0;
@@ -864,20 +807,11 @@ int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
     return 0;
 }
 
-static int mesh_ensure_out(sdf_mesh *m) {
-    if (m->emitted) return 0;
-    if (m->out.ensure((size_t)m->st.n_triangles * 72)) return 1;
-    if (sdf_mesh_emit_device(m, m->out.p)) return 1;
-    m->emitted = true;
-    return 0;
-}
-
 int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_emit_host: NULL argument");
     if (m->st.n_triangles == 0) return 0;
     HIPCHK(hipSetDevice(m->ctx->device));
-    if (mesh_ensure_out(m)) return 1;
-    HIPCHK(hipMemcpyAsync(h_out, m->out.p, (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_out, mesh_soup(m), (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToHost, m->ctx->stream));
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
     return 0;
 }
@@ -888,9 +822,8 @@ int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
     if (nt == 0) return 0;
     sdf_ctx *c = m->ctx;
     HIPCHK(hipSetDevice(c->device));
-    if (mesh_ensure_out(m)) return 1;
     if (c->scratch_out.ensure((size_t)nt * 50)) return 1;
-    hipLaunchKernelGGL(k_stl, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, (const double *)m->out.p, nt,
+    hipLaunchKernelGGL(k_stl, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, (const double *)mesh_soup(m), nt,
                        (unsigned short *)c->scratch_out.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)nt * 50, hipMemcpyDeviceToHost, c->stream));
@@ -913,14 +846,14 @@ int sdf_mesh_destroy(sdf_mesh *m) {
     sdf_ctx *c = m->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (m->arena.p) {   // keep one arena around for the next call
-        if (c->arena_pool.empty()) c->arena_pool.push_back(m->arena);
-        else if (c->arena_pool.back().bytes < m->arena.bytes) { c->arena_pool.back().release(); c->arena_pool.back() = m->arena; }
-        else m->arena.release();
-        m->arena.p = nullptr;
+    if (m->out.p) {   // keep one soup buffer around for the next call
+        if (c->arena_pool.empty()) c->arena_pool.push_back(m->out);
+        else if (c->arena_pool.back().bytes < m->out.bytes) { c->arena_pool.back().release(); c->arena_pool.back() = m->out; }
+        else m->out.release();
+        m->out.p = nullptr; m->out.bytes = 0;
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
-    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->batch_count, &m->batch_base, &m->batch_final, &m->out}) b->release();
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status}) b->release();
     delete m;
     return 0;
 }
