@@ -172,7 +172,9 @@ def main():
     # ---- roofline of the dominant kernel (k_mesh), from HIP events on the library's stream ----
     k_ms = float(np.mean(mesh_ms))
     shard_tris = int(st.get('n_triangles', tris)) if world == 1 else int(max(st.get('per_rank_triangles', [tris])))
-    alg_bytes = 36.0 * shard_tris                     # fused design: 36 B per emitted triangle
+    # fused design: the kernel's only HBM product is the ordered float64 soup, 9 doubles = 72 B per
+    # triangle (SURVEY 8d counts 36 B for a float32 soup; the reference's soup is float64)
+    alg_bytes = 72.0 * shard_tris
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     plain, special = tape.tape.flop_estimate()
     eval_vox = int(st['n_eval_voxels']) if world == 1 else int(st['n_eval_voxels'] // world)

@@ -93,13 +93,17 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
 }
 
 // ordered compaction of the pending batches into the work list (single workgroup)
+// (also clears the look-back words and the counters of the meshing pass that follows, so the
+// common path needs no memset launches)
 __global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restrict__ kinds, int nbatches,
                                                   int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
+                                                  unsigned long long *__restrict__ status,
                                                   long long shard_index, long long shard_count) {
     __shared__ int wave_sums[16];
     int base = 0;
     for (int start = 0; start < nbatches; start += 1024) {
         const int b = start + threadIdx.x;
+        if (b < nbatches) status[b] = 0ull;
         const int f = (b < nbatches && kinds[b] != 0) ? 1 : 0;
         int tot;
         const int pos = block_exclusive_scan<1024>(f, wave_sums, tot);
@@ -107,6 +111,8 @@ __global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restric
         base += tot;
     }
     if (threadIdx.x == 0) {   // contiguous chunk of the work list for this shard (same formula as sdf_amd/dist.py)
+        MeshCounters z = {};
+        *ctr = z;
         ctr->nwork = base;
         ctr->work_begin = (int)(((long long)base * shard_index) / shard_count);
         ctr->work_end = (int)(((long long)base * (shard_index + 1)) / shard_count);
@@ -295,6 +301,8 @@ struct DevBuf {
     void release() { if (p) g_pool.give(p, bytes, device); p = nullptr; bytes = 0; }
 };
 
+#define SDF_STAGE_BYTES (1u << 20)
+
 struct sdf_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -307,6 +315,7 @@ struct sdf_ctx {
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
     std::vector<DevBuf> arena_pool;   // soup buffers handed back by destroyed meshes
     std::vector<DevBuf> counter_pool; // 64-byte MeshCounters blocks handed back by destroyed meshes
+    void *h_stage = nullptr;          // pinned host staging: the axes on the way in, the counters on the way out
 };
 
 struct sdf_tape {
@@ -400,6 +409,7 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipHostMalloc(&c->h_stage, SDF_STAGE_BYTES, hipHostMallocDefault));
     McTables t;
     memcpy(t.ntri, MC_NTRI, 256);
     memcpy(t.amb, MC_AMBIGUOUS, 256);
@@ -424,6 +434,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     for (auto &b : c->counter_pool) b.release();
     g_pool.drop_device(c->device);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -639,10 +650,16 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     double *dX = (double *)m->axes.p, *dY = dX + nx, *dZ = dY + ny;
     g.X = dX; g.Y = dY; g.Z = dZ;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(m->counters.p, 0, sizeof(MeshCounters), c->stream));
+    const size_t axis_bytes = (size_t)(nx + ny + nz) * 8;
+    if (axis_bytes <= SDF_STAGE_BYTES - 256) {   // one copy from pinned memory instead of three from pageable
+        double *hs = (double *)c->h_stage;
+        memcpy(hs, X, (size_t)nx * 8); memcpy(hs + nx, Y, (size_t)ny * 8); memcpy(hs + nx + ny, Z, (size_t)nz * 8);
+        HIPCHK(hipMemcpyAsync(dX, hs, axis_bytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, c->stream));
+    }
 
     // ---- prepass: skip test for every batch, then the ordered work list (+ this shard's slice) ----
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -653,7 +670,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
     }
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
-                       (MeshCounters *)m->counters.p, (long long)shard_index, (long long)shard_count);
+                       (MeshCounters *)m->counters.p, (unsigned long long *)m->status.p, (long long)shard_index,
+                       (long long)shard_count);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
 
@@ -690,8 +708,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             if (m->out.ensure((size_t)cap * 72)) return 1;
             a.out = (double *)m->out.p; a.out_cap = m->out.bytes / 72;
         }
-        if (attempt) HIPCHK(hipMemsetAsync(m->counters.p, 0, MESH_COUNTERS_RESET_BYTES, c->stream));
-        HIPCHK(hipMemsetAsync(m->status.p, 0, (size_t)nb * 8, c->stream));
+        if (attempt) {   // (the first pass finds both cleared by k_compact)
+            HIPCHK(hipMemsetAsync(m->counters.p, 0, MESH_COUNTERS_RESET_BYTES, c->stream));
+            HIPCHK(hipMemsetAsync(m->status.p, 0, (size_t)nb * 8, c->stream));
+        }
         a.g = g; a.worklist = (const int *)m->worklist.p;
         a.kinds = (unsigned char *)m->kinds.p; a.status = (unsigned long long *)m->status.p;
         a.ctr = (MeshCounters *)m->counters.p;
@@ -702,8 +722,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipEventRecord(c->ev[3], c->stream));
         if (launch_mesh(t, precision, a, grid, bs)) return 1;
         HIPCHK(hipEventRecord(c->ev[4], c->stream));
-        HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        MeshCounters *hp = (MeshCounters *)((char *)c->h_stage + SDF_STAGE_BYTES - 256);   // pinned
+        HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        h = *hp;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
         m->st.ms_mesh = ms;
         if (c->prof.p) {

@@ -78,7 +78,11 @@ def main():
         d = out['kernels'][dom]
         fetch_kib = d.get('FETCH_SIZE', {}).get('mean')
         write_kib = d.get('WRITE_SIZE', {}).get('mean')
-        cal = None
+        # WRITE_SIZE calibration: measured once on k_gather (profiles/r01b_pmc.json), a kernel whose
+        # written byte count was known exactly (72 B per triangle, 8-byte stores per lane like k_mesh's
+        # output stores): raw KiB * 1024 * 0.99897 = bytes.  k_gather no longer exists (k_mesh writes the
+        # soup itself), so the factor is carried over.
+        cal = 0.99897
         g = next((k for k in per if 'k_gather' in k), None)
         if g and tris and 'WRITE_SIZE' in out['kernels'][g]:
             cal = (72.0 * tris) / (out['kernels'][g]['WRITE_SIZE']['mean'] * 1024.0)
@@ -88,13 +92,13 @@ def main():
         out['dominant_kernel'] = dom
         out['fetch_bytes_per_launch_corrected'] = fetch_kib * 2048.0 if fetch_kib is not None else None
         out['write_bytes_per_launch_raw'] = write_kib * 1024.0 if write_kib is not None else None
-        out['write_calibration_factor_from_k_gather'] = cal
+        out['write_calibration_factor'] = cal
         out['hbm_bytes_per_launch'] = hbm
-        out['algorithmic_bytes_per_launch'] = 36.0 * tris if tris else None
+        out['algorithmic_bytes_per_launch'] = 72.0 * tris if tris else None
     json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_pmc.json' % tag), 'w'), indent=1, sort_keys=True)
     print('\n'.join(md))
     print(json.dumps({k: out.get(k) for k in ('dominant_kernel', 'hbm_bytes_per_launch', 'algorithmic_bytes_per_launch',
-                                              'write_calibration_factor_from_k_gather')}))
+                                              'write_calibration_factor')}))
 
 
 if __name__ == '__main__':
