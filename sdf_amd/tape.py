@@ -442,6 +442,33 @@ def peephole(code):
     return [w for pair in out for w in pair]
 
 
+# which instruction fields name PS / DS slots (for the slot census after the peephole pass)
+_P_FIELDS = {'SAVE_P': 'a', 'LOAD_P': 'a', 'REP_PREP': 'a', 'REP_SET': 'ab', 'CIRC_PREP': 'a', 'CIRC_SET': 'a'}
+_D_FIELDS = {'COMB': 'a', 'PUSH_D': 'a', 'ELONGATE': 'a', 'ELONGATE2': 'a', 'ADD_DS': 'a', 'TRANS_LIN_PRE': 'a',
+             'TRANS_RAD_PRE': 'a', 'TRANS_MIX': 'ab', 'EXT_PRE': 'a', 'EXT_POST': 'a', 'EXTTO_PRE': 'a',
+             'EXTTO_MIX': 'ab', 'SLICE_POST': 'a'}
+
+
+def slot_census(code):
+    """(number of PS slots, number of DS slots) a tape really touches"""
+    np_, nd = 0, 0
+    for i in range(0, len(code), 2):
+        w0, w1 = int(code[i]), int(code[i + 1])
+        name = OP_NAMES[w0 & 255]
+        fields = {'a': w0 >> A_SHIFT, 'b': w1 >> B_SHIFT}
+        for f in _P_FIELDS.get(name, ''):
+            np_ = max(np_, fields[f] + 1)
+        for f in _D_FIELDS.get(name, ''):
+            nd = max(nd, fields[f] + 1)
+        if w0 & RL_FLAG:
+            np_ = max(np_, ((w0 >> RL_SHIFT) & 7) + 1)
+        if w0 & SV_FLAG:
+            np_ = max(np_, ((w0 >> SV_SHIFT) & 7) + 1)
+        if w0 & PD_FLAG:
+            nd = max(nd, ((w0 >> PD_SHIFT) & 7) + 1)
+    return np_, nd
+
+
 def lower(obj, dim=None):
     """lower an SDF2/SDF3/Node to a :class:`Tape`"""
     root = unwrap(obj)
@@ -452,5 +479,7 @@ def lower(obj, dim=None):
     lw.value(root, dim)
     lw.emit('END')
     assert lw.pdepth == 0 and lw.ddepth == 0
-    return Tape(np.array(peephole(lw.code), dtype=np.uint32), np.array(lw.consts, dtype=np.float64),
-                lw.pmax, lw.dmax, dim)
+    code = peephole(lw.code)
+    n_p, n_d = slot_census(code)          # the peephole pass can leave slots unused
+    assert n_p <= lw.pmax and n_d <= lw.dmax
+    return Tape(np.array(code, dtype=np.uint32), np.array(lw.consts, dtype=np.float64), n_p, n_d, dim)
