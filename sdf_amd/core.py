@@ -81,7 +81,9 @@ def generate(
         sdf,
         step=None, bounds=None, samples=SAMPLES,
         workers=WORKERS, batch_size=BATCH_SIZE,
-        verbose=True, sparse=True):
+        verbose=True, sparse=True, _stl=False):
+    """reference sdf/core.py:84-150.  (`_stl=True` is what `save` uses for .stl files: the soup
+    stays on the device and the 50-byte STL records come back instead of the points.)"""
 
     from . import engine, dist
     start = time.time()
@@ -106,13 +108,18 @@ def generate(
         num_samples = overlapped(len(X)) * overlapped(len(Y)) * overlapped(len(Z))
         print('%d samples in %d batches with %d workers' % (num_samples, num_batches, workers))
 
+    records = None
     if dist.world_size() > 1:
         points, stats = dist.generate_sharded(eng, tape, X, Y, Z, batch_size, sparse)
     else:
         mesh = eng.generate(tape, X, Y, Z, batch_size, sparse)
         try:
-            points = mesh.points()
             stats = mesh.stats()
+            if _stl:
+                records = mesh.stl_records()
+                points = np.empty((3 * mesh.n_triangles, 0))     # only its length is used below
+            else:
+                points = mesh.points()
         finally:
             mesh.close()
 
@@ -123,6 +130,8 @@ def generate(
         print('%d triangles in %g seconds' % (triangles, seconds))
 
     generate.last_stats = stats
+    if _stl:
+        return records if records is not None else stl.stl_records(points).view(np.uint8).reshape(-1)
     return points
 
 
@@ -131,10 +140,13 @@ generate.last_stats = None
 
 def save(path, *args, **kwargs):
     """reference sdf/core.py:152-158"""
-    points = generate(*args, **kwargs)
     if path.lower().endswith('.stl'):
-        stl.write_binary_stl(path, points)
+        # normals and the 50-byte records are made on the device (k_stl); byte-identical to
+        # stl.write_binary_stl(path, points) -- tests/test_gpu.py
+        records = generate(*args, _stl=True, **kwargs)
+        stl.write_stl_records(path, records)
     else:
+        points = generate(*args, **kwargs)
         mesh = _mesh(points)
         mesh.write(path)
 

@@ -32,3 +32,12 @@ def write_binary_stl(path, points):
         fp.write(b'\x00' * 80)
         fp.write(struct.pack('<I', n))
         fp.write(rec.tobytes())
+
+
+def write_stl_records(path, records):
+    """`records`: T x 50 bytes as a flat uint8 array (Engine Mesh.stl_records())"""
+    records = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1)
+    with open(path, 'wb') as fp:
+        fp.write(b'\x00' * 80)
+        fp.write(struct.pack('<I', len(records) // 50))
+        fp.write(memoryview(records))
