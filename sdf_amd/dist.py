@@ -16,6 +16,9 @@ largest count and exchanged with one `all_gather_into_tensor`, then compacted.
 import numpy as np
 
 
+_PAD_HINT = {}     # (tape, grid, shard) -> padded triangle count of the previous exchange
+
+
 def _dist():
     try:
         import torch.distributed as td
@@ -73,7 +76,17 @@ def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None,
     if device.type == 'cuda' and hasattr(eng, 'set_stream'):
         eng.set_stream(torch.cuda.current_stream(device).cuda_stream)
         adopted = True
-    mesh = eng.generate(tape, X, Y, Z, batch_size, sparse, shard=(r, world))
+    # On a GPU the shard's soup is written by the meshing kernel straight into the exchange buffer
+    # (sized from the previous call; no zero fill, no device-to-device copy).
+    local = None
+    key = (id(tape), len(X), len(Y), len(Z), batch_size, bool(sparse), r, world)
+    if device.type == 'cuda' and hasattr(eng, 'lib'):
+        cap = _PAD_HINT.get(key, 0)
+        cap = cap + cap // 8 + 4096 if cap else 1 << 20
+        local = torch.empty(cap * 9, dtype=torch.float64, device=device)
+        mesh = eng.generate(tape, X, Y, Z, batch_size, sparse, shard=(r, world), out_ptr=local.data_ptr(), out_cap=cap)
+    else:
+        mesh = eng.generate(tape, X, Y, Z, batch_size, sparse, shard=(r, world))
     try:
         st = mesh.stats()
         t_local = mesh.n_triangles
@@ -88,8 +101,12 @@ def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None,
         t_pad = int(counts.max())
 
         # 2) the exchange step: padded all-gather of the triangle buffers, then compaction
+        _PAD_HINT[key] = t_pad
         if t_pad:
-            local = _local_tensor(mesh, t_pad, device)
+            if local is not None and getattr(mesh, 'emitted', False) and local.numel() >= t_pad * 9:
+                local = local[:t_pad * 9]          # (the tail beyond this rank's count is padding)
+            else:
+                local = _local_tensor(mesh, t_pad, device)
             gathered = torch.empty(world * t_pad * 9, dtype=torch.float64, device=device)
             td.all_gather_into_tensor(gathered, local, group=group)
             gathered = gathered.view(world, t_pad * 9)
