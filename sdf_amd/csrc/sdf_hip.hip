@@ -616,7 +616,7 @@ static int launch_mesh(sdf_tape *t, int precision, MeshArgs &a, int grid, int bs
     if (c->mesh_slots >= 0) slots = std::max(slots, std::min(c->mesh_slots, 2));
     // measured on the 512^3 example: 4 waves per SIMD beat 2, and two samples per lane
     // beat one whenever the variant still fits 128 VGPRs
-    int shape = slots == 0 ? 3 : 0;
+    int shape = slots <= 1 ? 3 : 0;   // (2,2) and (4,4) register files: 1024 x 2; (8,8): 1024 x 1 (x 2 would spill)
     if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
     int rc;
     if (precision == SDF_PRECISION_F64)
