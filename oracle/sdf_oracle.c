@@ -437,6 +437,28 @@ static double eval_node(const tree_t *t, int id, const double *p) {
         if ((py - b) * d > px * b) return len2(px - 0, py - b);
         return len2(px - (-d), py - 0) - r; }
     /* ---------------- 2-D transforms ---------------- */
+    case NODE_texture2d: { /* text.py:116-153: bilinear lookup into the distance texture, fallback
+                            * rectangle outside it.  c: x0 y0 x1 y1 pw ph px py tw th rect(4) tex[th][tw] */
+        long tw = (long)c[8], th = (long)c[9];
+        const double *tex = c + 14;
+        double u = (x - c[0]) / (c[2] - c[0]);
+        double v = (y - c[1]) / (c[3] - c[1]);
+        v = 1 - v;
+        double fi = u * c[4] + c[6], fj = v * c[5] + c[7];
+        /* _bilinear_interpolate (:138-153): np.floor(...).astype(int), then np.clip */
+        double gi = floor(fi), gj = floor(fj);
+        long a0 = gi != gi ? 0 : (gi < -2 ? -2 : (gi > (double)tw ? tw : (long)gi));
+        long b0 = gj != gj ? 0 : (gj < -2 ? -2 : (gj > (double)th ? th : (long)gj));
+        long ix0 = a0 < 0 ? 0 : (a0 > tw - 1 ? tw - 1 : a0), ix1 = a0 + 1 < 0 ? 0 : (a0 + 1 > tw - 1 ? tw - 1 : a0 + 1);
+        long iy0 = b0 < 0 ? 0 : (b0 > th - 1 ? th - 1 : b0), iy1 = b0 + 1 < 0 ? 0 : (b0 + 1 > th - 1 ? th - 1 : b0 + 1);
+        double pa = tex[iy0 * tw + ix0], pb = tex[iy1 * tw + ix0], pc = tex[iy0 * tw + ix1], pd = tex[iy1 * tw + ix1];
+        double wa = ((double)ix1 - fi) * ((double)iy1 - fj), wb = ((double)ix1 - fi) * (fj - (double)iy0);
+        double wc = (fi - (double)ix0) * ((double)iy1 - fj), wd = (fi - (double)ix0) * (fj - (double)iy0);
+        double d = wa * pa + wb * pb + wc * pc + wd * pd;
+        double qx = fabs(x - c[10]) - c[12], qy = fabs(y - c[11]) - c[13];
+        double qd = len2(np_max(qx, 0), np_max(qy, 0)) + np_min(np_max(qx, qy), 0);
+        int outside = (fi < 0) || (fi >= (double)(tw - 1)) || (fj < 0) || (fj >= (double)(th - 1));
+        return outside ? qd : d; }
     case NODE_translate2: q[0] = x - c[0]; q[1] = y - c[1]; q[2] = z; return child(t, n, 0, q);
     case NODE_scale2: q[0] = x / c[0]; q[1] = y / c[1]; q[2] = z; return child(t, n, 0, q) * c[2];
     case NODE_rotate2: /* d2.py:229-240: np.dot(p, matrix), matrix row-major c[0..3] */

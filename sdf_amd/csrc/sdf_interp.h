@@ -35,6 +35,8 @@ SDF_DEV double m_fma(double a, double b, double c) { return fma(a, b, c); }
 SDF_DEV float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
 SDF_DEV double m_fabs(double x) { return fabs(x); }
 SDF_DEV float m_fabs(float x) { return fabsf(x); }
+SDF_DEV double m_floor(double x) { return floor(x); }
+SDF_DEV float m_floor(float x) { return floorf(x); }
 SDF_DEV double m_rint(double x) { return rint(x); }
 SDF_DEV float m_rint(float x) { return rintf(x); }
 // The libm bodies (ocml: argument reduction, polynomial tables) are large -- inlined at every use
@@ -506,6 +508,34 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const T r = c[0], d = c[1], b = c[2];
             const V px = m_fabs(x), py = m_fabs(y);
             v = vsel((py - b) * d > px * b, len2(px - T(0), py - b), len2(px - (-d), py - T(0)) - r); goto fold; }
+        L_L_TEXTURE2D: {  // text.py:116-153 (`f` of `_sdf`) + :138-153 (`_bilinear_interpolate`)
+            // c: x0 y0 x1 y1 | pw ph px py | tw th | fallback rectangle (cx cy hx hy) | texture[th][tw]
+            const int tw = (int)c[8], th = (int)c[9];
+            const T *tex = c + 14;
+            const V u = (x - c[0]) / (c[2] - c[0]);
+            V vv = (y - c[1]) / (c[3] - c[1]);
+            vv = T(1) - vv;
+            const V ti = u * c[4] + c[6], tj = vv * c[5] + c[7];
+            V d;
+            SDF_UNROLL
+            for (int k = 0; k < NS; k++) {
+                const T fi = ti.v[k], fj = tj.v[k];
+                // floor, then np.clip to the texture; the float clamp only keeps the int conversion in
+                // range (every value below -1 / above tw clips to the same indices)
+                const T gi = fi == fi ? s_clip(m_floor(fi), T(-2), (T)tw) : T(0);
+                const T gj = fj == fj ? s_clip(m_floor(fj), T(-2), (T)th) : T(0);
+                const int a0 = (int)gi, b0 = (int)gj;
+                const int ix0 = min(max(a0, 0), tw - 1), ix1 = min(max(a0 + 1, 0), tw - 1);
+                const int iy0 = min(max(b0, 0), th - 1), iy1 = min(max(b0 + 1, 0), th - 1);
+                const T pa = tex[iy0 * tw + ix0], pb = tex[iy1 * tw + ix0], pc = tex[iy0 * tw + ix1], pd = tex[iy1 * tw + ix1];
+                const T wa = ((T)ix1 - fi) * ((T)iy1 - fj), wb = ((T)ix1 - fi) * (fj - (T)iy0);
+                const T wc = (fi - (T)ix0) * ((T)iy1 - fj), wd = (fi - (T)ix0) * (fj - (T)iy0);
+                d.v[k] = wa * pa + wb * pb + wc * pc + wd * pd;
+            }
+            const V qx = m_fabs(x - c[10]) - c[12], qy = m_fabs(y - c[11]) - c[13];       // d2.py:102-114
+            const V q = len2(np_max(qx, T(0)), np_max(qy, T(0))) + np_min(np_max(qx, qy), T(0));
+            const Mask<NS> outside = (ti < T(0)) | (ti >= (T)(tw - 1)) | (tj < T(0)) | (tj >= (T)(th - 1));
+            v = vsel(outside, q, d); goto fold; }
         // ---------------- fold a parked distance ----------------
         L_COMB: { V d1; DGET(d1, sa); acc = post_combine(post, d1, acc, c[-1]); goto next; }
         // ---------------- point ops ----------------

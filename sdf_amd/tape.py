@@ -24,6 +24,8 @@ which is what removes most stack traffic: ``a | b.translate(t) | c`` lowers to
 ``A; SAVE_P; TRANSLATE; B[post=UNION]; LOAD_P; C[post=UNION]`` without touching DS.
 The constant at ``const_off`` is K (always reserved); leaf parameters follow it.
 """
+from array import array
+
 import numpy as np
 
 from . import dn
@@ -35,7 +37,7 @@ _LEAVES = [
     'capped_cylinder', 'rounded_cylinder', 'capped_cone', 'rounded_cone', 'ellipsoid',
     'pyramid', 'tetrahedron', 'octahedron', 'dodecahedron', 'icosahedron',
     'circle', 'line', 'rectangle', 'rounded_rectangle', 'equilateral_triangle', 'hexagon',
-    'rounded_x', 'polygon', 'vesica',
+    'rounded_x', 'polygon', 'vesica', 'texture2d',
 ]
 _MACHINE = (
     ['END'] + ['L_' + n.upper() for n in _LEAVES] + [
@@ -147,15 +149,17 @@ class Tape:
 class _Lowering:
     def __init__(self):
         self.code = []
-        self.consts = []
+        self.consts = array('d')
         self.pdepth = self.ddepth = 0
         self.pmax = self.dmax = 0
 
     # -- emission helpers --
-    def emit(self, op, post='SET', a=0, b=0, consts=(), K=0.0):
+    def emit(self, op, post='SET', a=0, b=0, consts=(), K=0.0, blob=None):
         off = len(self.consts)
         self.consts.append(float(K))
         self.consts.extend(float(c) for c in consts)
+        if blob is not None:          # bulk constants (a sampled field) behind the parameters
+            self.consts.frombytes(np.ascontiguousarray(blob, dtype=np.float64).tobytes())
         assert 0 <= a < 256 and 0 <= b < 256 and off <= COFF_MASK
         self.code.append(OP[op] | (POST[post] << 8) | (a << A_SHIFT))
         self.code.append(off | (b << B_SHIFT))
@@ -209,7 +213,7 @@ class _Lowering:
             raise TypeError('%s is a %d-D node used on %d-D points' % (op, n.dim, dim))
         leaf = 'L_' + op.upper()
         if leaf in OP:
-            self.emit(leaf, post, consts=n.params, K=K)
+            self.emit(leaf, post, consts=n.params, K=K, blob=(n.meta or {}).get('blob'))
             return False
         if op in _PURE_TRANSFORMS:
             self.emit(_PURE_TRANSFORMS[op], consts=n.params)
@@ -482,4 +486,4 @@ def lower(obj, dim=None):
     code = peephole(lw.code)
     n_p, n_d = slot_census(code)          # the peephole pass can leave slots unused
     assert n_p <= lw.pmax and n_d <= lw.dmax
-    return Tape(np.array(code, dtype=np.uint32), np.array(lw.consts, dtype=np.float64), n_p, n_d, dim)
+    return Tape(np.array(code, dtype=np.uint32), np.frombuffer(lw.consts, dtype=np.float64).copy(), n_p, n_d, dim)

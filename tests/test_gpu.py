@@ -409,3 +409,41 @@ def test_no_surface_and_empty_inputs(ns, oracle_lib, eng):
     assert eng.eval_points(f, np.zeros((0, 3))).shape == (0,)
     assert eng.marching_cubes(np.ones((1, 5, 5))).shape == (0, 3)
     assert eng.marching_cubes(np.ones((4, 4, 4))).shape == (0, 3)
+
+
+TEX = np.load(os.path.join(GOLDEN, 'texture.npz'))
+
+
+@pytest.mark.parametrize('name', ['frame', 'blobs', 'noise'])
+def test_image_leaf_on_device(name, ns, oracle_lib, eng):
+    """sampled 2-D field leaf (reference sdf/text.py:65-153) through the tape interpreter: values
+    (2-D and extruded) bit-identical to the reference, device bounds and the meshed soup too"""
+    from test_oracle import _pictures
+    arr, kw = _pictures()[name]
+    f = ns['image'](arr, **kw)
+    P = TEX['p2_' + name]
+    assert np.array_equal(eng.eval_points(f, P), TEX['v2_' + name], equal_nan=True)
+    g = f.extrude(0.4)
+    P3 = np.concatenate([P, np.linspace(-0.5, 0.5, len(P)).reshape(-1, 1)], axis=1)
+    assert np.array_equal(eng.eval_points(g, P3), TEX['v3_' + name], equal_nan=True)
+    assert np.array_equal(np.array(core._estimate_bounds(g)), TEX['gen_bounds_' + name])
+    pts = g.generate(samples=2 ** 15, verbose=False)
+    assert len(pts) // 3 == int(TEX['gen_ntri_' + name])
+    assert hashlib.sha256(pts.tobytes()).digest() == TEX['gen_sha_' + name].tobytes()
+
+
+def test_text_leaf_runs_on_device(ns, eng, oracle_lib):
+    """`text(...)`: the glyph raster depends on the FreeType build, so it is checked against the CPU
+    checker on the same texture (not against a golden)"""
+    font = '/usr/share/fonts/truetype/dejavu/DejaVuSans.ttf'
+    if not os.path.exists(font):
+        pytest.skip('no TrueType font on this box')
+    t = ns['text'](font, 'MI355X', width=4.0, points=96)
+    g = t.extrude(0.5)
+    rng = np.random.RandomState(3)
+    P = rng.uniform(-2.5, 2.5, (2000, 3)) * np.array([1.0, 0.4, 0.2])
+    assert np.array_equal(eng.eval_points(g, P), oracle_lib.evaluate(g, P), equal_nan=True)
+    w, h = ns['measure_text'](font, 'MI355X', width=4.0)
+    assert w == 4.0 and 0 < h < 4.0
+    pts = g.generate(samples=2 ** 18, verbose=False)
+    assert len(pts) > 3000 and np.isfinite(pts).all()

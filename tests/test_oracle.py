@@ -90,3 +90,34 @@ def test_generate_matches_reference(path, ns, oracle_lib):
     assert hashlib.sha256(r.points.tobytes()).digest() == d['sha256'].tobytes()
     if 'points' in d.files:
         assert np.array_equal(r.points, d['points'])
+
+
+# ---- sampled 2-D field leaves (reference sdf/text.py) ------------------------------------------
+def _pictures():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_texture', os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), 'tools', 'make_golden_texture.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.pictures()
+
+
+TEX = np.load(os.path.join(GOLDEN, 'texture.npz'))
+
+
+@pytest.mark.parametrize('name', ['frame', 'blobs', 'noise'])
+def test_image_leaf_matches_reference(name, ns, oracle_lib):
+    """`image(array)`: PIL conversion + EDT on the host, bilinear lookup + fallback rectangle in the
+    checker: the reference's values bit for bit, in 2-D, extruded, and meshed end to end"""
+    arr, kw = _pictures()[name]
+    f = ns['image'](arr, **kw)
+    P = TEX['p2_' + name]
+    assert np.array_equal(oracle_lib.evaluate(f, P), TEX['v2_' + name], equal_nan=True)
+    g = f.extrude(0.4)
+    P3 = np.concatenate([P, np.linspace(-0.5, 0.5, len(P)).reshape(-1, 1)], axis=1)
+    assert np.array_equal(oracle_lib.evaluate(g, P3), TEX['v3_' + name], equal_nan=True)
+    bounds = tuple(map(tuple, TEX['gen_bounds_' + name]))
+    assert np.array_equal(np.array(oracle_lib.estimate_bounds(g)), TEX['gen_bounds_' + name])
+    X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** 15)
+    r = oracle_lib.generate(g, X, Y, Z, 32, True)
+    assert len(r.points) // 3 == int(TEX['gen_ntri_' + name])
+    assert hashlib.sha256(r.points.tobytes()).digest() == TEX['gen_sha_' + name].tobytes()
