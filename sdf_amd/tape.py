@@ -84,6 +84,10 @@ _PURE_TRANSFORMS = {
     'bend_linear': 'BEND_LINEAR', 'bend_radial': 'BEND_RADIAL', 'wrap_around': 'WRAP_AROUND',
     'translate2': 'TRANSLATE2', 'rotate2': 'ROTATE2', 'revolve': 'REVOLVE',
 }
+# machine ops that rewrite the current point
+_POINT_WRITERS = {'TRANSLATE', 'SCALE', 'ROTATE', 'ELONGATE', 'TWIST', 'BEND', 'BEND_LINEAR', 'BEND_RADIAL',
+                  'WRAP_AROUND', 'CIRC_SET', 'REP_SET', 'TRANSLATE2', 'SCALE2', 'ROTATE2', 'ELONGATE2', 'REVOLVE',
+                  'SETZ0'}
 _BOOL_POST = {
     'union': ('UNION', 'SUNION'), 'difference': ('DIFF', 'SDIFF'),
     'intersection': ('INTER', 'SINTER'), 'blend': (None, 'BLEND'),
@@ -152,6 +156,13 @@ class _Lowering:
         self.consts = array('d')
         self.pdepth = self.ddepth = 0
         self.pmax = self.dmax = 0
+        # value numbering of the current point: every instruction that rewrites p gives it a new
+        # version; a PS slot remembers the version it holds.  A construct that must preserve p
+        # first looks for a live slot that already holds the current version (e.g. the save of an
+        # enclosing boolean) and borrows it instead of saving the same point again.
+        self.pver = 0
+        self.next_ver = 1
+        self.slot_ver = {}
 
     # -- emission helpers --
     def emit(self, op, post='SET', a=0, b=0, consts=(), K=0.0, blob=None):
@@ -163,6 +174,25 @@ class _Lowering:
         assert 0 <= a < 256 and 0 <= b < 256 and off <= COFF_MASK
         self.code.append(OP[op] | (POST[post] << 8) | (a << A_SHIFT))
         self.code.append(off | (b << B_SHIFT))
+        if op in _POINT_WRITERS:
+            self.pver = self.next_ver
+            self.next_ver += 1
+        elif op == 'LOAD_P':
+            self.pver = self.slot_ver[a]
+        elif op == 'SAVE_P':
+            self.slot_ver[a] = self.pver
+        elif op in ('REP_PREP', 'CIRC_PREP'):
+            self.slot_ver[a] = None           # the slot holds indices / polar coordinates, not a point
+
+    def save_point(self):
+        """a live slot holding the current point: (slot, owned).  Borrows an enclosing construct's
+        slot when one already holds this version of p, else allocates one and emits SAVE_P."""
+        for s in range(self.pdepth):
+            if self.slot_ver.get(s) == self.pver:
+                return s, False
+        s = self.palloc()
+        self.emit('SAVE_P', a=s)
+        return s, True
 
     def palloc(self):
         s = self.pdepth
@@ -254,15 +284,15 @@ class _Lowering:
         if op == 'repeat':
             prm = dn.repeat_params(n, dim)
             nn = int(prm[8])
-            s0 = self.palloc()
+            s0, owned = self.save_point()
             s1 = self.palloc()
-            self.emit('SAVE_P', a=s0)
             self.emit('REP_PREP', a=s1, consts=prm[:8])
             for k in range(nn):
                 self.emit('REP_SET', a=s0, b=s1, consts=list(prm[1:4]) + list(prm[9 + 3 * k: 12 + 3 * k]))
                 self.value(n.children[0], dim, 'SET' if k == 0 else 'UNION')
             self.pfree()
-            self.pfree()
+            if owned:
+                self.pfree()
             return True
         if op in ('transition_linear', 'transition_radial'):
             st = self.dalloc()
@@ -304,16 +334,15 @@ class _Lowering:
         """acc = b(p) with a(p) parked in DS[dslot]; both see the same p"""
         na = unwrap(a)
         need_save = self.clobbers(na)
-        sp = None
+        sp, owned = None, False
         if need_save:
-            sp = self.palloc()
-            self.emit('SAVE_P', a=sp)
+            sp, owned = self.save_point()
         self.value(na, dim)
         self.emit('PUSH_D', a=dslot)
         if need_save:
             self.emit('LOAD_P', a=sp)
         dirty = self.value(b, dim)
-        if need_save:
+        if owned:
             self.pfree()
         return dirty
 
@@ -332,12 +361,11 @@ class _Lowering:
         kids = n.children
         dirty_flags = [self.clobbers(c) for c in kids]
         save = any(dirty_flags[:-1])
-        sp = None
+        sp, owned = None, False
         dirty = False
         for i, c in enumerate(kids):
             if save and sp is None and dirty_flags[i] and i < len(kids) - 1:
-                sp = self.palloc()
-                self.emit('SAVE_P', a=sp)
+                sp, owned = self.save_point()
             if dirty:
                 self.emit('LOAD_P', a=sp)
                 dirty = False
@@ -351,7 +379,7 @@ class _Lowering:
                     dirty = self.value(c, dim, kinds[0])
                 else:
                     dirty = self.value(c, dim, kinds[1], float(K))
-        if sp is not None:
+        if owned:
             self.pfree()
         return dirty
 
