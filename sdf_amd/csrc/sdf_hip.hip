@@ -5,14 +5,14 @@
 //   k_skip                        the reference's `_skip` predicate for every batch at once
 //                                 (reference sdf/core.py:28-43), 16 lanes per batch
 //   k_compact                     ordered work list of the surviving batches
-//   k_mesh                        THE hot kernel: one persistent workgroup per CU pulls batches
+//   k_mesh (sdf_device.h)         THE hot kernel: one persistent workgroup per CU pulls batches
 //                                 from the work list; samples the (<=33)^3 tile through the tape
 //                                 interpreter (float64 -> float32 like skimage's cast) straight
 //                                 into LDS (143,748 B of gfx950's 160 KiB), classifies the cells,
-//                                 block-scans the triangle counts and emits the batch-local
-//                                 float32 soup (reference `_worker`, sdf/core.py:45-56)
-//                                 and writes the float64 world-space soup in reference order
-//                                 (`points * scale + offset`, reference sdf/core.py:58-60, :141)
+//                                 finds the batch's place in the ordered soup by a look-back over
+//                                 the earlier batches' counts and writes the float64 world-space
+//                                 triangles in reference order (reference `_worker`,
+//                                 sdf/core.py:45-60, and `points.extend`, :141)
 //   k_mc_rows / k_mc_emit         marching cubes of a caller-supplied volume (`_marching_cubes`)
 //   k_stl                         50-byte STL records (reference sdf/stl.py:4-24)
 #include <hip/hip_runtime.h>
