@@ -49,6 +49,8 @@ typedef struct sdf_stats {
     double ms_mesh;             /* the fused sample+march kernel alone (last run)          */
     double ms_emit;             /* ordered gather / f64 transform kernel (last emit)       */
     double ms_total;            /* first launch to last kernel of sdf_generate             */
+    int64_t n_pruned_instrs;    /* tape instructions the interval prepass removed, summed over the shard's batches */
+    int64_t n_batch_instrs;     /* (instructions per tape) x (batches of the shard): the total they come out of    */
 } sdf_stats;
 
 int sdf_abi_version(void);
@@ -59,12 +61,21 @@ int sdf_ctx_create(int device, sdf_ctx **out);
 int sdf_ctx_destroy(sdf_ctx *ctx);
 /* adopt a caller-owned hipStream_t (e.g. torch's current stream); NULL returns to the own stream */
 int sdf_ctx_set_stream(sdf_ctx *ctx, void *hip_stream);
+/* the interval prepass of sdf_generate (see sdf_tape_set_prune_info) is on by default; 0 switches it
+ * off for this context (results are identical either way; the environment variable SDF_PRUNE=0
+ * sets the initial state) */
+int sdf_ctx_set_prune(sdf_ctx *ctx, int enabled);
 int sdf_ctx_synchronize(sdf_ctx *ctx);
 
 /* Upload an op tape produced by sdf_amd/tape.py (2 x uint32 per instruction, float64 constants).
  * Plays the role of the reference's closure tree (reference sdf/d3.py:48-63). */
 int sdf_tape_create(sdf_ctx *ctx, const uint32_t *code, uint32_t n_words, const double *consts,
                     uint32_t n_consts, uint32_t n_pslots, uint32_t n_dslots, sdf_tape **out);
+/* Optional: per instruction, where the right operand and the left operand chain of a hard
+ * min / max combine start (0xFFFF: not a combine) -- produced by sdf_amd/tape.py next to the tape.
+ * With it, sdf_generate runs an interval prepass per surviving batch and skips the instructions
+ * that provably cannot influence any sample of that batch (results are unchanged bit for bit). */
+int sdf_tape_set_prune_info(sdf_tape *tape, const uint16_t *rstart, const uint16_t *lstart, uint32_t n_instr);
 int sdf_tape_destroy(sdf_tape *tape);
 
 /* f(P) for N points of dimension dim (2 or 3): replaces SDF3.__call__ / SDF2.__call__
@@ -115,6 +126,11 @@ int sdf_mesh_emit_host(sdf_mesh *mesh, double *h_out);
 int sdf_mesh_emit_stl_host(sdf_mesh *mesh, void *h_out);
 /* per-batch classification, n_batches bytes: 0 skipped, 1 empty, 2 nonempty, 3 other shard */
 int sdf_mesh_kinds(sdf_mesh *mesh, uint8_t *h_out);
+/* diagnostics: what the interval prepass decided, 16 words per batch in batch order like
+ * sdf_mesh_kinds (words 0..7: bit i set = instruction i skipped; 8..15: combine i takes its right
+ * operand; decided for every batch, used by the ones that were meshed).  Fails when the mesh was
+ * generated without the prepass. */
+int sdf_mesh_prune_masks(sdf_mesh *mesh, uint32_t *h_out);
 int sdf_mesh_destroy(sdf_mesh *mesh);
 
 #ifdef __cplusplus

@@ -36,7 +36,7 @@ struct McTables {   // uploaded once per context
 };
 
 struct MeshCounters {   // zeroed before every k_mesh run
-    unsigned long long tri_counter;   // (unused; kept for layout)
+    unsigned long long n_pruned;      // instructions the interval prepass removed, summed over the batches meshed
     unsigned long long n_eval;
     unsigned int work_counter;
     unsigned int overflow;
@@ -69,6 +69,9 @@ struct MeshArgs {
     int list_off;                  // byte offset of the triangle work list in dynamic LDS
     int list_cap;                  // its capacity in entries
     unsigned long long *prof;      // NULL, or 8 phase cycle counters (SDF_MESH_PROF=1 diagnostics)
+    int tape_stride;               // 0: `code` is the model's tape; else `code` holds one pruned tape per BATCH (interval
+                                   // prepass, sdf_prune.h), `tape_stride` 64-bit words apart, the last word = its length
+    int n_instr;                   // instructions of the model's tape (statistics)
 };
 
 // dynamic LDS layout of k_mesh
@@ -244,6 +247,12 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         SDF_PROF(0);
 
         // ---- 1. sample: volume = sdf(P).reshape(shape), cast to float32 (core.py:50-52) ----
+        // (with the interval prepass on, this batch has its own tape with the irrelevant instructions removed)
+        // (`code` stays the base of every address so that the loads remain scalar loads from a read-only
+        // kernel argument; w comes out of LDS, hence the readfirstlane)
+        const uint32_t *wcode = code + (size_t)__builtin_amdgcn_readfirstlane(b) * (size_t)a.tape_stride * 2;
+        if (a.tape_stride && tid == 0)
+            atomicAdd(&a.ctr->n_pruned, (unsigned long long)a.n_instr - reinterpret_cast<const unsigned long long *>(wcode)[a.tape_stride - 1]);
         const int nvox = lx * ly * lz;
         const int lyz = ly * lz;
         const float inv_lyz = 1.0f / (float)lyz, inv_lz = 1.0f / (float)lz;
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 const int ix = fast_div(i, inv_lyz), r = i - ix * lyz, iy = fast_div(r, inv_lz), iz = r - iy * lz;
                 px.v[k] = (T)axes[ix]; py.v[k] = (T)axes[33 + iy]; pz.v[k] = (T)axes[66 + iz];
             }
-            const V val = run_tape<T, FULL, NP, ND, NS>(code, consts, px, py, pz);
+            const V val = run_tape<T, FULL, NP, ND, NS>(wcode, consts, px, py, pz);
             SDF_UNROLL
             for (int k = 0; k < NS; k++) {
                 const int i = i0 + k * BLOCK + tid;

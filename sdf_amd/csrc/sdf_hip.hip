@@ -29,6 +29,7 @@
 #include "../../include/sdf_hip.h"
 #include "mc_table.h"
 #include "sdf_device.h"
+#include "sdf_prune.h"
 
 using namespace sdfk;
 
@@ -60,9 +61,15 @@ __global__ __launch_bounds__(256) void k_eval_grid(const uint32_t *__restrict__ 
 
 // reference sdf/core.py:28-43.  16 lanes per batch: lane 0 = centre, lanes 1..8 = corners in
 // itertools.product((x0,x1),(y0,y1),(z0,z1)) order.  kinds[b] = 0 (skipped) or 255 (pending).
+// Workgroups >= pa.first_block run the interval pass of the same batches instead (sdf_prune.h).
 template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
-                                              int nbatches, unsigned char *__restrict__ kinds) {
+                                              int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa) {
+    extern __shared__ double prune_lds[];
+    if ((int)blockIdx.x >= pa.first_block) {   // (uniform)
+        prune_block(code, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
+        return;
+    }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = gid >> 4, l = gid & 15;
     const bool live = b < nbatches && l < 9;
@@ -312,6 +319,7 @@ struct sdf_ctx {
     DevBuf scratch_in, scratch_out, rows, rows_off, mc;
     int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
+    int prune = 1;                    // SDF_PRUNE=0 switches the interval prepass off (diagnostics)
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
     std::vector<DevBuf> arena_pool;   // soup buffers handed back by destroyed meshes
     std::vector<DevBuf> counter_pool; // 64-byte MeshCounters blocks handed back by destroyed meshes
@@ -326,6 +334,7 @@ struct sdf_tape {
     uint32_t n_words = 0, n_consts = 0;
     bool full = false;
     uint32_t n_p = 0, n_d = 0;
+    uint16_t *d_rstart = nullptr, *d_lstart = nullptr;   // operand ranges of the prunable combines (or NULL)
     unsigned long long hint_key = 0, hint_total_tris = 0;   // arena sizing: last call of this tape
 };
 
@@ -333,7 +342,8 @@ struct sdf_mesh {
     sdf_ctx *ctx = nullptr;
     sdf_stats st = {};
     GridDesc g = {};
-    DevBuf axes, kinds, worklist, status, out;
+    DevBuf axes, kinds, worklist, status, out, prune, tapes;
+    bool pruned = false;
     DevBuf counters;               // this call's MeshCounters block (pooled in the context)
     int work_begin = 0, work_end = 0;
     void *emitted_to = nullptr;    // caller buffer the soup was gathered into by sdf_generate_to_device
@@ -419,6 +429,7 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     HIPCHK(hipMemcpy(c->mc.p, &t, sizeof(t), hipMemcpyHostToDevice));
     if (const char *e = getenv("SDF_MESH_SHAPE")) c->mesh_shape = atoi(e);
     if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
+    if (const char *e = getenv("SDF_PRUNE")) c->prune = atoi(e);
     if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(64)) return 1; }
     *out = c;
     return 0;
@@ -443,6 +454,12 @@ int sdf_ctx_destroy(sdf_ctx *c) {
 int sdf_ctx_set_stream(sdf_ctx *c, void *s) {
     if (!c) return fail("sdf_ctx_set_stream: ctx is NULL");
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+int sdf_ctx_set_prune(sdf_ctx *c, int enabled) {
+    if (!c) return fail("sdf_ctx_set_prune: ctx is NULL");
+    c->prune = enabled ? 1 : 0;
     return 0;
 }
 
@@ -476,6 +493,21 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     return 0;
 }
 
+int sdf_tape_set_prune_info(sdf_tape *t, const uint16_t *rstart, const uint16_t *lstart, uint32_t n_instr) {
+    if (!t || !rstart || !lstart) return fail("sdf_tape_set_prune_info: NULL argument");
+    if (n_instr * 2 != t->n_words) return fail("sdf_tape_set_prune_info: one entry per instruction expected");
+    for (uint32_t i = 0; i < n_instr; i++) {
+        const bool none = rstart[i] == 0xFFFF || lstart[i] == 0xFFFF;
+        if (!none && !(lstart[i] <= rstart[i] && rstart[i] <= i)) return fail("sdf_tape_set_prune_info: operand range out of order");
+    }
+    HIPCHK(hipSetDevice(t->ctx->device));
+    if (!t->d_rstart) HIPCHK(hipMalloc((void **)&t->d_rstart, n_instr * 2));
+    if (!t->d_lstart) HIPCHK(hipMalloc((void **)&t->d_lstart, n_instr * 2));
+    HIPCHK(hipMemcpy(t->d_rstart, rstart, n_instr * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->d_lstart, lstart, n_instr * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int sdf_tape_destroy(sdf_tape *t) {
     if (!t) return 0;
     (void)hipSetDevice(t->ctx->device);
@@ -483,6 +515,8 @@ int sdf_tape_destroy(sdf_tape *t) {
     if (t->d_code) (void)hipFree(t->d_code);
     if (t->d_c64) (void)hipFree(t->d_c64);
     if (t->d_c32) (void)hipFree(t->d_c32);
+    if (t->d_rstart) (void)hipFree(t->d_rstart);
+    if (t->d_lstart) (void)hipFree(t->d_lstart);
     delete t;
     return 0;
 }
@@ -600,7 +634,7 @@ int sdf_marching_cubes_host(sdf_ctx *c, const float *h_vol, int n0, int n1, int 
 
 // k_mesh launch: the register-file variant is the smallest that holds the tape's slots, the
 // shape (threads x samples per lane) a per-precision default found by measurement
-static int launch_mesh(sdf_tape *t, int precision, MeshArgs &a, int grid, int bs) {
+static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a, int grid, int bs) {
     sdf_ctx *c = t->ctx;
     const size_t tile = (size_t)(bs + 1) * (bs + 1) * (bs + 1) * 4;
     const size_t bits_off = (MESH_LDS_VOL + tile + 15) & ~(size_t)15;
@@ -620,11 +654,11 @@ static int launch_mesh(sdf_tape *t, int precision, MeshArgs &a, int grid, int bs
     if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
     int rc;
     if (precision == SDF_PRECISION_F64)
-        rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, grid, lds, c->stream, t->d_code, t->d_c64, a)
-                     : sdf_launch_mesh_f64(slots, shape, grid, lds, c->stream, t->d_code, t->d_c64, a);
+        rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, grid, lds, c->stream, (const uint32_t *)code, t->d_c64, a)
+                     : sdf_launch_mesh_f64(slots, shape, grid, lds, c->stream, (const uint32_t *)code, t->d_c64, a);
     else
-        rc = t->full ? sdf_launch_mesh_f32_full(slots, shape, grid, lds, c->stream, t->d_code, t->d_c32, a)
-                     : sdf_launch_mesh_f32(slots, shape, grid, lds, c->stream, t->d_code, t->d_c32, a);
+        rc = t->full ? sdf_launch_mesh_f32_full(slots, shape, grid, lds, c->stream, (const uint32_t *)code, t->d_c32, a)
+                     : sdf_launch_mesh_f32(slots, shape, grid, lds, c->stream, (const uint32_t *)code, t->d_c32, a);
     if (rc) return fail(std::string("k_mesh launch: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
@@ -663,12 +697,40 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
 
     // ---- prepass: skip test for every batch, then the ordered work list (+ this shard's slice) ----
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    if (sparse) {
-        const unsigned grid = (unsigned)(((long long)nb * 16 + 255) / 256);
-        LAUNCH_TAPE(k_skip, dim3(grid), dim3(256), 0, t, precision, g, nb, (unsigned char *)m->kinds.p);
-    } else {
-        HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
+    // interval pass: per batch, which instructions never matter (float64 sampling only: the intervals
+    // bound the float64 interpreter, not the float32 one).  The box of a batch is spanned by its first
+    // and last coordinate per axis: monotone axes only.
+    auto monotone = [](const double *a, int n) {
+        bool up = true, down = true;
+        for (int i = 1; i < n; i++) { up &= a[i - 1] <= a[i]; down &= a[i - 1] >= a[i]; }
+        return up || down;
+    };
+    const uint32_t n_instr = t->n_words / 2;
+    const bool pruning = c->prune && t->d_rstart && precision == SDF_PRECISION_F64 && n_instr <= 256 &&
+                         monotone(X, nx) && monotone(Y, ny) && monotone(Z, nz);
+    // 64-bit words per batch tape: the instructions, one more END, the length; whole 64-byte lines
+    const int tape_stride = (int)((n_instr + 2 + 7) & ~7u);
+    PruneArgs pa = {};
+    pa.first_block = 0x7fffffff;
+    unsigned skip_blocks = sparse ? (unsigned)(((long long)nb * 16 + 255) / 256) : 0u, prune_blocks = 0;
+    size_t prune_lds = 0;
+    if (pruning) {
+        if (m->prune.ensure((size_t)nb * 64) || m->tapes.ensure((size_t)nb * tape_stride * 8)) return 1;
+        pa.consts = (const double *)t->d_c64; pa.rstart = t->d_rstart; pa.lstart = t->d_lstart;
+        pa.n_instr = (int)n_instr; pa.n_p = std::max(t->n_p, 1u); pa.n_d = std::max(t->n_d, 1u);
+        pa.masks_out = (uint32_t *)m->prune.p; pa.tapes_out = (unsigned long long *)m->tapes.p; pa.tape_stride = tape_stride;
+        pa.first_block = (int)skip_blocks;
+        prune_blocks = (unsigned)(((long long)nb * 8 + PRUNE_BLOCK - 1) / PRUNE_BLOCK);
+        prune_lds = prune_lds_bytes(pa.n_p, pa.n_d);
     }
+    if (skip_blocks + prune_blocks) {
+        if (prune_lds > 32768) {   // (more dynamic LDS than the default limit: tapes with many saved-point slots)
+            const void *fn = t->full ? reinterpret_cast<const void *>(k_skip<double, true>) : reinterpret_cast<const void *>(k_skip<double, false>);
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
+        }
+        LAUNCH_TAPE(k_skip, dim3(skip_blocks + prune_blocks), dim3(256), prune_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
+    }
+    if (!sparse) HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
                        (MeshCounters *)m->counters.p, (unsigned long long *)m->status.p, (long long)shard_index,
                        (long long)shard_count);
@@ -717,10 +779,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
+        a.tape_stride = pruning ? tape_stride : 0;
+        a.n_instr = (int)n_instr;
         if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 64, c->stream));
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         HIPCHK(hipEventRecord(c->ev[3], c->stream));
-        if (launch_mesh(t, precision, a, grid, bs)) return 1;
+        if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs)) return 1;
         HIPCHK(hipEventRecord(c->ev[4], c->stream));
         MeshCounters *hp = (MeshCounters *)((char *)c->h_stage + SDF_STAGE_BYTES - 256);   // pinned
         HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -751,6 +815,9 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     m->st.n_triangles = (int64_t)h.total;
     m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
     m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
+    m->st.n_pruned_instrs = pruning ? (int64_t)h.n_pruned : 0;
+    m->pruned = pruning;
+    m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
     HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
     m->st.ms_prepass = ms;
@@ -863,6 +930,17 @@ int sdf_mesh_kinds(sdf_mesh *m, uint8_t *h_out) {
     return 0;
 }
 
+int sdf_mesh_prune_masks(sdf_mesh *m, uint32_t *h_out) {
+    if (!m || !h_out) return fail("sdf_mesh_prune_masks: NULL argument");
+    if (!m->pruned) return fail("sdf_mesh_prune_masks: this mesh was generated without the interval prepass");
+    const size_t n = (size_t)m->st.n_batches;
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(hipMemcpyAsync(h_out, m->prune.p, n * 64, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
 int sdf_mesh_destroy(sdf_mesh *m) {
     if (!m) return 0;
     sdf_ctx *c = m->ctx;
@@ -875,7 +953,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
         m->out.p = nullptr; m->out.bytes = 0;
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
-    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status}) b->release();
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes}) b->release();
     delete m;
     return 0;
 }

@@ -617,6 +617,7 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
         L_EXTTO_MIX: {  // d2.py:275
             V dd1, tt; DGET(dd1, sb); DGET(tt, sa);
             acc = dd1 + (acc - dd1) * tt; goto next; }
+        L_NOP: goto next;   // (sdf_prune.h: a skipped instruction whose prefixes still have to run)
         L_SLICE_POST: {  // d3.py:515-519
             V A; DGET(A, sa); const V B = -acc;
             acc = vsel(A <= T(0), B, A); goto next; }

@@ -37,7 +37,7 @@ class SdfStats(ctypes.Structure):
         ('n_ambiguous_cells', _c_i64), ('n_work_begin', _c_i64), ('n_work_end', _c_i64),
         ('n_retries', _c_i64),
         ('ms_prepass', ctypes.c_double), ('ms_mesh', ctypes.c_double), ('ms_emit', ctypes.c_double),
-        ('ms_total', ctypes.c_double),
+        ('ms_total', ctypes.c_double), ('n_pruned_instrs', _c_i64), ('n_batch_instrs', _c_i64),
     ]
 
 
@@ -49,9 +49,12 @@ ABI = {
     'sdf_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     'sdf_ctx_destroy': (ctypes.c_int, [_vp]),
     'sdf_ctx_set_stream': (ctypes.c_int, [_vp, _vp]),
+    'sdf_ctx_set_prune': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_synchronize': (ctypes.c_int, [_vp]),
     'sdf_tape_create': (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _f64p, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
+    'sdf_tape_set_prune_info': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16),
+                                               ctypes.c_uint32]),
     'sdf_tape_destroy': (ctypes.c_int, [_vp]),
     'sdf_eval_points': (ctypes.c_int, [_vp, _vp, _c_i64, ctypes.c_int, _vp, ctypes.c_int]),
     'sdf_eval_points_host': (ctypes.c_int, [_vp, _f64p, _c_i64, ctypes.c_int, _f64p, ctypes.c_int]),
@@ -73,6 +76,7 @@ ABI = {
     'sdf_mesh_emit_host': (ctypes.c_int, [_vp, _f64p]),
     'sdf_mesh_emit_stl_host': (ctypes.c_int, [_vp, _vp]),
     'sdf_mesh_kinds': (ctypes.c_int, [_vp, _u8p]),
+    'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
 ABI_VERSION = 1
@@ -130,6 +134,10 @@ class DeviceTape:
                                         _dp(tape.consts, _f64p), len(tape.consts),
                                         tape.n_pslots, tape.n_dslots, ctypes.byref(self.handle)))
         self._fin = weakref.finalize(self, lib.sdf_tape_destroy, self.handle)
+        if tape.rstart is not None and len(tape.rstart) == tape.n_instr:
+            u16p = ctypes.POINTER(ctypes.c_uint16)
+            _check(lib, lib.sdf_tape_set_prune_info(self.handle, _dp(tape.rstart, u16p), _dp(tape.lstart, u16p),
+                                                    tape.n_instr))
 
 
 class Mesh:
@@ -158,6 +166,14 @@ class Mesh:
         n = self.stats()['n_batches']
         out = np.empty(max(n, 1), np.uint8)
         _check(self.engine.lib, self.engine.lib.sdf_mesh_kinds(self.handle, _dp(out, _u8p)))
+        return out[:n]
+
+    def prune_masks(self):
+        """(n_batches, 16) uint32: the interval prepass's skip / forced bits per batch (batch order,
+        like kinds(); only the batches that were meshed used them)"""
+        n = self.stats()['n_batches']
+        out = np.zeros((max(n, 1), 16), np.uint32)
+        _check(self.engine.lib, self.engine.lib.sdf_mesh_prune_masks(self.handle, _dp(out, _u32p)))
         return out[:n]
 
     def points(self):
@@ -202,6 +218,10 @@ class Engine:
 
     def set_stream(self, stream_ptr):
         _check(self.lib, self.lib.sdf_ctx_set_stream(self.ctx, _vp(stream_ptr)))
+
+    def set_prune(self, enabled):
+        """interval prepass of generate on / off (default on; results are identical)"""
+        _check(self.lib, self.lib.sdf_ctx_set_prune(self.ctx, int(bool(enabled))))
 
     def synchronize(self):
         _check(self.lib, self.lib.sdf_ctx_synchronize(self.ctx))

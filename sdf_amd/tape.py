@@ -51,6 +51,7 @@ _MACHINE = (
         'PUSH_D', 'NEG', 'ADDC', 'SUBC', 'MULC', 'SHELL', 'ADD_DS',
         'TRANS_LIN_PRE', 'TRANS_RAD_PRE', 'TRANS_MIX',
         'EXT_PRE', 'EXT_POST', 'EXTTO_PRE', 'EXTTO_MIX', 'SLICE_POST',
+        'NOP',             # only its prefixes act (what the interval prepass leaves of a skipped instruction)
     ])
 OP = {name: i for i, name in enumerate(_MACHINE)}
 OP_NAMES = _MACHINE
@@ -114,6 +115,7 @@ class Tape:
         self.n_pslots = n_pslots
         self.n_dslots = n_dslots
         self.dim = dim
+        self.rstart = self.lstart = None
 
     @property
     def n_instr(self):
@@ -163,6 +165,12 @@ class _Lowering:
         self.pver = 0
         self.next_ver = 1
         self.slot_ver = {}
+        # per instruction: (first instruction of the RIGHT operand, first instruction of the LEFT
+        # operand chain) for instructions that combine two values with a hard min / max -- what the
+        # interval prepass needs to turn "this operand never wins in this batch" into a range of
+        # instructions to skip (csrc/sdf_prune.h)
+        self.meta = []
+        self.chain = []               # stack: index of the first instruction of the enclosing chain
 
     # -- emission helpers --
     def emit(self, op, post='SET', a=0, b=0, consts=(), K=0.0, blob=None):
@@ -174,6 +182,7 @@ class _Lowering:
         assert 0 <= a < 256 and 0 <= b < 256 and off <= COFF_MASK
         self.code.append(OP[op] | (POST[post] << 8) | (a << A_SHIFT))
         self.code.append(off | (b << B_SHIFT))
+        self.meta.append(None)
         if op in _POINT_WRITERS:
             self.pver = self.next_ver
             self.next_ver += 1
@@ -193,6 +202,12 @@ class _Lowering:
         s = self.palloc()
         self.emit('SAVE_P', a=s)
         return s, True
+
+    def note_combine(self, post, rstart):
+        """the instruction just emitted folds a right operand (instructions rstart..here-1) into a
+        left one (instructions chain start..rstart-1) with a hard min / max"""
+        if post in ('UNION', 'DIFF', 'INTER') and rstart is not None and self.chain:
+            self.meta[-1] = (rstart, self.chain[-1])
 
     def palloc(self):
         s = self.pdepth
@@ -228,14 +243,21 @@ class _Lowering:
         return False
 
     # -- lowering --
-    def value(self, obj, dim, post='SET', K=0.0):
-        """emit code that folds obj(p) into acc with `post`; returns True if p is clobbered"""
+    def here(self):
+        return len(self.code) // 2
+
+    def value(self, obj, dim, post='SET', K=0.0, _rs=None):
+        """emit code that folds obj(p) into acc with `post`; returns True if p is clobbered.
+        `_rs`: index of the first instruction that belongs to this operand (default: here)"""
         n = unwrap(obj)
+        if post != 'SET' and _rs is None:
+            _rs = self.here()
         if post != 'SET' and not self.transparent(n):
             s = self.dalloc()
             self.emit('PUSH_D', a=s)
             dirty = self.value(n, dim, 'SET')
             self.emit('COMB', post, a=s, K=K)
+            self.note_combine(post, _rs)
             self.dfree()
             return dirty
         op = n.op
@@ -244,10 +266,11 @@ class _Lowering:
         leaf = 'L_' + op.upper()
         if leaf in OP:
             self.emit(leaf, post, consts=n.params, K=K, blob=(n.meta or {}).get('blob'))
+            self.note_combine(post, _rs)
             return False
         if op in _PURE_TRANSFORMS:
             self.emit(_PURE_TRANSFORMS[op], consts=n.params)
-            self.value(n.children[0], 2 if op == 'revolve' else dim, post, K)
+            self.value(n.children[0], 2 if op == 'revolve' else dim, post, K, _rs=_rs)
             return True
         # everything below runs with post == 'SET'
         if op in _BOOL_POST:
@@ -275,10 +298,13 @@ class _Lowering:
         if op == 'circular_array':
             s = self.palloc()
             self.emit('CIRC_PREP', a=s, consts=n.params)
+            self.chain.append(self.here())
             self.emit('CIRC_SET', a=s, consts=[n.params[0]])
             self.value(n.children[0], dim)
+            rs = self.here()
             self.emit('CIRC_SET', a=s, consts=[0.0])
-            self.value(n.children[0], dim, 'UNION')
+            self.value(n.children[0], dim, 'UNION', _rs=rs)
+            self.chain.pop()
             self.pfree()
             return True
         if op == 'repeat':
@@ -287,9 +313,12 @@ class _Lowering:
             s0, owned = self.save_point()
             s1 = self.palloc()
             self.emit('REP_PREP', a=s1, consts=prm[:8])
+            self.chain.append(self.here())
             for k in range(nn):
+                rs = self.here()
                 self.emit('REP_SET', a=s0, b=s1, consts=list(prm[1:4]) + list(prm[9 + 3 * k: 12 + 3 * k]))
-                self.value(n.children[0], dim, 'SET' if k == 0 else 'UNION')
+                self.value(n.children[0], dim, 'SET' if k == 0 else 'UNION', _rs=rs if k else None)
+            self.chain.pop()
             self.pfree()
             if owned:
                 self.pfree()
@@ -363,6 +392,7 @@ class _Lowering:
         save = any(dirty_flags[:-1])
         sp, owned = None, False
         dirty = False
+        self.chain.append(self.here())
         for i, c in enumerate(kids):
             if save and sp is None and dirty_flags[i] and i < len(kids) - 1:
                 sp, owned = self.save_point()
@@ -379,12 +409,13 @@ class _Lowering:
                     dirty = self.value(c, dim, kinds[0])
                 else:
                     dirty = self.value(c, dim, kinds[1], float(K))
+        self.chain.pop()
         if owned:
             self.pfree()
         return dirty
 
 
-def peephole(code):
+def peephole(code, meta=None):
     """dispatch-count reduction on a lowered tape (list of u32 words, 2 per instruction); the
     arithmetic per sample is unchanged, so results stay bit-identical:
 
@@ -393,7 +424,7 @@ def peephole(code):
     * LOAD_P / SAVE_P / PUSH_D are folded into the NEXT instruction as its RL / SV / PD prefixes
       whenever the fixed prefix order (RL, SV, PD, then the op) reproduces the original order.
     """
-    ins = [[int(code[i]), int(code[i + 1])] for i in range(0, len(code), 2)]
+    ins = [[int(code[i]), int(code[i + 1]), i // 2] for i in range(0, len(code), 2)]   # + original index
     op = lambda w: w & 255
     sa = lambda w: w >> A_SHIFT
     # 1. duplicate saves.  Slots written by SAVE_P are read by LOAD_P (a) and REP_SET (a).
@@ -402,13 +433,13 @@ def peephole(code):
 
     def dedupe(ins):
         out, alias = [], {}
-        for k, (w0, w1) in enumerate(ins):
+        for k, (w0, w1, orig) in enumerate(ins):
             o, s = op(w0), sa(w0)
             if o in writers:
                 for bslot in [x for x, tgt in alias.items() if tgt == s]:
                     # slot s is rewritten: an alias to it may only be dropped if it is dead, i.e.
                     # not read again before it is written again
-                    for v0, _ in ins[k + 1:]:
+                    for v0, _, _ in ins[k + 1:]:
                         if sa(v0) == bslot and op(v0) in readers:
                             return None
                         if sa(v0) == bslot and op(v0) in writers:
@@ -420,7 +451,7 @@ def peephole(code):
                     continue
             elif o in readers and s in alias:
                 w0 = (w0 & ~(255 << A_SHIFT)) | (alias[s] << A_SHIFT)
-            out.append([w0, w1])
+            out.append([w0, w1, orig])
         return out
 
     ins = dedupe(ins) or ins
@@ -435,7 +466,7 @@ def peephole(code):
         rl = sv = pd = None
         pending_src = []
 
-    for w0, w1 in ins:
+    for w0, w1, orig in ins:
         o, s = op(w0), sa(w0)
         if s < 8 and not (w0 & PREFIX_MASK):
             if o == OP['LOAD_P']:
@@ -444,19 +475,19 @@ def peephole(code):
                 elif rl is not None:
                     pending_src = [x for x in pending_src if op(x[0]) != OP['LOAD_P']]   # first reload is dead
                 rl = s
-                pending_src.append([w0, w1])
+                pending_src.append([w0, w1, orig])
                 continue
             if o == OP['SAVE_P']:
                 if sv is not None:
                     flush_standalone()
                 sv = s
-                pending_src.append([w0, w1])
+                pending_src.append([w0, w1, orig])
                 continue
             if o == OP['PUSH_D']:
                 if pd is not None:
                     flush_standalone()
                 pd = s
-                pending_src.append([w0, w1])
+                pending_src.append([w0, w1, orig])
                 continue
         if pending_src:
             if o == OP['END']:
@@ -470,8 +501,19 @@ def peephole(code):
                     w0 |= PD_FLAG | (pd << PD_SHIFT)
                 rl = sv = pd = None
                 pending_src = []
-        out.append([w0, w1])
-    return [w for pair in out for w in pair]
+        out.append([w0, w1, orig])
+    new_code = [w for w0, w1, _ in out for w in (w0, w1)]
+    if meta is None:
+        return new_code
+    # carry the combine ranges over: an old index maps to the first kept instruction at or after it
+    import bisect
+    origs = [o for _, _, o in out]
+    remap = lambda old: bisect.bisect_left(origs, old)
+    new_meta = []
+    for _, _, o in out:
+        m = meta[o]
+        new_meta.append(None if m is None else (remap(m[0]), remap(m[1])))
+    return new_code, new_meta
 
 
 # which instruction fields name PS / DS slots (for the slot census after the peephole pass)
@@ -511,7 +553,12 @@ def lower(obj, dim=None):
     lw.value(root, dim)
     lw.emit('END')
     assert lw.pdepth == 0 and lw.ddepth == 0
-    code = peephole(lw.code)
+    code, meta = peephole(lw.code, lw.meta)
     n_p, n_d = slot_census(code)          # the peephole pass can leave slots unused
     assert n_p <= lw.pmax and n_d <= lw.dmax
-    return Tape(np.array(code, dtype=np.uint32), np.frombuffer(lw.consts, dtype=np.float64).copy(), n_p, n_d, dim)
+    t = Tape(np.array(code, dtype=np.uint32), np.frombuffer(lw.consts, dtype=np.float64).copy(), n_p, n_d, dim)
+    # per instruction: first instruction of the right operand / of the left chain (0xFFFF: not a
+    # prunable combine) -- input of the interval prepass
+    t.rstart = np.array([0xFFFF if m is None else m[0] for m in meta], dtype=np.uint16)
+    t.lstart = np.array([0xFFFF if m is None else m[1] for m in meta], dtype=np.uint16)
+    return t

@@ -447,3 +447,82 @@ def test_text_leaf_runs_on_device(ns, eng, oracle_lib):
     assert w == 4.0 and 0 < h < 4.0
     pts = g.generate(samples=2 ** 18, verbose=False)
     assert len(pts) > 3000 and np.isfinite(pts).all()
+
+
+# ---- interval prepass (csrc/sdf_prune.h): pruned execution must not change a single bit ----
+
+def _random_csg(rng, ns, depth=0):
+    """a random tree of the operations that have an interval form, plus a few that do not"""
+    r = lambda lo, hi: float(rng.uniform(lo, hi))
+    v3 = lambda s: tuple(float(t) for t in rng.uniform(-s, s, 3))
+    if depth >= 3 or (depth > 0 and rng.random() < 0.3):
+        k = int(rng.integers(0, 10))
+        if k == 0: f = ns['sphere'](r(0.2, 0.7), v3(0.6))
+        elif k == 1: f = ns['box']((r(0.2, 0.9), r(0.2, 0.9), r(0.2, 0.9)), v3(0.5))
+        elif k == 2: f = ns['rounded_box']((r(0.4, 1.0), r(0.4, 1.0), r(0.4, 1.0)), r(0.02, 0.15))
+        elif k == 3: f = ns['torus'](r(0.4, 0.8), r(0.05, 0.2))
+        elif k == 4: f = ns['capsule'](v3(0.7), v3(0.7), r(0.05, 0.3))
+        elif k == 5: f = ns['cylinder'](r(0.1, 0.5))
+        elif k == 6: f = ns['plane'](v3(1.0), v3(0.3))
+        elif k == 7: f = ns['octahedron'](r(0.3, 0.9))
+        elif k == 8: f = ns['rectangle']((r(0.2, 0.8), r(0.2, 0.8)), (r(-0.3, 0.3), r(-0.3, 0.3))).extrude(r(0.2, 1.0))
+        else: f = ns['capped_cylinder'](v3(0.6), v3(0.6), r(0.1, 0.3))
+        t = int(rng.integers(0, 6))
+        if t == 0: f = f.translate(v3(0.6))
+        elif t == 1: f = f.rotate(r(0, 3.0), v3(1.0))
+        elif t == 2: f = f.scale(r(0.5, 1.5))
+        elif t == 3: f = f.orient(v3(1.0))
+        elif t == 4: f = f.translate(v3(0.4)).rotate(r(0, 3.0), v3(1.0))
+        return f
+    kids = [_random_csg(rng, ns, depth + 1) for _ in range(int(rng.integers(2, 5)))]
+    op = ns['union' if depth == 0 else ('union', 'union', 'difference', 'difference', 'intersection')[int(rng.integers(0, 5))]]
+    k = None if rng.random() < 0.75 else r(0.05, 0.3)
+    f = op(*kids, k=k) if k is not None else op(*kids)
+    m = int(rng.integers(0, 8))
+    if m == 0: f = f.negate() if depth else f
+    elif m == 1: f = f.dilate(r(0.01, 0.1))
+    elif m == 2: f = f.shell(r(0.02, 0.1))
+    elif m == 3: f = f.translate(v3(0.3))
+    elif m == 4: f = f.rotate(r(0, 3.0), v3(1.0))
+    return f
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_pruned_generate_is_bit_identical_random_csg(seed, ns, oracle_lib, eng):
+    rng = np.random.default_rng(1000 + seed)
+    f = _random_csg(rng, ns)
+    n = 97 + 7 * (seed % 3)
+    X = np.arange(-1.6, 1.6, 3.2 / n); Y = np.arange(-1.5, 1.5, 3.0 / n); Z = np.arange(-1.4, 1.4, 2.8 / n)
+    sparse = seed % 2 == 0          # dense: every batch is sampled, i.e. goes through the prepass
+    res = []
+    for on in (True, False):
+        eng.set_prune(on)
+        try:
+            m = eng.generate(f, X, Y, Z, 32, sparse)
+            res.append((m.points(), m.kinds(), m.stats()))
+            m.close()
+        finally:
+            eng.set_prune(True)
+    (p1, k1, s1), (p0, k0, s0) = res
+    assert s0['n_pruned_instrs'] == 0
+    assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
+    o = oracle_lib.generate(f, X, Y, Z, 32, sparse)
+    assert np.array_equal(k1, o.kinds) and np.array_equal(p1, o.points)
+
+
+def test_prepass_prunes_the_canonical_example(ns, eng):
+    """most batches of the canonical CSG example are decided by part of the tree"""
+    f = fixtures.build('ex_example', ns)
+    A = np.arange(-1.2, 1.2, 2.4 / 256)
+    m = eng.generate(f, A, A, A, 32, True)
+    st = m.stats(); p1 = m.points(); kinds = m.kinds(); m_masks = m.prune_masks(); m.close()
+    assert st['n_batch_instrs'] > 0 and st['n_pruned_instrs'] > 0.05 * st['n_batch_instrs']
+    masks = m_masks[np.isin(kinds, (1, 2))]
+    assert masks.shape == (st['empty'] + st['nonempty'], 16) and (masks[:, :8] != 0).any()
+    eng.set_prune(False)
+    try:
+        m = eng.generate(f, A, A, A, 32, True)
+        p0 = m.points(); assert m.stats()['n_pruned_instrs'] == 0; m.close()
+    finally:
+        eng.set_prune(True)
+    assert np.array_equal(p1, p0)
