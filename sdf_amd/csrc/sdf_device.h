@@ -72,10 +72,13 @@ struct MeshArgs {
     int tape_stride;               // 0: `code` is the model's tape; else `code` holds one pruned tape per BATCH (interval
                                    // prepass, sdf_prune.h), `tape_stride` 64-bit words apart, the last word = its length
     int n_instr;                   // instructions of the model's tape (statistics)
+    float *park;                   // staging: one slot of park_cap triangles (9 floats each) per workgroup, or NULL
+    int park_cap;
+    unsigned park_spins;           // polls of the predecessors' counts before a batch is parked
 };
 
 // dynamic LDS layout of k_mesh
-enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_VOL = 1184 };
+enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_PEND = 1184, MESH_LDS_VOL = 1248 };
 
 __device__ __forceinline__ void batch_origin(const GridDesc &g, int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {
     // itertools.product(Xs, Ys, Zs): Z fastest (reference sdf/core.py:119)
@@ -152,7 +155,13 @@ __device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0
 // taken from the counter in order, so every predecessor is held by a RUNNING workgroup: the walk
 // never waits on a workgroup that is itself waiting for a CU.  Words are exchanged with agent-scope
 // atomics (per-CU L1 and per-XCD L2 are not coherent for plain accesses); every spin is bounded.
-// Called by wave 0 of the workgroup (all 64 lanes); returns the exclusive prefix, or ~0 on timeout.
+// Called by wave 0 of the workgroup (all 64 lanes).
+//
+// A workgroup whose predecessors are still sampling does not wait for them: it writes the batch's
+// triangles in compact form (9 floats each) into its own staging slot ("parks" the batch), goes on
+// with the next batch, and moves the parked triangles to their place once that batch is sampled
+// too (k_mesh).  Only the aggregate has to be published early; the walk can happen any time later.
+#define MESH_NOT_READY (~0ull - 1ull)
 #define MESH_FLAG_AGG (1ull << 62)
 #define MESH_FLAG_PFX (2ull << 62)
 #define MESH_VAL_MASK ((1ull << 62) - 1)
@@ -164,34 +173,50 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     }
     return v;
 }
-__device__ __forceinline__ unsigned long long ordered_base(unsigned long long *status, int w, int w_begin, unsigned long long total) {
+__device__ __forceinline__ void publish_count(unsigned long long *status, int w, int w_begin, unsigned long long total) {
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_store(&status[w], (w == w_begin ? MESH_FLAG_PFX : MESH_FLAG_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// this lane's word of the first look-back window of work item w (the 64 items in front of it).  The
+// caller issues it EARLY -- before the cell counting, whose work then hides the round trip to the
+// device-coherent level -- and hands it to ordered_base afterwards.
+__device__ __forceinline__ unsigned long long lookback_prefetch(const unsigned long long *status, int w, int w_begin) {
+    const int j = w - 1 - (int)(threadIdx.x & 63);
+    return j >= w_begin ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : MESH_FLAG_PFX;
+}
+// the exclusive prefix of work item w; ~0 on timeout; with max_spins small: MESH_NOT_READY when a
+// predecessor has not published its count yet.  `first` = lookback_prefetch(w), possibly stale
+// (a stale word can only say "not ready yet").
+__device__ __forceinline__ unsigned long long ordered_base(unsigned long long *status, int w, int w_begin, unsigned long long total,
+                                                           unsigned max_spins, unsigned long long first) {
     const int lane = threadIdx.x & 63;
-    if (w == w_begin) {
-        if (lane == 0) __hip_atomic_store(&status[w], MESH_FLAG_PFX | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    if (lane == 0) __hip_atomic_store(&status[w], MESH_FLAG_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == w_begin) return 0;
     unsigned long long excl = 0;
     int idx = w - 1;
-    for (unsigned spins = 0; spins < (1u << 24); spins++) {
+    bool use_first = true;
+    for (unsigned spins = 0; spins < max_spins;) {   // (only waiting counts as a spin, walking back does not)
         const int j = idx - lane;
-        const unsigned long long sw = j >= w_begin ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                   : MESH_FLAG_PFX;   // in front of the shard: prefix 0
+        unsigned long long sw = first;
+        if (!use_first)
+            sw = j >= w_begin ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : MESH_FLAG_PFX;   // in front of the shard: prefix 0
+        use_first = false;
         const unsigned flag = (unsigned)(sw >> 62);
         const unsigned long long pending = __ballot(flag == 0), is_pfx = __ballot(flag == 2);
         if (is_pfx) {
             const int p = __ffsll((long long)is_pfx) - 1;                 // nearest predecessor with a prefix
-            if (pending & ((1ull << p) - 1ull)) { __builtin_amdgcn_s_sleep(1); continue; }
+            if (pending & ((1ull << p) - 1ull)) { __builtin_amdgcn_s_sleep(1); spins++; continue; }
             excl += wave_sum_u64(lane <= p ? (sw & MESH_VAL_MASK) : 0ull);
             if (lane == 0) __hip_atomic_store(&status[w], MESH_FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return excl;
         }
-        if (pending) { __builtin_amdgcn_s_sleep(1); continue; }
+        if (pending) { __builtin_amdgcn_s_sleep(1); spins++; continue; }
         excl += wave_sum_u64(sw & MESH_VAL_MASK);
         idx -= 64;
     }
-    return ~0ull;
+    return max_spins < (1u << 24) ? MESH_NOT_READY : ~0ull;
 }
+#define MESH_SPIN_FOREVER (1u << 24)   // (bounded all the same: a timeout is reported as an error)
 
 // triangle j of an ambiguous cell: re-runs the selection (cheaper than carrying the tiling through
 // the LDS work list for the few cells concerned), applies skimage's face flip for
@@ -232,6 +257,46 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
     long long tprev = a.prof ? clock64() : 0;
 #define SDF_PROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
+    // position-dependent bookkeeping of work item w_ (thread 0)
+    auto settle = [&](int w_, unsigned long long excl, unsigned long long total_) {
+        if (excl == ~0ull) atomicOr(&a.ctr->overflow, 2u);           // look-back timed out (never expected)
+        else if (excl + total_ > a.out_cap) atomicOr(&a.ctr->overflow, 1u);
+        if (w_ == work_end - 1 && excl != ~0ull) a.ctr->total = excl + total_;
+    };
+    // the parked batch of this workgroup (all values workgroup-uniform)
+    float *my_park = a.park ? a.park + (size_t)blockIdx.x * (size_t)a.park_cap * 9 : nullptr;
+    int pend_w = -1, pend_total = 0;
+    double *pend_xf = reinterpret_cast<double *>(smem + MESH_LDS_PEND);   // its offset[3], scale[3]
+    auto place_parked = [&](unsigned long long pre_pend) {
+        if (pend_w < 0) return;
+        if (tid < 64) {
+            const unsigned long long excl = ordered_base(a.status, pend_w, work_begin, (unsigned long long)pend_total, MESH_SPIN_FOREVER, pre_pend);
+            if (tid == 0) {
+                settle(pend_w, excl, (unsigned long long)pend_total);
+                reinterpret_cast<unsigned long long *>(bcast + 4)[0] = excl;
+            }
+        }
+        __syncthreads();
+        const unsigned long long pbase = reinterpret_cast<unsigned long long *>(bcast + 4)[0];
+        if (pbase != ~0ull && pbase + (unsigned long long)pend_total <= a.out_cap) {
+            double *dst0 = a.out + pbase * 9ull;
+            const double pof0 = pend_xf[0], pof1 = pend_xf[1], pof2 = pend_xf[2], psc0 = pend_xf[3], psc1 = pend_xf[4], psc2 = pend_xf[5];
+            // 12 coordinates (four points) per thread and pass: three 16-byte loads in flight, then the
+            // stores; coordinate e belongs to axis e % 3
+            const int n9 = pend_total * 9, nchunk = n9 / 12;
+            const double sc[3] = {psc0, psc1, psc2}, of[3] = {pof0, pof1, pof2};
+            for (int ch = tid; ch < nchunk; ch += BLOCK) {
+                const float4 *src = reinterpret_cast<const float4 *>(my_park) + (size_t)ch * 3;
+                const float4 v0 = src[0], v1 = src[1], v2 = src[2];
+                const float f[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+                double *d = dst0 + (size_t)ch * 12;
+                SDF_UNROLL for (int q = 0; q < 12; q++) d[q] = (double)f[q] * sc[q % 3] + of[q % 3];
+            }
+            for (int e = nchunk * 12 + tid; e < n9; e += BLOCK) dst0[e] = (double)my_park[e] * sc[e % 3] + of[e % 3];
+        }
+        pend_w = -1;
+        __syncthreads();   // (bcast is reused)
+    };
     for (;;) {
         if (tid == 0) bcast[0] = work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
         __syncthreads();
@@ -281,6 +346,13 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         SDF_PROF(1);
 
         // ---- 2. count: a thread owns the i2-rows of cells (i0, i1) = row tid + k * BLOCK ----
+        // (wave 0 first asks for the predecessors' status words -- of this batch and of the parked one --
+        // so that the answers arrive while the cells are counted)
+        unsigned long long pre_own = 0, pre_pend = 0;
+        if (tid < 64) {
+            pre_own = lookback_prefetch(a.status, w, work_begin);
+            if (pend_w >= 0) pre_pend = lookback_prefetch(a.status, pend_w, work_begin);
+        }
         const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
         const int nrows = (c0 > 0 && c1 > 0 && c2 > 0) ? c0 * c1 : 0;
         const float inv_c1 = 1.0f / (float)max(c1, 1);
@@ -329,23 +401,41 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             row_off[k] = total + block_exclusive_scan<BLOCK>(n, wave_sums, tot);
             total += tot;
         }
-        // ---- ordered allocation (wave 0), then the per-batch bookkeeping ----
+        // ---- the batch's count is public from here on; bookkeeping that needs no position ----
+        if (tid < 64) publish_count(a.status, w, work_begin, (unsigned long long)total);
+        if (tid == 0) {
+            atomicAdd(total ? &a.ctr->n_nonempty : &a.ctr->n_empty, 1u);
+            atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
+            a.kinds[b] = total ? 2 : 1;
+        }
+        if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
+        // ---- a parked batch is older than this one: its predecessors have long published, place it ----
+        { const long long tp0 = a.prof ? clock64() : 0;
+        place_parked(pre_pend);
+        if (a.prof && tid == 0) atomicAdd(&a.prof[6], (unsigned long long)(clock64() - tp0)); }
+        // ---- ordered allocation (wave 0): take the position if every predecessor has published its
+        // count, else park this batch instead of waiting for them ----
+        const bool may_park = a.park && total <= a.park_cap;
         if (tid < 64) {
-            const unsigned long long excl = ordered_base(a.status, w, work_begin, (unsigned long long)total);
+            const unsigned long long excl = ordered_base(a.status, w, work_begin, (unsigned long long)total, may_park ? a.park_spins : MESH_SPIN_FOREVER, pre_own);
             if (tid == 0) {
-                if (excl == ~0ull) atomicOr(&a.ctr->overflow, 2u);           // look-back timed out (never expected)
-                else if (excl + (unsigned long long)total > a.out_cap) atomicOr(&a.ctr->overflow, 1u);
-                atomicAdd(total ? &a.ctr->n_nonempty : &a.ctr->n_empty, 1u);
-                atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
-                if (w == work_end - 1 && excl != ~0ull) a.ctr->total = excl + (unsigned long long)total;
-                a.kinds[b] = total ? 2 : 1;
+                if (excl != MESH_NOT_READY) settle(w, excl, (unsigned long long)total);
                 reinterpret_cast<unsigned long long *>(bcast + 2)[0] = excl;
             }
         }
-        if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
         __syncthreads();
         const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
-        const bool fits = base != ~0ull && base + (unsigned long long)total <= a.out_cap;
+        const bool parking = base == MESH_NOT_READY;
+        const bool fits = parking || (base != ~0ull && base + (unsigned long long)total <= a.out_cap);
+        // points * scale + offset (reference sdf/core.py:58-60): scale = first axis step of the
+        // batch, offset = its first sample, per axis
+        const double of0 = axes[0], of1 = axes[33], of2 = axes[66];
+        const double sc0 = axes[1] - of0, sc1 = axes[34] - of1, sc2 = axes[67] - of2;
+        if (parking) {
+            pend_w = w; pend_total = total;
+            if (tid == 0) { pend_xf[0] = of0; pend_xf[1] = of1; pend_xf[2] = of2; pend_xf[3] = sc0; pend_xf[4] = sc1; pend_xf[5] = sc2; }
+            if (a.prof && tid == 0) atomicAdd(&a.prof[7], 1ull);
+        }
         SDF_PROF(2);
 
         // ---- 3 + 4. per-triangle work list in LDS, then one lane per triangle ----
@@ -379,11 +469,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
             __syncthreads();
             SDF_PROF(3);
-            double *dst0 = a.out + (base + (unsigned long long)lo) * 9ull;
-            // points * scale + offset (reference sdf/core.py:58-60): scale = first axis step of the
-            // batch, offset = its first sample, per axis
-            const double of0 = axes[0], of1 = axes[33], of2 = axes[66];
-            const double sc0 = axes[1] - of0, sc1 = axes[34] - of1, sc2 = axes[67] - of2;
+            double *dst0 = a.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
+            float *park0 = my_park + (size_t)lo * 9;
             for (int t = tid; t < cn; t += BLOCK) {
                 const unsigned e = list[t];
                 const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
@@ -398,12 +485,17 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     mc_vertex(corner, lyz, lz, i0, i1, i2, tt[1], o + 3);
                     mc_vertex(corner, lyz, lz, i0, i1, i2, tt[2], o + 6);
                 }
-                double *dst = dst0 + (size_t)t * 9;
-                SDF_UNROLL
-                for (int q = 0; q < 9; q += 3) {
-                    dst[q] = (double)o[q] * sc0 + of0;
-                    dst[q + 1] = (double)o[q + 1] * sc1 + of1;
-                    dst[q + 2] = (double)o[q + 2] * sc2 + of2;
+                if (parking) {
+                    float *dst = park0 + (size_t)t * 9;
+                    SDF_UNROLL for (int q = 0; q < 9; q++) dst[q] = o[q];
+                } else {
+                    double *dst = dst0 + (size_t)t * 9;
+                    SDF_UNROLL
+                    for (int q = 0; q < 9; q += 3) {
+                        dst[q] = (double)o[q] * sc0 + of0;
+                        dst[q + 1] = (double)o[q + 1] * sc1 + of1;
+                        dst[q + 2] = (double)o[q + 2] * sc2 + of2;
+                    }
                 }
             }
             __syncthreads();   // list / vol are reused
@@ -411,6 +503,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         }
         __syncthreads();   // vol / bcast are reused by the next batch
     }
+    place_parked(pend_w >= 0 && tid < 64 ? lookback_prefetch(a.status, pend_w, work_begin) : 0ull);
     SDF_PROF(5);
 #undef SDF_PROF
 }

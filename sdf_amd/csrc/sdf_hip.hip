@@ -309,6 +309,7 @@ struct DevBuf {
 };
 
 #define SDF_STAGE_BYTES (1u << 20)
+#define SDF_PARK_TRIS 8192   // triangles per workgroup staging slot of k_mesh (36 bytes each); larger batches wait instead
 
 struct sdf_ctx {
     int device = 0;
@@ -320,6 +321,9 @@ struct sdf_ctx {
     int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int prune = 1;                    // SDF_PRUNE=0 switches the interval prepass off (diagnostics)
+    int parking = 1;                  // SDF_PARK=0: k_mesh waits for its predecessors instead of parking a batch (diagnostics)
+    int park_spins = 1;               // SDF_PARK_SPINS: polls before parking (tuning; measured: waiting never pays)
+    DevBuf park;                      // k_mesh's staging slots, one per CU (allocated by the first sdf_generate)
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
     std::vector<DevBuf> arena_pool;   // soup buffers handed back by destroyed meshes
     std::vector<DevBuf> counter_pool; // 64-byte MeshCounters blocks handed back by destroyed meshes
@@ -430,6 +434,8 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     if (const char *e = getenv("SDF_MESH_SHAPE")) c->mesh_shape = atoi(e);
     if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
     if (const char *e = getenv("SDF_PRUNE")) c->prune = atoi(e);
+    if (const char *e = getenv("SDF_PARK")) c->parking = atoi(e);
+    if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
     if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(64)) return 1; }
     *out = c;
     return 0;
@@ -439,7 +445,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof})
+    for (DevBuf *b : {&c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof, &c->park})
         b->release();
     for (auto &b : c->arena_pool) b.release();
     for (auto &b : c->counter_pool) b.release();
@@ -779,6 +785,9 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
+        if (c->parking && !c->park.p && c->park.ensure((size_t)c->n_cu * SDF_PARK_TRIS * 36)) return 1;
+        a.park = c->parking ? (float *)c->park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
+        a.park_spins = (unsigned)c->park_spins;
         a.tape_stride = pruning ? tape_stride : 0;
         a.n_instr = (int)n_instr;
         if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 64, c->stream));
@@ -795,8 +804,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (c->prof.p) {
             unsigned long long pc[8];
             HIPCHK(hipMemcpy(pc, c->prof.p, 64, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu list %llu emit %llu tail %llu\n",
-                    ms, pc[0], pc[1], pc[2], pc[3], pc[4], pc[5]);
+            fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked\n",
+                    ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7]);
         }
         m->st.n_retries = attempt;
         if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
