@@ -51,6 +51,8 @@ typedef struct sdf_stats {
     double ms_total;            /* first launch to last kernel of sdf_generate             */
     int64_t n_pruned_instrs;    /* tape instructions the interval prepass removed, summed over the shard's batches */
     int64_t n_batch_instrs;     /* (instructions per tape) x (batches of the shard): the total they come out of    */
+    int64_t n_sampled_voxels;   /* of n_eval_voxels, the samples that went through the interpreter (the rest lie in
+                                 * cell groups whose interval excludes the surface; in lots of 64)                 */
 } sdf_stats;
 
 int sdf_abi_version(void);
@@ -65,6 +67,10 @@ int sdf_ctx_set_stream(sdf_ctx *ctx, void *hip_stream);
  * off for this context (results are identical either way; the environment variable SDF_PRUNE=0
  * sets the initial state) */
 int sdf_ctx_set_prune(sdf_ctx *ctx, int enabled);
+/* the same for the second interval pass of sdf_generate: inside a batch, groups of 4^3 cells whose
+ * interval excludes the surface are not sampled (SDF_CULL=0 sets the initial state; results are
+ * identical either way) */
+int sdf_ctx_set_cull(sdf_ctx *ctx, int enabled);
 int sdf_ctx_synchronize(sdf_ctx *ctx);
 
 /* Upload an op tape produced by sdf_amd/tape.py (2 x uint32 per instruction, float64 constants).

@@ -25,6 +25,7 @@
 
 #include "sdf_interp.h"
 #include "sdf_mc33.h"
+#include "sdf_interval.h"
 
 namespace sdfk {
 
@@ -42,12 +43,13 @@ struct MeshCounters {   // zeroed before every k_mesh run
     unsigned int overflow;
     unsigned int n_empty, n_nonempty;
     unsigned long long n_ambiguous;
+    unsigned long long n_sampled;     // samples that went through the interpreter (the others were decided by intervals)
     unsigned long long total;         // triangles of this shard (written by the workgroup of the last work item)
     // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
     // and this shard's slice of it, so k_mesh can start without a host round trip
     int nwork, work_begin, work_end, pad_;
 };
-enum { MESH_COUNTERS_RESET_BYTES = 48 };   // the part of MeshCounters cleared before every k_mesh run
+enum { MESH_COUNTERS_RESET_BYTES = 56 };   // the part of MeshCounters cleared before every k_mesh run
 
 struct GridDesc {
     const double *X, *Y, *Z;   // device copies of the np.arange axes
@@ -75,6 +77,7 @@ struct MeshArgs {
     float *park;                   // staging: one slot of park_cap triangles (9 floats each) per workgroup, or NULL
     int park_cap;
     unsigned park_spins;           // polls of the predecessors' counts before a batch is parked
+    const unsigned char *cull;     // NULL, or k_cull's records: per work item, the sampling tasks to evaluate (cull_tasks)
 };
 
 // dynamic LDS layout of k_mesh
@@ -236,6 +239,156 @@ __device__ __noinline__ void mc33_triangle(const float *corner, int s0, int s1, 
     }
 }
 
+// ---- sampling tasks --------------------------------------------------------------------------
+// The samples of a tile are evaluated in TASKS of 64 (one per wave and sample slot).  A full 33^3
+// tile is cut into the 8^3 cubes of 4^3 samples plus its three far faces (563 tasks, dense); any
+// other tile into runs of 64 consecutive samples.  Cubes keep a task's samples close together in all
+// three directions, which is what lets whole tasks drop out in cull_tasks.
+struct TileTasks {
+    int lx, ly, lz, lyz, nvox;
+    float inv_lyz, inv_lz;
+    bool regular;
+    int ntask;
+    __device__ __forceinline__ TileTasks(int lx_, int ly_, int lz_) : lx(lx_), ly(ly_), lz(lz_) {
+        lyz = ly * lz; nvox = lx * lyz;
+        inv_lyz = 1.0f / (float)lyz; inv_lz = 1.0f / (float)lz;
+        regular = lx == 33 && ly == 33 && lz == 33;
+        ntask = regular ? 563 : (nvox + 63) >> 6;
+    }
+    // sample `lane` of a task; false: the task has no such sample (ix, iy, iz are valid indices all the same)
+    __device__ __forceinline__ bool sample(int task, int lane, int &ix, int &iy, int &iz) const {
+        if (!regular) {
+            const int i = min(task * 64 + lane, nvox - 1);
+            ix = fast_div(i, inv_lyz); const int r = i - ix * lyz; iy = fast_div(r, inv_lz); iz = r - iy * lz;
+            return task * 64 + lane < nvox;
+        }
+        if (task < 512) { ix = 4 * (task >> 6) + (lane >> 4); iy = 4 * ((task >> 3) & 7) + ((lane >> 2) & 3); iz = 4 * (task & 7) + (lane & 3); return true; }
+        if (task < 530) { const int p = min((task - 512) * 64 + lane, 1088); ix = 32; iy = fast_div(p, 1.0f / 33.0f); iz = p - 33 * iy; return (task - 512) * 64 + lane < 1089; }
+        if (task < 547) { const int p = min((task - 530) * 64 + lane, 1055); iy = 32; ix = fast_div(p, 1.0f / 33.0f); iz = p - 33 * ix; return (task - 530) * 64 + lane < 1056; }
+        const int p = (task - 547) * 64 + lane; iz = 32; ix = p >> 5; iy = p & 31; return true;
+    }
+};
+
+// Where can the surface not be?  The cells of the tile are taken in groups of 4^3; one thread runs
+// the tape in interval arithmetic (sdf_interval.h) over the box of a group's samples.  A group whose
+// interval excludes zero has no surface cell and its samples only matter by their sign: a sample is
+// evaluated iff it belongs to a group that could not be decided (a sample belongs to up to 8 groups:
+// along an axis, cell groups (i - 1) / 4 and i / 4).  Results are the same bit for bit: marching
+// cubes reads values only at the corners of cells with a sign change, and every such cell lies in an
+// undecided group.  (Two decided neighbours share a face of samples, so they cannot carry opposite
+// signs.)  The bound 1e-30 keeps the sign through the cast to float32.
+//
+// Writes the list of tasks to evaluate to tlist and +-1 to the samples of decided groups; returns
+// the number of listed tasks, or -1 when the tile is not culled (degenerate tile, or the interval
+// state of the tape does not fit in LDS).  Listing more tasks than necessary is harmless, missing one
+// is not.  This is the body of k_cull (sdf_hip.hip), a kernel of its own in front of k_mesh: inside
+// k_mesh the interval pass would run on half the waves of a workgroup that holds a whole CU, and its
+// registers would compete with the interpreter's.
+// scratch: u16 task count, tlist (u16 each), CULL_GSTATE: group states | from CULL_COUNT + 16: the states
+// of the 8^3-cell boxes (64 bytes) and the list of groups to evaluate (512 u16)
+enum { CULL_GSTATE = 1152, CULL_COUNT = 1664, CULL_RECORD = 1664, CULL_SCRATCH = 2816 };   // a batch's record in global memory: bytes [0, CULL_RECORD)
+template <int BLOCK>
+__device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *consts, int n_instr_w, int lx, int ly, int lz,
+                                       const double *axes, double *ia_state, int ia_bytes, unsigned char *scratch, int *wave_sums,
+                                       int ia_np, int ia_nd) {
+    const int tid = threadIdx.x;
+    const TileTasks tt(lx, ly, lz);
+    const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
+    const int per_pass = min(BLOCK, ia_bytes / ((6 * ia_np + 2 * ia_nd) * 8)) & ~63;
+    if (c0 <= 0 || c1 <= 0 || c2 <= 0 || per_pass < 64) return -1;
+    unsigned short *tlist = reinterpret_cast<unsigned short *>(scratch) + 1;   // (u16 0 of the record is the task count)
+    unsigned char *gstate = scratch + CULL_GSTATE;   // per cell group: 0 unknown, 1 positive, 2 negative
+    // the interval of the model over the box of cells [x0, x1) x [y0, y1) x [z0, z1) (clipped to the tile) -> 0 / 1 / 2
+    auto box_state = [&](int x0, int x1, int y0, int y1, int z0, int z1) -> unsigned char {
+        Ival bx{axes[x0], axes[min(x1, c0)]}, by{axes[33 + y0], axes[33 + min(y1, c1)]}, bz{axes[66 + z0], axes[66 + min(z1, c2)]};
+        if (bx.lo > bx.hi) { const double t = bx.lo; bx.lo = bx.hi; bx.hi = t; }     // (a descending axis)
+        if (by.lo > by.hi) { const double t = by.lo; by.lo = by.hi; by.hi = t; }
+        if (bz.lo > bz.hi) { const double t = bz.lo; bz.lo = bz.hi; bz.hi = t; }
+        if (ia::bad(bx) || ia::bad(by) || ia::bad(bz)) { bx = by = bz = ia::top(); }
+        const Ival v = ia_run_tape<false>(wcode, consts, nullptr, nullptr, n_instr_w, bx, by, bz, true,
+                                          IaShared{ia_state, ia_np, per_pass}, ia_nd, nullptr);
+        return v.lo > 1e-30 ? 1 : (v.hi < -1e-30 ? 2 : 0);
+    };
+    // two levels: the (up to) 4^3 boxes of 8^3 cells first, one wave; then only the groups inside the
+    // boxes that could not be decided
+    unsigned char *mstate = scratch + CULL_COUNT + 16;                                 // 64 bytes
+    unsigned short *elist = reinterpret_cast<unsigned short *>(scratch + CULL_COUNT + 80);   // up to 512 groups to evaluate
+    if (tid < 64) {
+        const int m0 = tid >> 4, m1 = (tid >> 2) & 3, m2 = tid & 3;
+        const bool live = 8 * m0 < c0 && 8 * m1 < c1 && 8 * m2 < c2;
+        const unsigned char st = box_state(live ? 8 * m0 : 0, 8 * m0 + 8, live ? 8 * m1 : 0, 8 * m1 + 8, live ? 8 * m2 : 0, 8 * m2 + 8);
+        mstate[tid] = live ? st : 1;
+    }
+    __syncthreads();
+    int nev = 0;
+    for (int g0 = 0; g0 < 512; g0 += BLOCK) {   // a group inherits the state of its box; the undecided ones are listed
+        const int gq = g0 + tid;
+        const int a0 = gq >> 6, a1 = (gq >> 3) & 7, a2 = gq & 7;
+        const bool exists = gq < 512 && 4 * a0 < c0 && 4 * a1 < c1 && 4 * a2 < c2;
+        const unsigned char ms = exists ? mstate[((a0 >> 1) * 4 + (a1 >> 1)) * 4 + (a2 >> 1)] : 1;
+        if (gq < 512) gstate[gq] = ms;
+        int n;
+        const int pos = nev + block_exclusive_scan<BLOCK>(ms == 0 ? 1 : 0, wave_sums, n);
+        if (ms == 0) elist[pos] = (unsigned short)gq;
+        nev += n;
+    }
+    __syncthreads();
+    for (int e0 = 0; e0 < nev; e0 += per_pass) {
+        if (tid < per_pass && (e0 + (tid & ~63)) < nev) {   // (whole waves)
+            const bool live = e0 + tid < nev;
+            const int gq = elist[min(e0 + tid, nev - 1)];
+            const int a0 = gq >> 6, a1 = (gq >> 3) & 7, a2 = gq & 7;
+            const unsigned char st = box_state(4 * a0, 4 * a0 + 4, 4 * a1, 4 * a1 + 4, 4 * a2, 4 * a2 + 4);
+            if (live) gstate[gq] = st;
+        }
+    }
+    __syncthreads();
+    auto unknown_in = [&](int j0lo, int j0hi, int j1lo, int j1hi, int j2lo, int j2hi) -> bool {   // any undecided group in a box of cells
+        bool u = false;
+        for (int q0 = max(j0lo, 0) >> 2; q0 <= (min(j0hi, c0 - 1) >> 2); q0++)
+            for (int q1 = max(j1lo, 0) >> 2; q1 <= (min(j1hi, c1 - 1) >> 2); q1++)
+                for (int q2 = max(j2lo, 0) >> 2; q2 <= (min(j2hi, c2 - 1) >> 2); q2++) u |= gstate[(q0 * 8 + q1) * 8 + q2] == 0;
+        return u;
+    };
+    // one thread per task: the cells around its samples, as a box (for the tasks that are runs of
+    // samples the box spans the rows / planes the run touches); the listed tasks in ascending order
+    int ntl = 0;
+    for (int t0 = 0; t0 < tt.ntask; t0 += BLOCK) {
+        const int task = t0 + tid;
+        bool need = false;
+        if (task < tt.ntask) {
+            if (!tt.regular) {
+                const int i0 = task * 64, i1 = min(i0 + 63, tt.nvox - 1);
+                const int x0 = i0 / tt.lyz, x1 = i1 / tt.lyz;
+                int y0 = 0, y1 = ly - 1, z0 = 0, z1 = lz - 1;
+                if (x0 == x1) {
+                    y0 = (i0 - x0 * tt.lyz) / lz; y1 = (i1 - x0 * tt.lyz) / lz;
+                    if (y0 == y1) { z0 = i0 - x0 * tt.lyz - y0 * lz; z1 = i1 - x0 * tt.lyz - y0 * lz; }
+                }
+                need = unknown_in(x0 - 1, x1, y0 - 1, y1, z0 - 1, z1);
+            } else if (task < 512) {
+                const int x0 = 4 * (task >> 6), y0 = 4 * ((task >> 3) & 7), z0 = 4 * (task & 7);
+                need = unknown_in(x0 - 1, x0 + 3, y0 - 1, y0 + 3, z0 - 1, z0 + 3);
+            } else if (task < 530) {
+                const int p0 = (task - 512) * 64, r0 = p0 / 33, r1 = min(p0 + 63, 1088) / 33;
+                need = unknown_in(31, 31, r0 - 1, r1, 0, 31);
+            } else if (task < 547) {
+                const int p0 = (task - 530) * 64, r0 = p0 / 33, r1 = min(p0 + 63, 1055) / 33;
+                need = unknown_in(r0 - 1, r1, 31, 31, 0, 31);
+            } else {
+                const int p0 = (task - 547) * 64, r0 = p0 >> 5, r1 = (p0 + 63) >> 5;
+                need = unknown_in(r0 - 1, r1, 0, 31, 31, 31);
+            }
+        }
+        int n;
+        const int pos = ntl + block_exclusive_scan<BLOCK>(need ? 1 : 0, wave_sums, n);
+        if (need) tlist[pos] = (unsigned short)task;
+        ntl += n;
+    }
+    __syncthreads();
+    return ntl;
+}
+
 template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
     typedef Vec<T, NS> V;
@@ -248,7 +401,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     float *vol = reinterpret_cast<float *>(smem + MESH_LDS_VOL);    // (bs+1)^3 floats
     unsigned long long *bits = reinterpret_cast<unsigned long long *>(smem + a.bits_off);   // 1 bit per sample: value > 0
     unsigned *list = reinterpret_cast<unsigned *>(smem + a.list_off);
-    const int tid = threadIdx.x;
+    // `tid` is made opaque to the optimiser at every phase boundary (SDF_FRESH): whatever a phase derives
+    // from it is worked out again there instead of being kept -- i.e. spilled -- across the interpreter
+    int tid = threadIdx.x;
+#define SDF_FRESH() asm volatile("" : "+v"(tid))
     const GridDesc g = a.g;
     const signed char *tri_tab = &a.mc->tri[0][0];
 
@@ -298,6 +454,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         __syncthreads();   // (bcast is reused)
     };
     for (;;) {
+        SDF_FRESH();
         if (tid == 0) bcast[0] = work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
         __syncthreads();
         const int w = bcast[0];
@@ -318,32 +475,75 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         const uint32_t *wcode = code + (size_t)__builtin_amdgcn_readfirstlane(b) * (size_t)a.tape_stride * 2;
         if (a.tape_stride && tid == 0)
             atomicAdd(&a.ctr->n_pruned, (unsigned long long)a.n_instr - reinterpret_cast<const unsigned long long *>(wcode)[a.tape_stride - 1]);
-        const int nvox = lx * ly * lz;
-        const int lyz = ly * lz;
-        const float inv_lyz = 1.0f / (float)lyz, inv_lz = 1.0f / (float)lz;
-        for (int i0 = 0; i0 < nvox; i0 += BLOCK * NS) {
+        const TileTasks tt(lx, ly, lz);
+        const int nvox = tt.nvox, lyz = tt.lyz;
+        const int wave = tid >> 6, lane = tid & 63;
+        constexpr int NWAVE = BLOCK / 64;
+        // ---- 1a. groups of 4^3 cells whose interval excludes the surface are not sampled: k_cull left the
+        // list of tasks to evaluate and the sign of the decided groups (cull_tasks) ----
+        long long tsub = a.prof ? clock64() : 0;
+#define SDF_SUBPROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tsub)); tsub = tn; } } while (0)
+        const unsigned short *tlist = reinterpret_cast<const unsigned short *>(list) + 1;   // (the list region is idle while sampling)
+        const unsigned char *gstate = reinterpret_cast<const unsigned char *>(list) + CULL_GSTATE;
+        int ntl = tt.ntask;
+        bool culled = false;
+        if (a.cull) {
+            if (tid < CULL_RECORD / 4) list[tid] = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[tid];
+            __syncthreads();
+            const int n = (int)reinterpret_cast<const unsigned short *>(list)[0];
+            culled = n != 0xFFFF;
+            if (culled) {
+                ntl = n;
+                // the samples of decided groups get +-1 (those of undecided groups are all evaluated)
+                const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
+                for (int i = tid; i < nvox; i += BLOCK) {
+                    const int ix = fast_div(i, tt.inv_lyz), r = i - ix * lyz, iy = fast_div(r, tt.inv_lz), iz = r - iy * tt.lz;
+                    const unsigned st = gstate[((min(ix, c0 - 1) >> 2) * 8 + (min(iy, c1 - 1) >> 2)) * 8 + (min(iz, c2 - 1) >> 2)];
+                    if (st) vol[i] = st == 2 ? -1.0f : 1.0f;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
+        SDF_SUBPROF(9);
+        // ---- 1c. evaluate the listed tasks: NS per wave and pass ----
+        for (int t0 = wave * NS; t0 < ntl; t0 += NWAVE * NS) {
             V px, py, pz;
             SDF_UNROLL
             for (int k = 0; k < NS; k++) {
-                const int i = min(i0 + k * BLOCK + tid, nvox - 1);
-                const int ix = fast_div(i, inv_lyz), r = i - ix * lyz, iy = fast_div(r, inv_lz), iz = r - iy * lz;
+                const int tk = min(t0 + k, ntl - 1);
+                int ix, iy, iz;
+                tt.sample(culled ? (int)tlist[tk] : tk, lane, ix, iy, iz);
                 px.v[k] = (T)axes[ix]; py.v[k] = (T)axes[33 + iy]; pz.v[k] = (T)axes[66 + iz];
             }
             const V val = run_tape<T, FULL, NP, ND, NS>(wcode, consts, px, py, pz);
             SDF_UNROLL
-            for (int k = 0; k < NS; k++) {
-                const int i = i0 + k * BLOCK + tid;
-                const float f = (float)val.v[k];
-                if (i < nvox) vol[i] = f;
-                // the wave's 64 consecutive samples -> one word of the sign-bit volume (the marching
-                // phases classify cells from these bits instead of re-reading 8 floats per cell)
-                const unsigned long long m = __ballot(i < nvox && f > 0.0f);
-                if ((tid & 63) == 0 && i < nvox) bits[i >> 6] = m;
+            for (int k = 0; k < NS; k++) {   // (the sample index is worked out again rather than kept across the interpreter)
+                int ix, iy, iz;
+                const bool valid = t0 + k < ntl && tt.sample(culled ? (int)tlist[t0 + k] : t0 + k, lane, ix, iy, iz);
+                if (valid) vol[ix * lyz + iy * tt.lz + iz] = (float)val.v[k];
+            }
+        }
+        __syncthreads();
+        SDF_FRESH();
+        SDF_SUBPROF(10);
+        // ---- 1d. the sign-bit volume: one word per 64 consecutive samples (the marching phases classify
+        // cells from these bits instead of re-reading 8 floats per cell) ----
+        for (int word = wave * 4; word < ((nvox + 63) >> 6); word += NWAVE * 4) {   // (four reads in flight per lane)
+            float f[4];
+            SDF_UNROLL for (int k = 0; k < 4; k++) f[k] = vol[min((word + k) * 64 + lane, nvox - 1)];
+            SDF_UNROLL
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long m = __ballot((word + k) * 64 + lane < nvox && f[k] > 0.0f);
+                if (lane == 0 && word + k < ((nvox + 63) >> 6)) bits[word + k] = m;
             }
         }
         if (tid < 2) bits[((nvox + 63) >> 6) + tid] = 0ull;   // the row extraction reads one word ahead
         __syncthreads();
+        SDF_SUBPROF(11);
+#undef SDF_SUBPROF
         SDF_PROF(1);
+        SDF_FRESH();
 
         // ---- 2. count: a thread owns the i2-rows of cells (i0, i1) = row tid + k * BLOCK ----
         // (wave 0 first asks for the predecessors' status words -- of this batch and of the parked one --
@@ -437,6 +637,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             if (a.prof && tid == 0) atomicAdd(&a.prof[7], 1ull);
         }
         SDF_PROF(2);
+        SDF_FRESH();
 
         // ---- 3 + 4. per-triangle work list in LDS, then one lane per triangle ----
         for (int lo = 0; fits && lo < total; lo += a.list_cap) {
@@ -503,8 +704,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         }
         __syncthreads();   // vol / bcast are reused by the next batch
     }
+    SDF_FRESH();
     place_parked(pend_w >= 0 && tid < 64 ? lookback_prefetch(a.status, pend_w, work_begin) : 0ull);
     SDF_PROF(5);
+#undef SDF_FRESH
 #undef SDF_PROF
 }
 

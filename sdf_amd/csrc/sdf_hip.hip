@@ -99,6 +99,37 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
     }
 }
 
+// One workgroup per work item of this shard: which sampling tasks of the batch have to be evaluated
+// (cull_tasks, sdf_device.h).  The record goes to global memory; k_mesh picks it up.
+#define CULL_BLOCK 256
+__global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
+                                                     const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
+                                                     int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
+                                                     unsigned char *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
+    int *wave_sums = reinterpret_cast<int *>(cull_smem);                       // 64 B
+    double *axes = reinterpret_cast<double *>(cull_smem + 64);                 // 3 * 33 doubles
+    unsigned char *scratch = cull_smem + 896;                                  // CULL_SCRATCH bytes
+    double *ia_state = reinterpret_cast<double *>(cull_smem + 896 + CULL_SCRATCH);
+    const int tid = threadIdx.x;
+    const int w = ctr->work_begin + (int)blockIdx.x;
+    if (w >= ctr->work_end) return;
+    const int b = __builtin_amdgcn_readfirstlane(worklist[w]);   // (uniform: the tape is then read with scalar loads)
+    int ox, oy, oz, lx, ly, lz;
+    batch_origin(g, b, ox, oy, oz, lx, ly, lz);
+    if (tid < lx) axes[tid] = g.X[ox + tid];
+    else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
+    else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
+    __syncthreads();
+    const uint32_t *wcode = code + (size_t)b * (size_t)tape_stride * 2;
+    const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
+    const int ntl = cull_tasks<CULL_BLOCK>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd);
+    if (tid == 0) reinterpret_cast<unsigned short *>(scratch)[0] = ntl < 0 ? (unsigned short)0xFFFF : (unsigned short)ntl;
+    __syncthreads();
+    for (int i = tid; i < CULL_RECORD / 4; i += CULL_BLOCK)
+        reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD)[i] = reinterpret_cast<const unsigned *>(scratch)[i];
+}
+
 // ordered compaction of the pending batches into the work list (single workgroup)
 // (also clears the look-back words and the counters of the meshing pass that follows, so the
 // common path needs no memset launches)
@@ -322,6 +353,7 @@ struct sdf_ctx {
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int prune = 1;                    // SDF_PRUNE=0 switches the interval prepass off (diagnostics)
     int parking = 1;                  // SDF_PARK=0: k_mesh waits for its predecessors instead of parking a batch (diagnostics)
+    int cull = 1;                     // SDF_CULL=0: k_mesh samples every voxel of a batch instead of deciding cell groups by intervals
     int park_spins = 1;               // SDF_PARK_SPINS: polls before parking (tuning; measured: waiting never pays)
     DevBuf park;                      // k_mesh's staging slots, one per CU (allocated by the first sdf_generate)
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
@@ -346,7 +378,7 @@ struct sdf_mesh {
     sdf_ctx *ctx = nullptr;
     sdf_stats st = {};
     GridDesc g = {};
-    DevBuf axes, kinds, worklist, status, out, prune, tapes;
+    DevBuf axes, kinds, worklist, status, out, prune, tapes, cull;
     bool pruned = false;
     DevBuf counters;               // this call's MeshCounters block (pooled in the context)
     int work_begin = 0, work_end = 0;
@@ -435,8 +467,9 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
     if (const char *e = getenv("SDF_PRUNE")) c->prune = atoi(e);
     if (const char *e = getenv("SDF_PARK")) c->parking = atoi(e);
+    if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
-    if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(64)) return 1; }
+    if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(128)) return 1; }
     *out = c;
     return 0;
 }
@@ -466,6 +499,12 @@ int sdf_ctx_set_stream(sdf_ctx *c, void *s) {
 int sdf_ctx_set_prune(sdf_ctx *c, int enabled) {
     if (!c) return fail("sdf_ctx_set_prune: ctx is NULL");
     c->prune = enabled ? 1 : 0;
+    return 0;
+}
+
+int sdf_ctx_set_cull(sdf_ctx *c, int enabled) {
+    if (!c) return fail("sdf_ctx_set_cull: ctx is NULL");
+    c->cull = enabled ? 1 : 0;
     return 0;
 }
 
@@ -712,8 +751,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         return up || down;
     };
     const uint32_t n_instr = t->n_words / 2;
-    const bool pruning = c->prune && t->d_rstart && precision == SDF_PRECISION_F64 && n_instr <= 256 &&
-                         monotone(X, nx) && monotone(Y, ny) && monotone(Z, nz);
+    const bool intervals_ok = precision == SDF_PRECISION_F64 && monotone(X, nx) && monotone(Y, ny) && monotone(Z, nz);
+    const bool pruning = c->prune && t->d_rstart && n_instr <= 256 && intervals_ok;
     // 64-bit words per batch tape: the instructions, one more END, the length; whole 64-byte lines
     const int tape_stride = (int)((n_instr + 2 + 7) & ~7u);
     PruneArgs pa = {};
@@ -741,6 +780,20 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                        (MeshCounters *)m->counters.p, (unsigned long long *)m->status.p, (long long)shard_index,
                        (long long)shard_count);
     HIPCHK(hipGetLastError());
+    // second interval pass, per surviving batch: the groups of 4^3 cells the surface cannot be in are not sampled
+    const bool culling = c->cull && intervals_ok;
+    if (culling) {
+        if (m->cull.ensure((size_t)nb * CULL_RECORD)) return 1;
+        const int ia_np = (int)std::max(t->n_p, 1u), ia_nd = (int)std::max(t->n_d, 1u);
+        const size_t ia_bytes = std::min<size_t>((size_t)CULL_BLOCK * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
+        const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
+        if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cull), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_cull, dim3(nb), dim3(CULL_BLOCK), lds, c->stream,
+                           pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
+                           (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
+                           ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
 
     // ---- meshing.  The whole chain (prepass -> k_mesh) is enqueued without a host round trip: the
@@ -788,9 +841,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (c->parking && !c->park.p && c->park.ensure((size_t)c->n_cu * SDF_PARK_TRIS * 36)) return 1;
         a.park = c->parking ? (float *)c->park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
         a.park_spins = (unsigned)c->park_spins;
+        a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
         a.tape_stride = pruning ? tape_stride : 0;
         a.n_instr = (int)n_instr;
-        if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 64, c->stream));
+        if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, c->stream));
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         HIPCHK(hipEventRecord(c->ev[3], c->stream));
         if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs)) return 1;
@@ -802,8 +856,9 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
         m->st.ms_mesh = ms;
         if (c->prof.p) {
-            unsigned long long pc[8];
-            HIPCHK(hipMemcpy(pc, c->prof.p, 64, hipMemcpyDeviceToHost));
+            unsigned long long pc[16];
+            HIPCHK(hipMemcpy(pc, c->prof.p, 128, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu\n", pc[8], pc[9], pc[10], pc[11]);
             fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked\n",
                     ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7]);
         }
@@ -825,6 +880,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
     m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
     m->st.n_pruned_instrs = pruning ? (int64_t)h.n_pruned : 0;
+    m->st.n_sampled_voxels = (int64_t)h.n_sampled;
     m->pruned = pruning;
     m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
@@ -962,7 +1018,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
         m->out.p = nullptr; m->out.bytes = 0;
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
-    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes}) b->release();
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull}) b->release();
     delete m;
     return 0;
 }

@@ -1,0 +1,347 @@
+// sdf_interval.h -- the tape in interval arithmetic: which instructions can a batch skip
+// (prepass, sdf_prune.h), and where inside a batch can the surface not be (k_mesh, sdf_device.h)?
+//
+// Inside one 33^3 batch most of a CSG tree is irrelevant: far from the cylinders of the canonical
+// example, `max(sphere & box, -cylinders)` is decided by its left operand at EVERY sample, so the
+// five instructions that evaluate the cylinders only burn VALU cycles.  The prepass runs the tape
+// once per batch in INTERVAL arithmetic over the batch's box of sample coordinates
+// (8 lanes per batch, one octant each; a decision must hold in all eight) and, at every hard
+// min / max, compares the operand intervals:
+//     the right operand can never win  ->  its instructions are skipped in this batch
+//     the left  operand can never win  ->  the instructions of the left chain are skipped and the
+//                                          combine is "forced" to take the right value
+// (sdf_amd/tape.py records for every combine where its operands start) and then writes the batch
+// its OWN tape with those instructions left out (`compact_tape`), which k_mesh's interpreter runs
+// instead of the model's tape -- a pruned instruction costs nothing at all there.  Tapes longer
+// than 256 instructions are not pruned.
+//
+// This never changes a result.  Every interval operation below performs the SAME floating-point
+// operations, in the same order, as the float64 interpreter (sdf_interp.h) does for that op, on
+// the interval's end points: +, -, *, /, sqrt and fma are correctly rounded, hence monotone in each
+// argument, so the range of an operation over a box of arguments is spanned by its values at the
+// corners -- the interval contains every value the interpreter can produce for a sample in the
+// box (no outward rounding is needed, and none is done).  An operand is only dropped when its interval lies STRICTLY on the losing
+// side of the other's, in which case min / max returns the other operand bit for bit.  Anything
+// that could be NaN, and every op without an interval form (trig, repeat, ...), yields the whole
+// real line, which never licenses a skip.  The parity tests (bit-identical soups against the CPU
+// checker and the reference goldens, plus a random-CSG sweep) run with the prepass active.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "opcodes.h"
+
+namespace sdfk {
+
+struct Ival {
+    double lo, hi;
+};
+
+namespace ia {
+
+__device__ __forceinline__ Ival top() { return Ival{-__builtin_inf(), __builtin_inf()}; }
+__device__ __forceinline__ Ival pt(double c) { return Ival{c, c}; }
+__device__ __forceinline__ bool bad(const Ival &a) { return !(a.lo <= a.hi); }                 // NaN or empty
+__device__ __forceinline__ Ival fix(const Ival &a) { return bad(a) ? top() : a; }
+__device__ __forceinline__ Ival wide(double lo, double hi) { return fix(Ival{lo, hi}); }   // (NaN -> the whole line)
+__device__ __forceinline__ Ival add(const Ival &a, const Ival &b) { return wide(a.lo + b.lo, a.hi + b.hi); }
+__device__ __forceinline__ Ival sub(const Ival &a, const Ival &b) { return wide(a.lo - b.hi, a.hi - b.lo); }
+__device__ __forceinline__ Ival addc(const Ival &a, double c) { return wide(a.lo + c, a.hi + c); }
+__device__ __forceinline__ Ival subc(const Ival &a, double c) { return wide(a.lo - c, a.hi - c); }
+__device__ __forceinline__ Ival csub(double c, const Ival &a) { return wide(c - a.hi, c - a.lo); }
+__device__ __forceinline__ Ival neg(const Ival &a) { return Ival{-a.hi, -a.lo}; }
+__device__ __forceinline__ Ival mulc(const Ival &a, double c) {      // a * c (== c * a)
+    const double p = a.lo * c, q = a.hi * c;
+    if (p != p || q != q) return top();                              // (0 * inf, a NaN constant)
+    return wide(fmin(p, q), fmax(p, q));
+}
+// fma(x, c, r) with a constant c: monotone in x (direction = sign of c) and in r
+__device__ __forceinline__ Ival fmac(const Ival &x, double c, const Ival &r) {
+    const double l = c >= 0 ? fma(x.lo, c, r.lo) : fma(x.hi, c, r.lo);
+    const double h = c >= 0 ? fma(x.hi, c, r.hi) : fma(x.lo, c, r.hi);
+    if (c != c || l != l || h != h) return top();
+    return wide(l, h);
+}
+__device__ __forceinline__ Ival divc(const Ival &a, double c) {
+    if (!(c != 0.0)) return top();                                   // 0 or NaN
+    const double p = a.lo / c, q = a.hi / c;
+    if (p != p || q != q) return top();
+    return wide(fmin(p, q), fmax(p, q));
+}
+__device__ __forceinline__ Ival sqr(const Ival &a) {                 // x * x
+    const double l = a.lo * a.lo, h = a.hi * a.hi;
+    if (l != l || h != h) return top();
+    if (a.lo >= 0) return Ival{l, h};
+    if (a.hi <= 0) return Ival{h, l};
+    return Ival{0.0, fmax(l, h)};
+}
+__device__ __forceinline__ Ival sqrt_(const Ival &a) {
+    // only sums of squares get here: never negative, never NaN unless a bound already is
+    if (bad(a) || a.lo < 0) return top();
+    return Ival{sqrt(a.lo), sqrt(a.hi)};
+}
+__device__ __forceinline__ Ival abs_(const Ival &a) {
+    if (a.lo >= 0) return a;
+    if (a.hi <= 0) return neg(a);
+    return Ival{0.0, fmax(-a.lo, a.hi)};
+}
+__device__ __forceinline__ Ival min_(const Ival &a, const Ival &b) { return Ival{fmin(a.lo, b.lo), fmin(a.hi, b.hi)}; }
+__device__ __forceinline__ Ival max_(const Ival &a, const Ival &b) { return Ival{fmax(a.lo, b.lo), fmax(a.hi, b.hi)}; }
+__device__ __forceinline__ Ival maxc(const Ival &a, double c) { return Ival{fmax(a.lo, c), fmax(a.hi, c)}; }
+__device__ __forceinline__ Ival minc(const Ival &a, double c) { return Ival{fmin(a.lo, c), fmin(a.hi, c)}; }
+__device__ __forceinline__ Ival clip01(const Ival &a) { return Ival{fmin(fmax(a.lo, 0.0), 1.0), fmin(fmax(a.hi, 0.0), 1.0)}; }
+// sdf_interp.h len2 / len3: sqrt(x*x + y*y), sqrt((x*x + y*y) + z*z)
+__device__ __forceinline__ Ival len2(const Ival &x, const Ival &y) { return sqrt_(add(sqr(x), sqr(y))); }
+__device__ __forceinline__ Ival len3(const Ival &x, const Ival &y, const Ival &z) { return sqrt_(add(add(sqr(x), sqr(y)), sqr(z))); }
+// sdf_interp.h dot3 / dot2: fma(z, c, fma(y, b, x * a))
+__device__ __forceinline__ Ival dot3c(const Ival &x, const Ival &y, const Ival &z, double a, double b, double c) {
+    return fmac(z, c, fmac(y, b, mulc(x, a)));
+}
+__device__ __forceinline__ Ival dot2c(const Ival &x, const Ival &y, double a, double b) { return fmac(y, b, mulc(x, a)); }
+
+}  // namespace ia
+
+// Machine state of the interval run: the current point and distance live in registers, the saved
+// points / distances in (dynamic) LDS, [slot][component][thread] -- a run-time slot number would put
+// a per-thread array into scratch memory.  The host sizes it for the slots the tape uses.
+enum { PRUNE_BLOCK = 256 };
+struct IaShared {
+    double *base;
+    int n_p;
+    int stride;     // threads that share the array
+    __device__ __forceinline__ double &ps(uint32_t slot, int k) { return base[(slot * 6 + k) * stride + threadIdx.x]; }
+    __device__ __forceinline__ double &ds(uint32_t slot, int k) { return base[(n_p * 6 + slot * 2 + k) * stride + threadIdx.x]; }
+};
+__host__ __device__ inline size_t prune_lds_bytes(int n_p, int n_d) { return (size_t)(6 * n_p + 2 * n_d) * PRUNE_BLOCK * 8; }
+
+
+__device__ __forceinline__ Ival ia_box_like(const Ival &qx, const Ival &qy, const Ival &qz) {
+    using namespace ia;
+    const Ival mx = max_(max_(qx, qy), qz);
+    return add(len3(maxc(qx, 0.0), maxc(qy, 0.0), maxc(qz, 0.0)), minc(mx, 0.0));
+}
+
+// value interval of a leaf (the formulas of sdf_interp.h, operation by operation), or the whole
+// line for leaves without an interval form
+__device__ __noinline__ Ival ia_leaf(uint32_t op, const double *c, const Ival &x, const Ival &y, const Ival &z) {
+    using namespace ia;
+    switch (op) {
+    case OP_L_SPHERE: return subc(len3(subc(x, c[1]), subc(y, c[2]), subc(z, c[3])), c[0]);
+    case OP_L_PLANE: return dot3c(csub(c[3], x), csub(c[4], y), csub(c[5], z), c[0], c[1], c[2]);
+    case OP_L_BOX:
+        return ia_box_like(subc(abs_(subc(x, c[0])), c[3]), subc(abs_(subc(y, c[1])), c[4]), subc(abs_(subc(z, c[2])), c[5]));
+    case OP_L_ROUNDED_BOX:
+        return subc(ia_box_like(addc(subc(abs_(x), c[0]), c[3]), addc(subc(abs_(y), c[1]), c[3]), addc(subc(abs_(z), c[2]), c[3])), c[3]);
+    case OP_L_TORUS: return subc(len2(subc(len2(x, y), c[0]), z), c[1]);
+    case OP_L_CYLINDER: return subc(len2(x, y), c[0]);
+    case OP_L_ROUNDED_CYLINDER: {
+        const Ival d0 = addc(subc(len2(x, y), c[0]), c[1]), d1 = addc(subc(abs_(z), c[2]), c[1]);
+        return subc(add(minc(max_(d0, d1), 0.0), len2(maxc(d0, 0.0), maxc(d1, 0.0))), c[1]);
+    }
+    case OP_L_CAPSULE: {
+        const Ival pax = subc(x, c[0]), pay = subc(y, c[1]), paz = subc(z, c[2]);
+        const Ival h = clip01(divc(dot3c(pax, pay, paz, c[3], c[4], c[5]), c[6]));
+        return subc(len3(sub(pax, mulc(h, c[3])), sub(pay, mulc(h, c[4])), sub(paz, mulc(h, c[5]))), c[7]);
+    }
+    case OP_L_OCTAHEDRON: return mulc(subc(add(add(abs_(x), abs_(y)), abs_(z)), c[0]), c[1]);
+    case OP_L_CIRCLE: return subc(len2(subc(x, c[1]), subc(y, c[2])), c[0]);
+    case OP_L_LINE: return dot2c(csub(c[2], x), csub(c[3], y), c[0], c[1]);
+    case OP_L_RECTANGLE: {
+        const Ival qx = subc(abs_(subc(x, c[0])), c[2]), qy = subc(abs_(subc(y, c[1])), c[3]);
+        return add(len2(maxc(qx, 0.0), maxc(qy, 0.0)), minc(max_(qx, qy), 0.0));
+    }
+    default: return top();
+    }
+}
+
+// interval of post(d1, d2) (sdf_interp.h post_combine)
+__device__ __forceinline__ Ival ia_post(uint32_t post, const Ival &d1, const Ival &d2, double K) {
+    using namespace ia;
+    switch (post) {
+    case POST_SET: return d2;
+    case POST_UNION: return min_(d1, d2);
+    case POST_DIFF: return max_(d1, neg(d2));
+    case POST_INTER: return max_(d1, d2);
+    case POST_BLEND: return add(mulc(d2, K), mulc(d1, 1.0 - K));
+    default: break;
+    }
+    // polynomial smooth min / max (dn.py:7-50), for K > 0: with e = the second operand (negated for
+    // a difference) and h the clipped blend weight, the result is min(d1, e) - K (1 - h')^2 resp.
+    // max(d1, e) + K (1 - h')^2 with h' in [1/2, 1], i.e. within K / 4 of the hard result on its far
+    // side.  Bounded analytically, with a margin far above the rounding of the few operations.
+    if (!(K > 0.0) || bad(d1) || bad(d2)) return top();
+    const Ival e = post == POST_SDIFF ? neg(d2) : d2;
+    Ival r = post == POST_SUNION ? min_(d1, e) : max_(d1, e);
+    if (post == POST_SUNION) r.lo -= 0.25 * K; else r.hi += 0.25 * K;
+    const double m = 1e-9 * (fabs(r.lo) + fabs(r.hi) + K);
+    return fix(Ival{r.lo - m, r.hi + m});
+}
+
+// 0 keep both, 1 the right operand never wins, 2 the left operand never wins
+__device__ __forceinline__ int ia_decide(uint32_t post, const Ival &left, const Ival &right) {
+    switch (post) {
+    case POST_UNION: return right.lo > left.hi ? 1 : (left.lo > right.hi ? 2 : 0);
+    case POST_INTER: return right.hi < left.lo ? 1 : (left.hi < right.lo ? 2 : 0);
+    case POST_DIFF: return -right.lo < left.lo ? 1 : (left.hi < -right.hi ? 2 : 0);       // max(left, -right)
+    default: return 0;
+    }
+}
+
+__device__ __forceinline__ void mask_set_range(uint32_t *m, int a, int b) {   // bits a..b inclusive, 0 <= a <= b < 256
+    for (int k = 0; k < 8; k++) {
+        const int lo = a - 32 * k, hi = b - 32 * k;
+        if (hi < 0 || lo > 31) continue;
+        m[k] |= (0xFFFFFFFFu >> (31 - (hi > 31 ? 31 : hi))) & (0xFFFFFFFFu << (lo < 0 ? 0 : lo));
+    }
+}
+
+// (the masks live in registers: no run-time indexing of the arrays)
+__device__ __forceinline__ void mask_set_bit(uint32_t *m, int i) {
+    for (int k = 0; k < 8; k++) if ((i >> 5) == k) m[k] |= 1u << (i & 31);
+}
+__device__ __forceinline__ uint32_t mask_word(const uint32_t *m, int idx) {
+    uint32_t r = 0;
+    for (int k = 0; k < 8; k++) r = idx == k ? m[k] : r;
+    return r;
+}
+
+// One pass of the tape over the box (x, y, z); returns the interval of the model's value.  All
+// lanes of the wave run the same tape (uniform control flow).  With DECIDE the 8 lanes of a batch
+// agree on which operands to drop with a ballot and every one of them records it: masks[0..8) skip
+// bits, masks[8..16) forced bits (without DECIDE rstart / lstart / masks are not touched).
+template <bool DECIDE>
+__device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, const double *__restrict__ consts,
+                                            const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart, int n_instr,
+                                            Ival x, Ival y, Ival z, bool live, IaShared sh, int n_d, uint32_t *masks) {
+    using namespace ia;
+    const int lane = threadIdx.x & 63, gbase = lane & ~7;
+    Ival acc = pt(0.0);
+    for (int i = 0; i < sh.n_p; i++)
+        for (int k = 0; k < 6; k++) sh.ps(i, k) = 0.0;
+    for (int i = 0; i < n_d; i++) { sh.ds(i, 0) = 0.0; sh.ds(i, 1) = 0.0; }
+    uint32_t keep[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // point bookkeeping is never skipped (see below)
+    // (slot numbers were validated against n_p / n_d when the tape was created)
+    auto psave = [&](uint32_t k) {
+        sh.ps(k, 0) = x.lo; sh.ps(k, 1) = x.hi; sh.ps(k, 2) = y.lo; sh.ps(k, 3) = y.hi; sh.ps(k, 4) = z.lo; sh.ps(k, 5) = z.hi;
+    };
+    auto pload = [&](uint32_t k) {
+        x = Ival{sh.ps(k, 0), sh.ps(k, 1)}; y = Ival{sh.ps(k, 2), sh.ps(k, 3)}; z = Ival{sh.ps(k, 4), sh.ps(k, 5)};
+    };
+    auto dsave = [&](uint32_t k, const Ival &v) { sh.ds(k, 0) = v.lo; sh.ds(k, 1) = v.hi; };
+    auto dload = [&](uint32_t k) { return Ival{sh.ds(k, 0), sh.ds(k, 1)}; };
+    for (int ip = 0; ip < n_instr; ip++) {
+        const uint32_t w0 = code[2 * ip], w1 = code[2 * ip + 1];
+        const uint32_t op = w0 & 255u, post = (w0 >> 8) & 7u, sa = (w0 >> 24) & 7u;
+        const double *c = consts + (w1 & 0xFFFFFFu) + 1;
+        if (op == OP_END) break;
+        if (w0 & 0x000800u) pload((w0 >> 12) & 7u);
+        if (w0 & 0x008000u) psave((w0 >> 16) & 7u);
+        if (w0 & 0x080000u) dsave((w0 >> 20) & 7u, acc);
+        const bool is_leaf = op >= OP_L_SPHERE && op < OP_COMB;
+        if (is_leaf || op == OP_COMB) {
+            const Ival left = is_leaf ? acc : dload(sa);
+            const Ival right = is_leaf ? ia_leaf(op, c, x, y, z) : acc;
+            int rs = 0xFFFF, ls = 0xFFFF;
+            if constexpr (DECIDE) { rs = rstart[ip]; ls = lstart[ip]; }
+            if (DECIDE && rs != 0xFFFF && ls != 0xFFFF && rs <= ip && ls <= rs) {
+                const int d = live ? ia_decide(post, left, right) : 3;     // dead lanes agree with everything
+                const unsigned long long b1 = __ballot(d == 1 || d == 3), b2 = __ballot(d == 2 || d == 3);
+                if (((b1 >> gbase) & 0xFFull) == 0xFFull) mask_set_range(masks, rs, ip);
+                else if (((b2 >> gbase) & 0xFFull) == 0xFFull && rs > ls) {
+                    mask_set_range(masks, ls, rs - 1);
+                    mask_set_bit(masks + 8, ip);
+                }
+            }
+            acc = ia_post(post, left, right, c[-1]);
+            continue;
+        }
+        switch (op) {
+        case OP_TRANSLATE: x = subc(x, c[0]); y = subc(y, c[1]); z = subc(z, c[2]); break;
+        case OP_SCALE: x = divc(x, c[0]); y = divc(y, c[1]); z = divc(z, c[2]); break;
+        case OP_ROTATE: {
+            const Ival nx = dot3c(x, y, z, c[0], c[3], c[6]);
+            const Ival ny = dot3c(x, y, z, c[1], c[4], c[7]);
+            const Ival nz = dot3c(x, y, z, c[2], c[5], c[8]);
+            x = nx; y = ny; z = nz; break; }
+        case OP_ELONGATE: {
+            const Ival qx = subc(abs_(x), c[0]), qy = subc(abs_(y), c[1]), qz = subc(abs_(z), c[2]);
+            dsave(sa, minc(max_(qx, max_(qy, qz)), 0.0));
+            x = maxc(qx, 0.0); y = maxc(qy, 0.0); z = maxc(qz, 0.0); break; }
+        case OP_TRANSLATE2: x = subc(x, c[0]); y = subc(y, c[1]); break;
+        case OP_SCALE2: x = divc(x, c[0]); y = divc(y, c[1]); break;
+        case OP_ROTATE2: {
+            const Ival nx = dot2c(x, y, c[0], c[2]), ny = dot2c(x, y, c[1], c[3]);
+            x = nx; y = ny; break; }
+        case OP_ELONGATE2: {
+            const Ival qx = subc(abs_(x), c[0]), qy = subc(abs_(y), c[1]);
+            dsave(sa, minc(max_(qx, qy), 0.0));
+            x = maxc(qx, 0.0); y = maxc(qy, 0.0); break; }
+        case OP_REVOLVE: { const Ival nx = subc(len2(x, y), c[0]); y = z; x = nx; z = pt(0.0); break; }
+        case OP_SETZ0: z = pt(0.0); break;
+        case OP_SAVE_P: psave(sa); if constexpr (DECIDE) mask_set_bit(keep, ip); break;
+        case OP_LOAD_P: pload(sa); if constexpr (DECIDE) mask_set_bit(keep, ip); break;
+        case OP_PUSH_D: dsave(sa, acc); break;
+        case OP_NOP: break;
+        case OP_NEG: acc = neg(acc); break;
+        case OP_ADDC: acc = addc(acc, c[0]); break;
+        case OP_SUBC: acc = subc(acc, c[0]); break;
+        case OP_MULC: acc = mulc(acc, c[0]); break;
+        case OP_SHELL: acc = subc(abs_(acc), c[0]); break;
+        case OP_ADD_DS: acc = add(acc, dload(sa)); break;
+        case OP_EXT_PRE: dsave(sa, subc(abs_(z), c[0])); break;
+        case OP_EXT_POST: {
+            const Ival w = dload(sa);
+            acc = add(minc(max_(acc, w), 0.0), len2(maxc(acc, 0.0), maxc(w, 0.0))); break; }
+        default:
+            // an op without an interval form: everything it may write becomes unknown
+            x = y = z = top(); acc = top();
+            for (int k = 0; k < n_d; k++) dsave(k, top());
+            if (op == OP_REP_PREP || op == OP_CIRC_PREP) psave(sa);
+            break;
+        }
+    }
+    // A boolean saves the point its operands share inside its FIRST operand and restores it between
+    // operands (tape.py `boolean`): those moves must happen even when the operand around them is
+    // skipped.  As prefixes they survive on a NOP (compact_tape); as stand-alone instructions they
+    // are exempted here.
+    if constexpr (DECIDE)
+        for (int k = 0; k < 8; k++) masks[k] &= ~keep[k];
+    return acc;
+}
+
+// The batch's tape: the model's tape without the skipped instructions.
+//   * a skipped instruction that carries prefixes leaves a NOP with those prefixes (the point / distance
+//     moves of the surrounding constructs ride on their neighbours, tape.py peephole);
+//   * a forced hard min / max IS its right operand: post becomes SET (a forced COMB would then copy acc
+//     onto itself and disappears); a forced difference is -right: SET, then NEG.  Forcing always skips at
+//     least one instruction of the left chain, so the result never grows beyond the original length.
+// Every lane of a batch holds the same masks and runs this loop (uniform: scalar loads of the
+// tape); only lane 0 of the batch stores.  Returns the number of instructions (END included).
+__device__ __forceinline__ int compact_tape(const unsigned long long *__restrict__ code64, int n_instr, const uint32_t *masks,
+                                            unsigned long long *__restrict__ out, bool store) {
+    const unsigned long long PREFIX = 0x00FFF800ull, POSTM = 0x700ull;
+    int n = 0;
+    auto put = [&](unsigned long long w) { if (store) out[n] = w; n++; };
+    uint32_t skip_w = 0, force_w = 0;
+    for (int ip = 0; ip < n_instr; ip++) {
+        const unsigned long long w = code64[ip];
+        const uint32_t op = (uint32_t)w & 255u, post = ((uint32_t)w >> 8) & 7u;
+        if ((ip & 31) == 0) { skip_w = mask_word(masks, ip >> 5); force_w = mask_word(masks + 8, ip >> 5); }
+        const bool skip = skip_w & 1u, forced = force_w & 1u;
+        skip_w >>= 1; force_w >>= 1;
+        if (skip) {
+            if (w & PREFIX) put((w & PREFIX) | OP_NOP);
+        } else if (!forced) {
+            put(w);
+        } else if (op == OP_COMB) {
+            if (post == POST_DIFF) put((w & PREFIX) | OP_NEG);
+            else if (w & PREFIX) put((w & PREFIX) | OP_NOP);
+        } else {
+            put(w & ~POSTM);                                  // a leaf: post = SET
+            if (post == POST_DIFF) put(OP_NEG);
+        }
+    }
+    return n;
+}
+
+}  // namespace sdfk

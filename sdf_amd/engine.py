@@ -38,6 +38,7 @@ class SdfStats(ctypes.Structure):
         ('n_retries', _c_i64),
         ('ms_prepass', ctypes.c_double), ('ms_mesh', ctypes.c_double), ('ms_emit', ctypes.c_double),
         ('ms_total', ctypes.c_double), ('n_pruned_instrs', _c_i64), ('n_batch_instrs', _c_i64),
+        ('n_sampled_voxels', _c_i64),
     ]
 
 
@@ -50,6 +51,7 @@ ABI = {
     'sdf_ctx_destroy': (ctypes.c_int, [_vp]),
     'sdf_ctx_set_stream': (ctypes.c_int, [_vp, _vp]),
     'sdf_ctx_set_prune': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'sdf_ctx_set_cull': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_synchronize': (ctypes.c_int, [_vp]),
     'sdf_tape_create': (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _f64p, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
@@ -222,6 +224,10 @@ class Engine:
     def set_prune(self, enabled):
         """interval prepass of generate on / off (default on; results are identical)"""
         _check(self.lib, self.lib.sdf_ctx_set_prune(self.ctx, int(bool(enabled))))
+
+    def set_cull(self, enabled):
+        """interval culling of cell groups inside a batch on / off (default on; results are identical)"""
+        _check(self.lib, self.lib.sdf_ctx_set_cull(self.ctx, int(bool(enabled))))
 
     def synchronize(self):
         _check(self.lib, self.lib.sdf_ctx_synchronize(self.ctx))

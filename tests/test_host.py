@@ -101,8 +101,8 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.sdf_abi_version() == engine.ABI_VERSION
-    # struct layout of sdf_stats: 11 int64 + 4 double + 2 int64
-    assert ctypes.sizeof(engine.SdfStats) == 17 * 8
+    # struct layout of sdf_stats: 11 int64 + 4 double + 3 int64
+    assert ctypes.sizeof(engine.SdfStats) == 18 * 8
 
 
 def test_no_cpu_fallback_without_device(ns):
