@@ -460,6 +460,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         const int w = bcast[0];
         if (w >= work_end) break;
         const int b = a.worklist[w];
+        // k_cull's record of the batch (cull_tasks) travels next to the axes: into the list region, idle until phase 3
+        if (a.cull && tid < CULL_RECORD / 4) list[tid] = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[tid];
         int ox, oy, oz, lx, ly, lz;
         batch_origin(g, b, ox, oy, oz, lx, ly, lz);
         if (tid < lx) axes[tid] = g.X[ox + tid];
@@ -488,21 +490,30 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         int ntl = tt.ntask;
         bool culled = false;
         if (a.cull) {
-            if (tid < CULL_RECORD / 4) list[tid] = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[tid];
-            __syncthreads();
             const int n = (int)reinterpret_cast<const unsigned short *>(list)[0];
             culled = n != 0xFFFF;
             if (culled) {
                 ntl = n;
-                // the samples of decided groups get +-1 (those of undecided groups are all evaluated)
+                // the samples of decided groups get +-1 (those of undecided groups are all evaluated afterwards,
+                // whatever is written to them here)
                 const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
-                for (int i = tid; i < nvox; i += BLOCK) {
-                    const int ix = fast_div(i, tt.inv_lyz), r = i - ix * lyz, iy = fast_div(r, tt.inv_lz), iz = r - iy * tt.lz;
-                    const unsigned st = gstate[((min(ix, c0 - 1) >> 2) * 8 + (min(iy, c1 - 1) >> 2)) * 8 + (min(iz, c2 - 1) >> 2)];
-                    if (st) vol[i] = st == 2 ? -1.0f : 1.0f;
+                if (tt.regular) {
+                    // a thread per row of 33 samples along z: the 8 group states of the row in one read
+                    for (int r = tid; r < 33 * 33; r += BLOCK) {
+                        const int ix = fast_div(r, 1.0f / 33.0f), iy = r - 33 * ix;
+                        const unsigned long long st8 = *reinterpret_cast<const unsigned long long *>(gstate + ((min(ix, 31) >> 2) * 8 + (min(iy, 31) >> 2)) * 8);
+                        float *row = vol + r * 33;
+                        SDF_UNROLL
+                        for (int iz = 0; iz < 33; iz++) row[iz] = ((st8 >> (8 * (min(iz, 31) >> 2))) & 255ull) == 2ull ? -1.0f : 1.0f;
+                    }
+                } else {
+                    for (int i = tid; i < nvox; i += BLOCK) {
+                        const int ix = fast_div(i, tt.inv_lyz), r = i - ix * lyz, iy = fast_div(r, tt.inv_lz), iz = r - iy * tt.lz;
+                        vol[i] = gstate[((min(ix, c0 - 1) >> 2) * 8 + (min(iy, c1 - 1) >> 2)) * 8 + (min(iz, c2 - 1) >> 2)] == 2 ? -1.0f : 1.0f;
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
         if (tid == 0) atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
         SDF_SUBPROF(9);
