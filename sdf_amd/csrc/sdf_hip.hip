@@ -117,9 +117,11 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict_
     const int b = __builtin_amdgcn_readfirstlane(worklist[w]);   // (uniform: the tape is then read with scalar loads)
     int ox, oy, oz, lx, ly, lz;
     batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-    if (tid < lx) axes[tid] = g.X[ox + tid];
-    else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
-    else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
+    for (int i = tid; i < 99; i += CULL_BLOCK) {
+        if (i < 33) { if (i < lx) axes[i] = g.X[ox + i]; }
+        else if (i < 66) { if (i - 33 < ly) axes[i] = g.Y[oy + i - 33]; }
+        else if (i - 66 < lz) axes[i] = g.Z[oz + i - 66];
+    }
     __syncthreads();
     const uint32_t *wcode = code + (size_t)b * (size_t)tape_stride * 2;
     const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
@@ -371,6 +373,7 @@ struct sdf_tape {
     bool full = false;
     uint32_t n_p = 0, n_d = 0;
     uint16_t *d_rstart = nullptr, *d_lstart = nullptr;   // operand ranges of the prunable combines (or NULL)
+    bool ia_complete = false;                            // every op has an interval form (sdf_interval.h ia_has_form)
     unsigned long long hint_key = 0, hint_total_tris = 0;   // arena sizing: last call of this tape
 };
 
@@ -523,6 +526,8 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     sdf_tape *t = new sdf_tape();
     t->ctx = c; t->n_words = n_words; t->n_consts = n_consts;
     t->full = tape_needs_full(code, n_words, consts);
+    t->ia_complete = true;
+    for (uint32_t i = 0; i < n_words; i += 2) t->ia_complete = t->ia_complete && ia_has_form(code[i] & 255u);
     t->n_p = n_p; t->n_d = n_d;
     std::vector<float> c32(n_consts);
     for (uint32_t i = 0; i < n_consts; i++) c32[i] = (float)consts[i];
@@ -781,7 +786,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                        (long long)shard_count);
     HIPCHK(hipGetLastError());
     // second interval pass, per surviving batch: the groups of 4^3 cells the surface cannot be in are not sampled
-    const bool culling = c->cull && intervals_ok;
+    const bool culling = c->cull && intervals_ok && t->ia_complete;
     if (culling) {
         if (m->cull.ensure((size_t)nb * CULL_RECORD)) return 1;
         const int ia_np = (int)std::max(t->n_p, 1u), ia_nd = (int)std::max(t->n_d, 1u);

@@ -115,6 +115,20 @@ struct IaShared {
 __host__ __device__ inline size_t prune_lds_bytes(int n_p, int n_d) { return (size_t)(6 * n_p + 2 * n_d) * PRUNE_BLOCK * 8; }
 
 
+// ops with an interval form below (ia_leaf / ia_run_tape); a tape made of these only is worth the
+// cell-group pass of k_cull, any other op turns everything behind it into the whole line
+__host__ __device__ inline bool ia_has_form(uint32_t op) {
+    switch (op) {
+    case OP_END: case OP_L_SPHERE: case OP_L_PLANE: case OP_L_BOX: case OP_L_ROUNDED_BOX: case OP_L_TORUS: case OP_L_CYLINDER:
+    case OP_L_ROUNDED_CYLINDER: case OP_L_CAPSULE: case OP_L_OCTAHEDRON: case OP_L_CIRCLE: case OP_L_LINE: case OP_L_RECTANGLE:
+    case OP_COMB: case OP_TRANSLATE: case OP_SCALE: case OP_ROTATE: case OP_ELONGATE: case OP_TRANSLATE2: case OP_SCALE2:
+    case OP_ROTATE2: case OP_ELONGATE2: case OP_REVOLVE: case OP_SETZ0: case OP_SAVE_P: case OP_LOAD_P: case OP_PUSH_D: case OP_NOP:
+    case OP_NEG: case OP_ADDC: case OP_SUBC: case OP_MULC: case OP_SHELL: case OP_ADD_DS: case OP_EXT_PRE: case OP_EXT_POST:
+        return true;
+    default: return false;
+    }
+}
+
 __device__ __forceinline__ Ival ia_box_like(const Ival &qx, const Ival &qy, const Ival &qz) {
     using namespace ia;
     const Ival mx = max_(max_(qx, qy), qz);
