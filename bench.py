@@ -178,6 +178,10 @@ def main():
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     plain, special = tape.tape.flop_estimate()
     eval_vox = int(st['n_eval_voxels']) if world == 1 else int(st['n_eval_voxels'] // world)
+    # of those, the samples that went through the interpreter (the rest were decided by the interval
+    # passes: k_cull); the flop estimate below is for the model's whole tape, before per-batch pruning
+    sampled_vox = int(st.get('n_sampled_voxels', st['n_eval_voxels']))
+    sampled_vox = sampled_vox if world == 1 else sampled_vox // world
     # HBM traffic of k_mesh per launch from the PMC passes of tools/profile.sh (separate rocprofv3
     # --pmc runs of this same command; FETCH_SIZE/WRITE_SIZE corrected as MI355X_MICROARCH.md says,
     # see tools/summarize_prof.py); the newest committed summary is used
@@ -197,8 +201,10 @@ def main():
         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
         'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': round(k_ms, 4),
         'note': 'path is VALU/latency bound by construction (SURVEY 8d): see valu',
-        'valu': {'eval_voxels_per_launch': eval_vox, 'flops_per_voxel_est': plain + special,
-                 'achieved_tflops_est': round((plain + special) * eval_vox / (k_ms * 1e-3) / 1e12, 3) if k_ms > 0 else 0,
+        'valu': {'eval_voxels_per_launch': eval_vox, 'interpreted_voxels_per_launch': sampled_vox,
+                 'pruned_instr_fraction': round(st.get('n_pruned_instrs', 0) / max(st.get('n_batch_instrs', 0), 1), 4),
+                 'flops_per_voxel_est': plain + special,
+                 'achieved_tflops_est': round((plain + special) * sampled_vox / (k_ms * 1e-3) / 1e12, 3) if k_ms > 0 else 0,
                  'peak_tflops': FP64_VECTOR_PEAK_TFLOPS if args.precision == 'f64' else 157.3},
     }
 
