@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
                                               int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa) {
     extern __shared__ double prune_lds[];
     if ((int)blockIdx.x >= pa.first_block) {   // (uniform)
-        prune_block(code, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
+        prune_block<FULL>(code, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
         return;
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
 // One workgroup per work item of this shard: which sampling tasks of the batch have to be evaluated
 // (cull_tasks, sdf_device.h).  The record goes to global memory; k_mesh picks it up.
 #define CULL_BLOCK 256
+template <bool FULL>
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict_
     __syncthreads();
     const uint32_t *wcode = code + (size_t)b * (size_t)tape_stride * 2;
     const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
-    const int ntl = cull_tasks<CULL_BLOCK>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd);
+    const int ntl = cull_tasks<CULL_BLOCK, FULL>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd);
     if (tid == 0) reinterpret_cast<unsigned short *>(scratch)[0] = ntl < 0 ? (unsigned short)0xFFFF : (unsigned short)ntl;
     __syncthreads();
     for (int i = tid; i < CULL_RECORD / 4; i += CULL_BLOCK)
@@ -792,8 +793,9 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const int ia_np = (int)std::max(t->n_p, 1u), ia_nd = (int)std::max(t->n_d, 1u);
         const size_t ia_bytes = std::min<size_t>((size_t)CULL_BLOCK * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
-        if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cull), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_cull, dim3(nb), dim3(CULL_BLOCK), lds, c->stream,
+        auto kc = t->full ? k_cull<true> : k_cull<false>;
+        if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kc, dim3(nb), dim3(CULL_BLOCK), lds, c->stream,
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
                            (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
                            ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p);

@@ -31,7 +31,19 @@
 
 #include "opcodes.h"
 
+// the interval primitives also compile for the host: tests/test_interval_host.py builds them into a
+// small CPU program and checks the enclosures against sampled points
+#define SDF_IA __host__ __device__ __forceinline__
+
 namespace sdfk {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void ia_sincos(double x, double *s, double *c) { o_sincos(x, s, c); }   // (outlined ocml bodies, sdf_interp.h)
+__device__ __forceinline__ double ia_atan2(double y, double x) { return o_atan2(y, x); }
+#else
+inline void ia_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
+inline double ia_atan2(double y, double x) { return atan2(y, x); }
+#endif
 
 struct Ival {
     double lo, hi;
@@ -39,65 +51,177 @@ struct Ival {
 
 namespace ia {
 
-__device__ __forceinline__ Ival top() { return Ival{-__builtin_inf(), __builtin_inf()}; }
-__device__ __forceinline__ Ival pt(double c) { return Ival{c, c}; }
-__device__ __forceinline__ bool bad(const Ival &a) { return !(a.lo <= a.hi); }                 // NaN or empty
-__device__ __forceinline__ Ival fix(const Ival &a) { return bad(a) ? top() : a; }
-__device__ __forceinline__ Ival wide(double lo, double hi) { return fix(Ival{lo, hi}); }   // (NaN -> the whole line)
-__device__ __forceinline__ Ival add(const Ival &a, const Ival &b) { return wide(a.lo + b.lo, a.hi + b.hi); }
-__device__ __forceinline__ Ival sub(const Ival &a, const Ival &b) { return wide(a.lo - b.hi, a.hi - b.lo); }
-__device__ __forceinline__ Ival addc(const Ival &a, double c) { return wide(a.lo + c, a.hi + c); }
-__device__ __forceinline__ Ival subc(const Ival &a, double c) { return wide(a.lo - c, a.hi - c); }
-__device__ __forceinline__ Ival csub(double c, const Ival &a) { return wide(c - a.hi, c - a.lo); }
-__device__ __forceinline__ Ival neg(const Ival &a) { return Ival{-a.hi, -a.lo}; }
-__device__ __forceinline__ Ival mulc(const Ival &a, double c) {      // a * c (== c * a)
+SDF_IA Ival top() { return Ival{-__builtin_inf(), __builtin_inf()}; }
+SDF_IA Ival pt(double c) { return Ival{c, c}; }
+SDF_IA bool bad(const Ival &a) { return !(a.lo <= a.hi); }                 // NaN or empty
+SDF_IA Ival fix(const Ival &a) { return bad(a) ? top() : a; }
+SDF_IA Ival wide(double lo, double hi) { return fix(Ival{lo, hi}); }   // (NaN -> the whole line)
+SDF_IA Ival add(const Ival &a, const Ival &b) { return wide(a.lo + b.lo, a.hi + b.hi); }
+SDF_IA Ival sub(const Ival &a, const Ival &b) { return wide(a.lo - b.hi, a.hi - b.lo); }
+SDF_IA Ival addc(const Ival &a, double c) { return wide(a.lo + c, a.hi + c); }
+SDF_IA Ival subc(const Ival &a, double c) { return wide(a.lo - c, a.hi - c); }
+SDF_IA Ival csub(double c, const Ival &a) { return wide(c - a.hi, c - a.lo); }
+SDF_IA Ival neg(const Ival &a) { return Ival{-a.hi, -a.lo}; }
+SDF_IA Ival mulc(const Ival &a, double c) {      // a * c (== c * a)
     const double p = a.lo * c, q = a.hi * c;
     if (p != p || q != q) return top();                              // (0 * inf, a NaN constant)
     return wide(fmin(p, q), fmax(p, q));
 }
 // fma(x, c, r) with a constant c: monotone in x (direction = sign of c) and in r
-__device__ __forceinline__ Ival fmac(const Ival &x, double c, const Ival &r) {
+SDF_IA Ival fmac(const Ival &x, double c, const Ival &r) {
     const double l = c >= 0 ? fma(x.lo, c, r.lo) : fma(x.hi, c, r.lo);
     const double h = c >= 0 ? fma(x.hi, c, r.hi) : fma(x.lo, c, r.hi);
     if (c != c || l != l || h != h) return top();
     return wide(l, h);
 }
-__device__ __forceinline__ Ival divc(const Ival &a, double c) {
+SDF_IA Ival divc(const Ival &a, double c) {
     if (!(c != 0.0)) return top();                                   // 0 or NaN
     const double p = a.lo / c, q = a.hi / c;
     if (p != p || q != q) return top();
     return wide(fmin(p, q), fmax(p, q));
 }
-__device__ __forceinline__ Ival sqr(const Ival &a) {                 // x * x
+SDF_IA Ival sqr(const Ival &a) {                 // x * x
     const double l = a.lo * a.lo, h = a.hi * a.hi;
     if (l != l || h != h) return top();
     if (a.lo >= 0) return Ival{l, h};
     if (a.hi <= 0) return Ival{h, l};
     return Ival{0.0, fmax(l, h)};
 }
-__device__ __forceinline__ Ival sqrt_(const Ival &a) {
+SDF_IA Ival sqrt_(const Ival &a) {
     // only sums of squares get here: never negative, never NaN unless a bound already is
     if (bad(a) || a.lo < 0) return top();
     return Ival{sqrt(a.lo), sqrt(a.hi)};
 }
-__device__ __forceinline__ Ival abs_(const Ival &a) {
+SDF_IA Ival abs_(const Ival &a) {
     if (a.lo >= 0) return a;
     if (a.hi <= 0) return neg(a);
     return Ival{0.0, fmax(-a.lo, a.hi)};
 }
-__device__ __forceinline__ Ival min_(const Ival &a, const Ival &b) { return Ival{fmin(a.lo, b.lo), fmin(a.hi, b.hi)}; }
-__device__ __forceinline__ Ival max_(const Ival &a, const Ival &b) { return Ival{fmax(a.lo, b.lo), fmax(a.hi, b.hi)}; }
-__device__ __forceinline__ Ival maxc(const Ival &a, double c) { return Ival{fmax(a.lo, c), fmax(a.hi, c)}; }
-__device__ __forceinline__ Ival minc(const Ival &a, double c) { return Ival{fmin(a.lo, c), fmin(a.hi, c)}; }
-__device__ __forceinline__ Ival clip01(const Ival &a) { return Ival{fmin(fmax(a.lo, 0.0), 1.0), fmin(fmax(a.hi, 0.0), 1.0)}; }
+SDF_IA Ival min_(const Ival &a, const Ival &b) { return Ival{fmin(a.lo, b.lo), fmin(a.hi, b.hi)}; }
+SDF_IA Ival max_(const Ival &a, const Ival &b) { return Ival{fmax(a.lo, b.lo), fmax(a.hi, b.hi)}; }
+SDF_IA Ival maxc(const Ival &a, double c) { return Ival{fmax(a.lo, c), fmax(a.hi, c)}; }
+SDF_IA Ival minc(const Ival &a, double c) { return Ival{fmin(a.lo, c), fmin(a.hi, c)}; }
+SDF_IA Ival clip01(const Ival &a) { return Ival{fmin(fmax(a.lo, 0.0), 1.0), fmin(fmax(a.hi, 0.0), 1.0)}; }
 // sdf_interp.h len2 / len3: sqrt(x*x + y*y), sqrt((x*x + y*y) + z*z)
-__device__ __forceinline__ Ival len2(const Ival &x, const Ival &y) { return sqrt_(add(sqr(x), sqr(y))); }
-__device__ __forceinline__ Ival len3(const Ival &x, const Ival &y, const Ival &z) { return sqrt_(add(add(sqr(x), sqr(y)), sqr(z))); }
+SDF_IA Ival len2(const Ival &x, const Ival &y) { return sqrt_(add(sqr(x), sqr(y))); }
+SDF_IA Ival len3(const Ival &x, const Ival &y, const Ival &z) { return sqrt_(add(add(sqr(x), sqr(y)), sqr(z))); }
 // sdf_interp.h dot3 / dot2: fma(z, c, fma(y, b, x * a))
-__device__ __forceinline__ Ival dot3c(const Ival &x, const Ival &y, const Ival &z, double a, double b, double c) {
+SDF_IA Ival dot3c(const Ival &x, const Ival &y, const Ival &z, double a, double b, double c) {
     return fmac(z, c, fmac(y, b, mulc(x, a)));
 }
-__device__ __forceinline__ Ival dot2c(const Ival &x, const Ival &y, double a, double b) { return fmac(y, b, mulc(x, a)); }
+SDF_IA Ival dot2c(const Ival &x, const Ival &y, double a, double b) { return fmac(y, b, mulc(x, a)); }
+
+// ---- ops that go through libm, or whose floating-point form is not monotone term by term ------
+// hypot / atan2 / sin / cos are not correctly rounded on the device (ocml: a few ulp), so their
+// interval forms are the exact range of the real function over the box, widened by a margin
+// (1e-12 relative / absolute) that is four orders above any libm error and still far below anything
+// that decides a group (the culling test asks for |bound| > 1e-30, the operand test for a strict
+// gap).  Correctly rounded steps around them (a - delta, cos * d, x + t * c) stay exact corner forms.
+SDF_IA bool finite_(const Ival &a) { return a.lo - a.lo == 0.0 && a.hi - a.hi == 0.0; }
+SDF_IA Ival pad(const Ival &a, double rel, double abs_) {
+    if (bad(a)) return top();
+    const double m = rel * fmax(fabs(a.lo), fabs(a.hi)) + abs_;
+    return wide(a.lo - m, a.hi + m);
+}
+// a * b for two intervals: the rounded product is monotone in each factor, so the corners span it
+SDF_IA Ival mul(const Ival &a, const Ival &b) {
+    const double p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
+    if (p0 != p0 || p1 != p1 || p2 != p2 || p3 != p3) return top();
+    return wide(fmin(fmin(p0, p1), fmin(p2, p3)), fmax(fmax(p0, p1), fmax(p2, p3)));
+}
+SDF_IA Ival rint_(const Ival &a) { return wide(rint(a.lo), rint(a.hi)); }
+// s_clip(x, lo, hi) of sdf_interp.h for non-NaN x: min(max(x, lo), hi), monotone in x
+SDF_IA Ival clipc(const Ival &a, double lo, double hi) {
+    if (lo != lo || hi != hi) return top();
+    return wide(fmin(fmax(a.lo, lo), hi), fmin(fmax(a.hi, lo), hi));
+}
+// does [l, h] (already widened by the caller) contain p + k * period for an integer k?
+SDF_IA bool hits(double l, double h, double p, double period) { return ceil((l - p) / period) <= floor((h - p) / period); }
+// ranges of sin and cos over an angle interval
+SDF_IA void sincos_range(const Ival &ang, Ival &sn, Ival &cs) {
+    const double two_pi = 6.283185307179586, pi = 3.141592653589793;
+    sn = cs = Ival{-1.0, 1.0};
+    if (!finite_(ang) || !(ang.hi - ang.lo < 6.0)) { sn = cs = pad(sn, 0.0, 1e-12); return; }
+    double sl, cl, sh, ch;
+    ia_sincos(ang.lo, &sl, &cl);
+    ia_sincos(ang.hi, &sh, &ch);
+    sn = Ival{fmin(sl, sh), fmax(sl, sh)};
+    cs = Ival{fmin(cl, ch), fmax(cl, ch)};
+    const double l = ang.lo - 1e-9, h = ang.hi + 1e-9;
+    if (hits(l, h, 0.0, two_pi)) cs.hi = 1.0;
+    if (hits(l, h, pi, two_pi)) cs.lo = -1.0;
+    if (hits(l, h, 0.5 * pi, two_pi)) sn.hi = 1.0;
+    if (hits(l, h, -0.5 * pi, two_pi)) sn.lo = -1.0;
+    sn = pad(sn, 0.0, 1e-12);
+    cs = pad(cs, 0.0, 1e-12);
+}
+// circular_array, first half (sdf_interp.h L_CIRC_PREP, d3.py:379-392): d = hypot(x, y),
+// a = atan2(y, x) mod da (Python's floored modulo, so a lies in [0, da])
+SDF_IA void circ_prep(const Ival &x, const Ival &y, double da, Ival &d, Ival &a) {
+    d = a = top();
+    if (!finite_(x) || !finite_(y) || !(da > 0.0) || !(da < 7.0)) return;
+    d = pad(len2(x, y), 1e-12, 1e-300);
+    if (bad(d)) { d = top(); return; }
+    d.lo = fmax(d.lo, 0.0);
+    a = Ival{0.0, da};
+    // a box that touches the origin or the negative x axis (-0.0 counts) sees the jump of atan2
+    if (x.lo <= 0.0 && y.lo <= 0.0 && y.hi >= 0.0) return;
+    // elsewhere the angle has no stationary point and is monotone along every edge of the box
+    const double t0 = ia_atan2(y.lo, x.lo), t1 = ia_atan2(y.lo, x.hi), t2 = ia_atan2(y.hi, x.lo), t3 = ia_atan2(y.hi, x.hi);
+    const double tl = fmin(fmin(t0, t1), fmin(t2, t3)) - 1e-12, th = fmax(fmax(t0, t1), fmax(t2, t3)) + 1e-12;
+    if (!(tl <= th)) return;
+    const double kl = floor(tl / da), kh = floor(th / da);
+    if (kl != kh) return;                                   // the box straddles a sector boundary
+    const double lo = tl - kl * da, hi = th - kl * da;
+    if (!(lo > 1e-9) || !(da - hi > 1e-9)) return;          // (too close to a boundary to trust kl)
+    a = Ival{lo - 1e-12, hi + 1e-12};
+}
+// second half (L_CIRC_SET): p = (cos(a - delta) * d, sin(a - delta) * d, z)
+SDF_IA void circ_set(const Ival &d, const Ival &a, double delta, Ival &x, Ival &y) {
+    x = y = top();
+    if (!finite_(d) || !finite_(a) || delta != delta) return;
+    Ival sn, cs;
+    sincos_range(subc(a, delta), sn, cs);
+    x = mul(cs, d);
+    y = mul(sn, d);
+}
+// easing curves that are non-decreasing on [0, 1] and need no trigonometry (sdf_interp.h ease_apply,
+// ease.py): values at the end points, widened (the floating-point forms are not monotone to the ulp)
+SDF_IA double ease_value(int id, double t, bool &known) {
+    double u, v;
+    known = true;
+    switch (id) {
+    case EASE_linear: return t;
+    case EASE_in_quad: return t * t;
+    case EASE_out_quad: return -t * (t - 2.0);
+    case EASE_in_out_quad: u = 2.0 * t - 1.0; return t < 0.5 ? 2.0 * t * t : -0.5 * (u * (u - 2.0) - 1.0);
+    case EASE_in_cubic: return t * t * t;
+    case EASE_out_cubic: u = t - 1.0; return u * u * u + 1.0;
+    case EASE_in_out_cubic: u = t * 2.0; v = u - 2.0; return u < 1.0 ? 0.5 * u * u * u : 0.5 * (v * v * v + 2.0);
+    case EASE_in_quart: return t * t * t * t;
+    case EASE_out_quart: u = t - 1.0; return -(u * u * u * u - 1.0);
+    case EASE_in_out_quart: u = t * 2.0; v = u - 2.0; return u < 1.0 ? 0.5 * u * u * u * u : -0.5 * (v * v * v * v - 2.0);
+    case EASE_in_quint: return t * t * t * t * t;
+    case EASE_out_quint: u = t - 1.0; return u * u * u * u * u + 1.0;
+    case EASE_in_out_quint: u = t * 2.0; v = u - 2.0; return u < 1.0 ? 0.5 * u * u * u * u * u : 0.5 * (v * v * v * v * v + 2.0);
+    case EASE_in_circ: return -1.0 * (sqrt(fmax(1.0 - t * t, 0.0)) - 1.0);
+    case EASE_out_circ: u = t - 1.0; return sqrt(fmax(1.0 - u * u, 0.0));
+    case EASE_in_out_circ:
+        u = t * 2.0; v = u - 2.0;
+        return u < 1.0 ? -0.5 * (sqrt(fmax(1.0 - u * u, 0.0)) - 1.0) : 0.5 * (sqrt(fmax(1.0 - v * v, 0.0)) + 1.0);
+    case EASE_in_square: return t < 1.0 ? 0.0 : 1.0;
+    case EASE_out_square: return t > 0.0 ? 1.0 : 0.0;
+    case EASE_in_out_square: return t < 0.5 ? 0.0 : 1.0;
+    default: known = false; return 0.0;
+    }
+}
+SDF_IA Ival ease01(int id, const Ival &t) {
+    if (bad(t) || t.lo < 0.0 || t.hi > 1.0) return top();
+    bool k0, k1;
+    const double a = ease_value(id, t.lo, k0), b = ease_value(id, t.hi, k1);
+    if (!k0 || !k1 || a != a || b != b) return top();
+    return Ival{fmin(a, b) - 1e-12, fmax(a, b) + 1e-12};
+}
 
 }  // namespace ia
 
@@ -124,6 +248,7 @@ __host__ __device__ inline bool ia_has_form(uint32_t op) {
     case OP_COMB: case OP_TRANSLATE: case OP_SCALE: case OP_ROTATE: case OP_ELONGATE: case OP_TRANSLATE2: case OP_SCALE2:
     case OP_ROTATE2: case OP_ELONGATE2: case OP_REVOLVE: case OP_SETZ0: case OP_SAVE_P: case OP_LOAD_P: case OP_PUSH_D: case OP_NOP:
     case OP_NEG: case OP_ADDC: case OP_SUBC: case OP_MULC: case OP_SHELL: case OP_ADD_DS: case OP_EXT_PRE: case OP_EXT_POST:
+    case OP_REP_PREP: case OP_REP_SET: case OP_CIRC_PREP: case OP_CIRC_SET: case OP_BEND_LINEAR:
         return true;
     default: return false;
     }
@@ -223,7 +348,7 @@ __device__ __forceinline__ uint32_t mask_word(const uint32_t *m, int idx) {
 // lanes of the wave run the same tape (uniform control flow).  With DECIDE the 8 lanes of a batch
 // agree on which operands to drop with a ballot and every one of them records it: masks[0..8) skip
 // bits, masks[8..16) forced bits (without DECIDE rstart / lstart / masks are not touched).
-template <bool DECIDE>
+template <bool DECIDE, bool FULL>
 __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, const double *__restrict__ consts,
                                             const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart, int n_instr,
                                             Ival x, Ival y, Ival z, bool live, IaShared sh, int n_d, uint32_t *masks) {
@@ -306,6 +431,44 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
         case OP_EXT_POST: {
             const Ival w = dload(sa);
             acc = add(minc(max_(acc, w), 0.0), len2(maxc(acc, 0.0), maxc(w, 0.0))); break; }
+        case OP_BEND_LINEAR: {   // sdf_interp.h L_BEND_LINEAR (d3.py:435-445); the easing id is c[10]
+            const Ival tt = ease01((int)c[10], clip01(divc(dot3c(subc(x, c[0]), subc(y, c[1]), subc(z, c[2]), c[3], c[4], c[5]), c[6])));
+            x = add(x, mulc(tt, c[7])); y = add(y, mulc(tt, c[8])); z = add(z, mulc(tt, c[9])); break; }
+        case OP_REP_PREP: {      // L_REP_PREP (dn.py:80-112): PS[sa] = the cell index of p, per axis
+            const int dim = (int)c[0];
+            Ival idx[3] = {pt(0.0), pt(0.0), pt(0.0)};
+            const Ival pp[3] = {x, y, z};
+            for (int i = 0; i < 3; i++) {
+                if (i >= dim) continue;
+                const double s = c[1 + i];
+                Ival r = s != 0.0 ? rint_(divc(pp[i], s)) : pt(0.0);
+                if (c[4] != 0.0) r = clipc(r, -c[5 + i], c[5 + i]);
+                idx[i] = r;
+            }
+            sh.ps(sa, 0) = idx[0].lo; sh.ps(sa, 1) = idx[0].hi; sh.ps(sa, 2) = idx[1].lo; sh.ps(sa, 3) = idx[1].hi;
+            sh.ps(sa, 4) = idx[2].lo; sh.ps(sa, 5) = idx[2].hi; break; }
+        case OP_REP_SET: {       // L_REP_SET: p = p0 - spacing * (index + n); the index is taken as independent of p0
+            const uint32_t sb = (w1 >> 24) & 7u;
+            const Ival ax{sh.ps(sa, 0), sh.ps(sa, 1)}, ay{sh.ps(sa, 2), sh.ps(sa, 3)}, az{sh.ps(sa, 4), sh.ps(sa, 5)};
+            const Ival bx{sh.ps(sb, 0), sh.ps(sb, 1)}, by{sh.ps(sb, 2), sh.ps(sb, 3)}, bz{sh.ps(sb, 4), sh.ps(sb, 5)};
+            x = sub(ax, mulc(addc(bx, c[3]), c[0]));
+            y = sub(ay, mulc(addc(by, c[4]), c[1]));
+            z = sub(az, mulc(addc(bz, c[5]), c[2])); break; }
+        case OP_CIRC_PREP: case OP_CIRC_SET:   // circular_array (d3.py:379-392); trig-capable builds only
+            if constexpr (FULL) {
+                if (op == OP_CIRC_PREP) {          // L_CIRC_PREP: PS[sa] = (hypot(x, y), atan2(y, x) mod da, z)
+                    Ival d, a;
+                    circ_prep(x, y, c[0], d, a);
+                    sh.ps(sa, 0) = d.lo; sh.ps(sa, 1) = d.hi; sh.ps(sa, 2) = a.lo; sh.ps(sa, 3) = a.hi;
+                    sh.ps(sa, 4) = z.lo; sh.ps(sa, 5) = z.hi;
+                } else {                           // L_CIRC_SET: p = (cos(a - delta) * d, sin(a - delta) * d, z)
+                    const Ival d{sh.ps(sa, 0), sh.ps(sa, 1)}, a{sh.ps(sa, 2), sh.ps(sa, 3)};
+                    circ_set(d, a, c[0], x, y);
+                    z = Ival{sh.ps(sa, 4), sh.ps(sa, 5)};
+                }
+                break;
+            }
+            [[fallthrough]];
         default:
             // an op without an interval form: everything it may write becomes unknown
             x = y = z = top(); acc = top();

@@ -526,3 +526,77 @@ def test_prepass_prunes_the_canonical_example(ns, eng):
     finally:
         eng.set_prune(True)
     assert np.array_equal(p1, p0)
+
+
+# ---- interval forms of circular_array / repeat / bend_linear (sdf_interval.h): the pruned and culled
+# execution against the plain one on the same device (same libm), bit for bit ----
+
+def _both_ways(eng, f, X, Y, Z, sparse=True):
+    res = []
+    for on in (True, False):
+        eng.set_prune(on); eng.set_cull(on)
+        try:
+            m = eng.generate(f, X, Y, Z, 32, sparse)
+            res.append((m.points(), m.kinds(), m.stats()))
+            m.close()
+        finally:
+            eng.set_prune(True); eng.set_cull(True)
+    return res
+
+
+@pytest.mark.parametrize('name,samples', [('ex_gearlike', 2 ** 24), ('ex_weave', 2 ** 23), ('ex_knurling', 2 ** 22)])
+def test_interval_passes_on_trig_models_are_bit_identical(name, samples, ns, eng):
+    f = fixtures.build(name, ns)
+    bounds = core._estimate_bounds(f)
+    X, Y, Z, _ = core.grid_axes(bounds, samples=samples)
+    (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, f, X, Y, Z)
+    assert s0['n_pruned_instrs'] == 0 and s0['n_sampled_voxels'] == s0['n_eval_voxels']
+    assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
+    if name != 'ex_knurling':     # (twist has no interval form: knurling is neither pruned nor culled)
+        assert s1['n_pruned_instrs'] > 0.1 * s1['n_batch_instrs']
+        assert s1['n_sampled_voxels'] < 0.8 * s1['n_eval_voxels']
+
+
+def _random_array_tree(rng, ns):
+    r = lambda lo, hi: float(rng.uniform(lo, hi))
+    parts = []
+    for _ in range(int(rng.integers(1, 4))):
+        k = int(rng.integers(0, 4))
+        if k == 0: f = ns['sphere'](r(0.1, 0.3))
+        elif k == 1: f = ns['rounded_box']((r(0.2, 0.8), r(0.1, 0.4), r(0.1, 0.4)), r(0.01, 0.05))
+        elif k == 2: f = ns['capsule']((-r(0.1, 0.4), 0, 0), (r(0.1, 0.4), 0, r(-0.2, 0.2)), r(0.05, 0.15))
+        else: f = ns['cylinder'](r(0.05, 0.2)) & ns['slab'](z0=-r(0.1, 0.5), z1=r(0.1, 0.5))
+        w = int(rng.integers(0, 5))
+        if w == 0:
+            f = f.circular_array(int(rng.integers(1, 12)), r(0.0, 1.2))
+        elif w == 1:
+            e = (ns['ease'].linear, ns['ease'].in_out_quad, ns['ease'].out_cubic, ns['ease'].in_out_circ,
+                 ns['ease'].in_out_square, ns['ease'].out_bounce)[int(rng.integers(0, 6))]
+            f = f.bend_linear((-r(0.1, 0.5), 0, 0), (r(0.1, 0.5), 0, 0), (0, r(-0.3, 0.3), r(-0.3, 0.3)), e)
+        elif w == 2:
+            pad = int(rng.integers(0, 2))
+            if rng.random() < 0.5:
+                f = f.repeat((r(0.5, 1.2), r(0.5, 1.2), 0), padding=pad)
+            else:
+                f = f.repeat(r(0.6, 1.3), count=int(rng.integers(0, 3)), padding=pad)
+        elif w == 3:
+            f = f.translate((r(0.2, 0.8), 0, 0)).circular_array(int(rng.integers(2, 9)), 0).repeat((2.0, 2.0, 0), padding=1)
+        if rng.random() < 0.5:
+            f = f.rotate(r(0, 3.0), (r(-1, 1), r(-1, 1), 1.0)).translate((r(-0.5, 0.5), r(-0.5, 0.5), r(-0.3, 0.3)))
+        parts.append(f)
+    f = parts[0]
+    for g in parts[1:]:
+        c = int(rng.integers(0, 4))
+        f = (f | g) if c == 0 else ((f - g) if c == 1 else (ns['union'](f, g, k=r(0.05, 0.2)) if c == 2 else (f | g.translate((0.3, 0.2, 0.1)))))
+    return f & ns['sphere'](1.45)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_interval_passes_with_arrays_and_bends_random(seed, ns, eng):
+    rng = np.random.default_rng(7000 + seed)
+    f = _random_array_tree(rng, ns)
+    n = 93 + 5 * (seed % 4)
+    X = np.arange(-1.5, 1.5, 3.0 / n); Y = np.arange(-1.5, 1.5, 3.0 / n) + 0.003; Z = np.arange(-1.5, 1.5, 3.0 / n) - 0.001
+    (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, f, X, Y, Z, sparse=seed % 3 != 0)
+    assert s0['n_pruned_instrs'] == 0
+    assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
