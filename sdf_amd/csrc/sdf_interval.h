@@ -294,7 +294,7 @@ __device__ __noinline__ Ival ia_leaf(uint32_t op, const double *c, const Ival &x
 }
 
 // interval of post(d1, d2) (sdf_interp.h post_combine)
-__device__ __forceinline__ Ival ia_post(uint32_t post, const Ival &d1, const Ival &d2, double K) {
+SDF_IA Ival ia_post(uint32_t post, const Ival &d1, const Ival &d2, double K) {
     using namespace ia;
     switch (post) {
     case POST_SET: return d2;
@@ -304,14 +304,18 @@ __device__ __forceinline__ Ival ia_post(uint32_t post, const Ival &d1, const Iva
     case POST_BLEND: return add(mulc(d2, K), mulc(d1, 1.0 - K));
     default: break;
     }
-    // polynomial smooth min / max (dn.py:7-50), for K > 0: with e = the second operand (negated for
-    // a difference) and h the clipped blend weight, the result is min(d1, e) - K (1 - h')^2 resp.
-    // max(d1, e) + K (1 - h')^2 with h' in [1/2, 1], i.e. within K / 4 of the hard result on its far
-    // side.  Bounded analytically, with a margin far above the rounding of the few operations.
+    // polynomial smooth min / max (dn.py:7-50), for K > 0: with e = the second operand (negated for a
+    // difference) and t = (e - d1) / K, the blend weight is h = clip((1 + t) / 2) and the result is
+    //     min(d1, e) - (K / 4) (1 - |t|)^2   resp.   max(d1, e) + (K / 4) (1 - |t|)^2      for |t| <= 1,
+    // the hard result beyond.  The correction falls with |t|, so the range of |e - d1| over the box
+    // bounds it from both sides; the margin is far above the rounding of the few operations.
     if (!(K > 0.0) || bad(d1) || bad(d2)) return top();
     const Ival e = post == POST_SDIFF ? neg(d2) : d2;
+    const Ival ad = abs_(sub(e, d1));
+    const double tmin = fmin(ad.lo / K, 1.0), tmax = fmin(ad.hi / K, 1.0);
+    const double cmax = 0.25 * K * (1.0 - tmin) * (1.0 - tmin), cmin = 0.25 * K * (1.0 - tmax) * (1.0 - tmax);
     Ival r = post == POST_SUNION ? min_(d1, e) : max_(d1, e);
-    if (post == POST_SUNION) r.lo -= 0.25 * K; else r.hi += 0.25 * K;
+    if (post == POST_SUNION) { r.lo -= cmax; r.hi -= cmin; } else { r.lo += cmin; r.hi += cmax; }
     const double m = 1e-9 * (fabs(r.lo) + fabs(r.hi) + K);
     return fix(Ival{r.lo - m, r.hi + m});
 }

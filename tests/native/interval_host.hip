@@ -110,6 +110,26 @@ int main() {
             CHECK(in(r, idx) && in(q, v), "repeat: p[%g,%g] s=%g u=%g idx=%g v=%g not in [%g,%g]", p.lo, p.hi, s, u, idx, v, q.lo, q.hi);
         }
     }
+    // ---- polynomial smooth union / difference / intersection (sdf_interp.h post_combine) ----
+    for (int it = 0; it < 300000; it++) {
+        const double K = std::pow(10.0, pick(-2, 0.3)), c1 = pick(-2, 2), c2 = it % 3 ? pick(-2, 2) : c1 + pick(-1.5, 1.5) * K;
+        const double w = std::pow(10.0, pick(-4, 0));
+        const Ival d1{c1 - w * U(rng), c1 + w * U(rng)}, d2{c2 - w * U(rng), c2 + w * U(rng)};
+        const uint32_t posts[3] = {POST_SUNION, POST_SDIFF, POST_SINTER};
+        for (int q = 0; q < 3; q++) {
+            const Ival r = ia_post(posts[q], d1, d2, K);
+            for (int k = 0; k < 10; k++) {
+                const double a = k == 0 ? d1.lo : (k == 1 ? d1.hi : pick(d1.lo, d1.hi)), b = k == 0 ? d2.hi : (k == 1 ? d2.lo : pick(d2.lo, d2.hi));
+                auto clip = [](double x) { return fmin(fmax(x, 0.0), 1.0); };
+                double h, m, v;
+                if (q == 0) { h = clip(0.5 + 0.5 * (b - a) / K); m = b + (a - b) * h; v = m - K * h * (1.0 - h); }
+                else if (q == 1) { h = clip(0.5 - 0.5 * (b + a) / K); m = a + (-b - a) * h; v = m + K * h * (1.0 - h); }
+                else { h = clip(0.5 - 0.5 * (b - a) / K); m = b + (a - b) * h; v = m + K * h * (1.0 - h); }
+                CHECK(in(r, v), "smooth %d: K=%g d1[%g,%g] d2[%g,%g] a=%g b=%g v=%.17g not in [%.17g,%.17g]", q, K, d1.lo, d1.hi, d2.lo, d2.hi, a, b, v, r.lo, r.hi);
+            }
+            tight_sum += 0; 
+        }
+    }
     // ---- interval product ----
     for (int it = 0; it < 100000; it++) {
         const Ival a{pick(-3, 3), 0}, b{pick(-3, 3), 0};
