@@ -530,16 +530,21 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     t->ia_complete = true;
     for (uint32_t i = 0; i < n_words; i += 2) t->ia_complete = t->ia_complete && ia_has_form(code[i] & 255u);
     t->n_p = n_p; t->n_d = n_d;
-    std::vector<float> c32(n_consts);
-    for (uint32_t i = 0; i < n_consts; i++) c32[i] = (float)consts[i];
+    // two more constants behind the tape's own: a K slot and +0.0, the operand of the `acc + (+0.0)` that a
+    // decided smooth combine turns into (sdf_interval.h compact_tape); an instruction with constant
+    // offset n_consts reads it as c[0]
+    std::vector<double> c64(consts, consts + n_consts);
+    c64.push_back(0.0); c64.push_back(0.0);
+    std::vector<float> c32(c64.size());
+    for (size_t i = 0; i < c64.size(); i++) c32[i] = (float)c64[i];
     std::vector<uint32_t> pcode(code, code + n_words);   // + one more END: the interpreter looks one instruction ahead
     pcode.push_back(code[n_words - 2]); pcode.push_back(code[n_words - 1]);
     HIPCHK(hipMalloc((void **)&t->d_code, pcode.size() * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&t->d_c64, n_consts * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&t->d_c32, n_consts * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&t->d_c64, c64.size() * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&t->d_c32, c32.size() * sizeof(float)));
     HIPCHK(hipMemcpy(t->d_code, pcode.data(), pcode.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(t->d_c64, consts, n_consts * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(t->d_c32, c32.data(), n_consts * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->d_c64, c64.data(), c64.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->d_c32, c32.data(), c32.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = t;
     return 0;
 }
@@ -758,7 +763,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     };
     const uint32_t n_instr = t->n_words / 2;
     const bool intervals_ok = precision == SDF_PRECISION_F64 && monotone(X, nx) && monotone(Y, ny) && monotone(Z, nz);
-    const bool pruning = c->prune && t->d_rstart && n_instr <= 256 && intervals_ok;
+    const bool pruning = c->prune && t->d_rstart && n_instr <= 256 && intervals_ok && t->n_consts < 0xFFFFF0u;
     // 64-bit words per batch tape: the instructions, one more END, the length; whole 64-byte lines
     const int tape_stride = (int)((n_instr + 2 + 7) & ~7u);
     PruneArgs pa = {};
@@ -771,6 +776,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         pa.n_instr = (int)n_instr; pa.n_p = std::max(t->n_p, 1u); pa.n_d = std::max(t->n_d, 1u);
         pa.masks_out = (uint32_t *)m->prune.p; pa.tapes_out = (unsigned long long *)m->tapes.p; pa.tape_stride = tape_stride;
         pa.first_block = (int)skip_blocks;
+        pa.zero_off = t->n_consts;
         prune_blocks = (unsigned)(((long long)nb * 8 + PRUNE_BLOCK - 1) / PRUNE_BLOCK);
         prune_lds = prune_lds_bytes(pa.n_p, pa.n_d);
     }

@@ -320,12 +320,29 @@ SDF_IA Ival ia_post(uint32_t post, const Ival &d1, const Ival &d2, double K) {
     return fix(Ival{r.lo - m, r.hi + m});
 }
 
-// 0 keep both, 1 the right operand never wins, 2 the left operand never wins
-__device__ __forceinline__ int ia_decide(uint32_t post, const Ival &left, const Ival &right) {
+// 0 keep both, 1 the right operand never wins, 2 the left operand never wins.
+// The polynomial smooth forms (sdf_interp.h post_combine) have ONE exact direction each: when the
+// blend weight h clips to 0 over the whole box,
+//     smooth union / intersection:  m = d2 + (d1 - d2) * 0 = d2 + (+-0),  result = m -+ K * 0 * 1  ->  d2 + (+0.0)
+//     smooth difference:            m = d1 + (-d2 - d1) * 0 = d1 + (-0),  result = m + K * 0 * 1   ->  d1 + (+0.0)
+// bit for bit (the other direction, h = 1, gives d2 + (d1 - d2), which is not d1 in floating point).  h is
+// evaluated here with the interpreter's own operations on the end points (all monotone), so "h == 0
+// everywhere" is exact; compact_tape then replaces the combine by `+ (+0.0)` on the surviving operand.
+SDF_IA int ia_decide(uint32_t post, const Ival &left, const Ival &right, double K) {
+    using namespace ia;
     switch (post) {
     case POST_UNION: return right.lo > left.hi ? 1 : (left.lo > right.hi ? 2 : 0);
     case POST_INTER: return right.hi < left.lo ? 1 : (left.hi < right.lo ? 2 : 0);
     case POST_DIFF: return -right.lo < left.lo ? 1 : (left.hi < -right.hi ? 2 : 0);       // max(left, -right)
+    case POST_SUNION: case POST_SINTER: case POST_SDIFF: {
+        if (!(K > 0.0) || !finite_(left) || !finite_(right)) return 0;
+        Ival e;
+        if (post == POST_SUNION) e = addc(divc(mulc(sub(right, left), 0.5), K), 0.5);       // 0.5 + 0.5 * (d2 - d1) / K
+        else if (post == POST_SINTER) e = csub(0.5, divc(mulc(sub(right, left), 0.5), K));  // 0.5 - 0.5 * (d2 - d1) / K
+        else e = csub(0.5, divc(mulc(add(right, left), 0.5), K));                           // 0.5 - 0.5 * (d2 + d1) / K
+        if (bad(e) || !(e.hi <= 0.0)) return 0;
+        return post == POST_SDIFF ? 1 : 2;
+    }
     default: return 0;
     }
 }
@@ -387,10 +404,15 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
             int rs = 0xFFFF, ls = 0xFFFF;
             if constexpr (DECIDE) { rs = rstart[ip]; ls = lstart[ip]; }
             if (DECIDE && rs != 0xFFFF && ls != 0xFFFF && rs <= ip && ls <= rs) {
-                const int d = live ? ia_decide(post, left, right) : 3;     // dead lanes agree with everything
+                const int d = live ? ia_decide(post, left, right, c[-1]) : 3;     // dead lanes agree with everything
                 const unsigned long long b1 = __ballot(d == 1 || d == 3), b2 = __ballot(d == 2 || d == 3);
-                if (((b1 >> gbase) & 0xFFull) == 0xFFull) mask_set_range(masks, rs, ip);
-                else if (((b2 >> gbase) & 0xFFull) == 0xFFull && rs > ls) {
+                if (((b1 >> gbase) & 0xFFull) == 0xFFull) {
+                    if (post < POST_SUNION) mask_set_range(masks, rs, ip);
+                    else {                                   // smooth: the combine itself stays, as `+ (+0.0)`
+                        if (rs < ip) mask_set_range(masks, rs, ip - 1);
+                        mask_set_bit(masks + 8, ip);
+                    }
+                } else if (((b2 >> gbase) & 0xFFull) == 0xFFull && rs > ls) {
                     mask_set_range(masks, ls, rs - 1);
                     mask_set_bit(masks + 8, ip);
                 }
@@ -493,14 +515,16 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
 // The batch's tape: the model's tape without the skipped instructions.
 //   * a skipped instruction that carries prefixes leaves a NOP with those prefixes (the point / distance
 //     moves of the surrounding constructs ride on their neighbours, tape.py peephole);
+//   * a decided smooth combine becomes `acc + (+0.0)` behind the surviving operand (ia_decide);
 //   * a forced hard min / max IS its right operand: post becomes SET (a forced COMB would then copy acc
 //     onto itself and disappears); a forced difference is -right: SET, then NEG.  Forcing always skips at
 //     least one instruction of the left chain, so the result never grows beyond the original length.
 // Every lane of a batch holds the same masks and runs this loop (uniform: scalar loads of the
 // tape); only lane 0 of the batch stores.  Returns the number of instructions (END included).
 __device__ __forceinline__ int compact_tape(const unsigned long long *__restrict__ code64, int n_instr, const uint32_t *masks,
-                                            unsigned long long *__restrict__ out, bool store) {
+                                            unsigned long long *__restrict__ out, bool store, uint32_t zero_off) {
     const unsigned long long PREFIX = 0x00FFF800ull, POSTM = 0x700ull;
+    const unsigned long long ADD0 = ((unsigned long long)zero_off << 32) | OP_ADDC;   // acc + (+0.0)
     int n = 0;
     auto put = [&](unsigned long long w) { if (store) out[n] = w; n++; };
     uint32_t skip_w = 0, force_w = 0;
@@ -514,12 +538,16 @@ __device__ __forceinline__ int compact_tape(const unsigned long long *__restrict
             if (w & PREFIX) put((w & PREFIX) | OP_NOP);
         } else if (!forced) {
             put(w);
+        } else if (post == POST_SDIFF) {                      // smooth difference whose right operand was dropped
+            put((w & PREFIX) | ADD0);
         } else if (op == OP_COMB) {
             if (post == POST_DIFF) put((w & PREFIX) | OP_NEG);
+            else if (post >= POST_SUNION) put((w & PREFIX) | ADD0);
             else if (w & PREFIX) put((w & PREFIX) | OP_NOP);
         } else {
             put(w & ~POSTM);                                  // a leaf: post = SET
             if (post == POST_DIFF) put(OP_NEG);
+            else if (post >= POST_SUNION) put(ADD0);
         }
     }
     return n;

@@ -15,6 +15,7 @@ struct PruneArgs {
     unsigned long long *tapes_out;   // [batch][tape_stride]: the batch's own tape; word tape_stride-1 = its length
     int tape_stride;
     int first_block;                 // workgroups >= first_block of the prepass kernel run the interval pass
+    uint32_t zero_off;               // consts[zero_off + 1] == +0.0 (appended by sdf_tape_create)
 };
 
 // The interval pass of one workgroup of the prepass kernel (k_skip, sdf_hip.hip): 8 lanes per batch
@@ -45,7 +46,7 @@ __device__ __forceinline__ void prune_block(const uint32_t *__restrict__ code, c
     ia_run_tape<true, FULL>(code, pa.consts, pa.rstart, pa.lstart, pa.n_instr, bx, by, bz, live, IaShared{lds, pa.n_p, PRUNE_BLOCK}, pa.n_d, masks);
     const bool store = live && oct == 0;
     unsigned long long *out = pa.tapes_out + (size_t)(live ? b : 0) * pa.tape_stride;
-    const int n = compact_tape(reinterpret_cast<const unsigned long long *>(code), pa.n_instr, masks, out, store);
+    const int n = compact_tape(reinterpret_cast<const unsigned long long *>(code), pa.n_instr, masks, out, store, pa.zero_off);
     if (store) {
         out[n] = out[n - 1];                                    // the interpreter looks one instruction ahead
         out[pa.tape_stride - 1] = (unsigned long long)n;

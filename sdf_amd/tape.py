@@ -205,8 +205,8 @@ class _Lowering:
 
     def note_combine(self, post, rstart):
         """the instruction just emitted folds a right operand (instructions rstart..here-1) into a
-        left one (instructions chain start..rstart-1) with a hard min / max"""
-        if post in ('UNION', 'DIFF', 'INTER') and rstart is not None and self.chain:
+        left one (instructions chain start..rstart-1) with a hard or polynomial-smooth min / max"""
+        if post in ('UNION', 'DIFF', 'INTER', 'SUNION', 'SDIFF', 'SINTER') and rstart is not None and self.chain:
             self.meta[-1] = (rstart, self.chain[-1])
 
     def palloc(self):
