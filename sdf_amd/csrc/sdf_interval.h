@@ -249,6 +249,8 @@ __host__ __device__ inline bool ia_has_form(uint32_t op) {
     case OP_ROTATE2: case OP_ELONGATE2: case OP_REVOLVE: case OP_SETZ0: case OP_SAVE_P: case OP_LOAD_P: case OP_PUSH_D: case OP_NOP:
     case OP_NEG: case OP_ADDC: case OP_SUBC: case OP_MULC: case OP_SHELL: case OP_ADD_DS: case OP_EXT_PRE: case OP_EXT_POST:
     case OP_REP_PREP: case OP_REP_SET: case OP_CIRC_PREP: case OP_CIRC_SET: case OP_BEND_LINEAR:
+    case OP_TWIST: case OP_BEND: case OP_BEND_RADIAL: case OP_TRANS_LIN_PRE: case OP_TRANS_RAD_PRE: case OP_TRANS_MIX:
+    case OP_EXTTO_PRE: case OP_EXTTO_MIX: case OP_SLICE_POST:
         return true;
     default: return false;
     }
@@ -480,6 +482,42 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
             x = sub(ax, mulc(addc(bx, c[3]), c[0]));
             y = sub(ay, mulc(addc(by, c[4]), c[1]));
             z = sub(az, mulc(addc(bz, c[5]), c[2])); break; }
+        case OP_TRANS_LIN_PRE:   // L_TRANS_LIN_PRE (d3.py:459-470): DS[sa] = ease(clip(dot(p - p0, v) / |v|^2))
+            dsave(sa, ease01((int)c[7], clip01(divc(dot3c(subc(x, c[0]), subc(y, c[1]), subc(z, c[2]), c[3], c[4], c[5]), c[6])))); break;
+        case OP_TRANS_MIX: {     // L_TRANS_MIX: t * d2 + (1 - t) * d1
+            const uint32_t sb = (w1 >> 24) & 7u;
+            const Ival tt = dload(sa), dd = dload(sb);
+            acc = add(mul(tt, acc), mul(csub(1.0, tt), dd)); break; }
+        case OP_EXTTO_PRE:       // L_EXTTO_PRE (d2.py:274)
+            dsave(sa, ease01((int)c[1], addc(clipc(divc(z, c[0]), -0.5, 0.5), 0.5))); break;
+        case OP_EXTTO_MIX: {     // L_EXTTO_MIX (d2.py:275): d1 + (d2 - d1) * t
+            const uint32_t sb = (w1 >> 24) & 7u;
+            const Ival dd1 = dload(sb), tt = dload(sa);
+            acc = add(dd1, mul(sub(acc, dd1), tt)); break; }
+        case OP_SLICE_POST: {    // L_SLICE_POST (d3.py:515-519): A <= 0 ? -acc : A
+            const Ival A = dload(sa), B = neg(acc);
+            if (bad(A) || bad(B)) acc = top();
+            else if (A.hi <= 0.0) acc = B;
+            else if (A.lo > 0.0) acc = A;
+            else acc = Ival{fmin(A.lo, B.lo), fmax(A.hi, B.hi)};
+            break; }
+        case OP_TWIST: case OP_BEND: case OP_BEND_RADIAL: case OP_TRANS_RAD_PRE:   // trig-capable builds only
+            if constexpr (FULL) {
+                if (op == OP_TWIST || op == OP_BEND) {      // L_TWIST / L_BEND (d3.py:407-433): rotation by c0 * z resp. c0 * x
+                    Ival sn, cs;
+                    sincos_range(mulc(op == OP_TWIST ? z : x, c[0]), sn, cs);
+                    const Ival nx = sub(mul(cs, x), mul(sn, y)), ny = add(mul(sn, x), mul(cs, y));
+                    x = nx; y = ny;
+                } else {                                    // hypot(x, y) goes through libm: widened
+                    Ival r = finite_(x) && finite_(y) ? pad(len2(x, y), 1e-12, 1e-300) : top();
+                    if (!bad(r)) r.lo = fmax(r.lo, 0.0);
+                    const Ival tt = clip01(divc(subc(r, c[0]), c[1]));
+                    if (op == OP_BEND_RADIAL) z = sub(z, mulc(ease01((int)c[3], tt), c[2]));   // L_BEND_RADIAL (d3.py:447-457)
+                    else dsave(sa, ease01((int)c[2], tt));                                    // L_TRANS_RAD_PRE (d3.py:472-481)
+                }
+                break;
+            }
+            [[fallthrough]];
         case OP_CIRC_PREP: case OP_CIRC_SET:   // circular_array (d3.py:379-392); trig-capable builds only
             if constexpr (FULL) {
                 if (op == OP_CIRC_PREP) {          // L_CIRC_PREP: PS[sa] = (hypot(x, y), atan2(y, x) mod da, z)

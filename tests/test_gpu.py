@@ -552,7 +552,7 @@ def test_interval_passes_on_trig_models_are_bit_identical(name, samples, ns, eng
     (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, f, X, Y, Z)
     assert s0['n_pruned_instrs'] == 0 and s0['n_sampled_voxels'] == s0['n_eval_voxels']
     assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
-    if name != 'ex_knurling':     # (twist has no interval form: knurling is neither pruned nor culled)
+    if True:
         assert s1['n_pruned_instrs'] > (0.1 if name == 'ex_weave' else 0.01) * s1['n_batch_instrs']
         assert s1['n_sampled_voxels'] < 0.8 * s1['n_eval_voxels']
 
@@ -566,7 +566,15 @@ def _random_array_tree(rng, ns):
         elif k == 1: f = ns['rounded_box']((r(0.2, 0.8), r(0.1, 0.4), r(0.1, 0.4)), r(0.01, 0.05))
         elif k == 2: f = ns['capsule']((-r(0.1, 0.4), 0, 0), (r(0.1, 0.4), 0, r(-0.2, 0.2)), r(0.05, 0.15))
         else: f = ns['cylinder'](r(0.05, 0.2)) & ns['slab'](z0=-r(0.1, 0.5), z1=r(0.1, 0.5))
-        w = int(rng.integers(0, 5))
+        w = int(rng.integers(0, 10))
+        eases = (ns['ease'].linear, ns['ease'].in_out_quad, ns['ease'].out_cubic, ns['ease'].in_out_circ,
+                 ns['ease'].in_out_square, ns['ease'].out_bounce, ns['ease'].in_sine)
+        e2 = eases[int(rng.integers(0, len(eases)))]
+        if w == 5: f = f.twist(r(-3.0, 3.0))
+        elif w == 6: f = f.bend(r(-2.0, 2.0))
+        elif w == 7: f = f.bend_radial(r(0.1, 0.4), r(0.5, 1.0), r(-0.4, 0.4), e2)
+        elif w == 8: f = f.transition_linear(ns['sphere'](r(0.2, 0.5)), (0, 0, -r(0.1, 0.5)), (0, 0, r(0.1, 0.5)), e2)
+        elif w == 9: f = f.transition_radial(ns['box'](r(0.3, 0.7)), r(0.0, 0.3), r(0.4, 1.0), e2)
         if w == 0:
             f = f.circular_array(int(rng.integers(1, 12)), r(0.0, 1.2))
         elif w == 1:
@@ -591,7 +599,7 @@ def _random_array_tree(rng, ns):
     return f & ns['sphere'](1.45)
 
 
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', range(24))
 def test_interval_passes_with_arrays_and_bends_random(seed, ns, eng):
     rng = np.random.default_rng(7000 + seed)
     f = _random_array_tree(rng, ns)
