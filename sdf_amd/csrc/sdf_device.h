@@ -389,6 +389,18 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
     return ntl;
 }
 
+// Stores of the soup.  Marking them non-temporal (so that 200 MB of output would not flush the parked
+// triangles out of the XCD's L2) was measured and is OFF: 8-byte non-temporal stores are not merged in
+// L2, WRITE_SIZE doubled (368 -> 749 MB per launch) and the step got 14 % slower.
+#ifndef SDF_SOUP_NT
+#define SDF_SOUP_NT 0
+#endif
+#if SDF_SOUP_NT
+#define SDF_SOUP_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define SDF_SOUP_STORE(PTR, VAL) (*(PTR) = (VAL))
+#endif
+
 template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
     typedef Vec<T, NS> V;
@@ -437,18 +449,24 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (pbase != ~0ull && pbase + (unsigned long long)pend_total <= a.out_cap) {
             double *dst0 = a.out + pbase * 9ull;
             const double pof0 = pend_xf[0], pof1 = pend_xf[1], pof2 = pend_xf[2], psc0 = pend_xf[3], psc1 = pend_xf[4], psc2 = pend_xf[5];
-            // 12 coordinates (four points) per thread and pass: three 16-byte loads in flight, then the
-            // stores; coordinate e belongs to axis e % 3
-            const int n9 = pend_total * 9, nchunk = n9 / 12;
+            // consecutive lanes move consecutive coordinates (4-byte loads, 8-byte stores: whole cache lines per
+            // instruction on both sides); coordinate e belongs to axis e % 3, so the axis of a thread's k-th
+            // coordinate is (its first axis + k * (BLOCK % 3)) % 3.  Eight loads in flight per thread.
+            static_assert(BLOCK % 3 == 1 || BLOCK % 3 == 2, "axis rotation below");
+            const int n9 = pend_total * 9;
             const double sc[3] = {psc0, psc1, psc2}, of[3] = {pof0, pof1, pof2};
-            for (int ch = tid; ch < nchunk; ch += BLOCK) {
-                const float4 *src = reinterpret_cast<const float4 *>(my_park) + (size_t)ch * 3;
-                const float4 v0 = src[0], v1 = src[1], v2 = src[2];
-                const float f[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-                double *d = dst0 + (size_t)ch * 12;
-                SDF_UNROLL for (int q = 0; q < 12; q++) d[q] = (double)f[q] * sc[q % 3] + of[q % 3];
+            constexpr int U = 8;
+            for (int e0 = tid; e0 < n9; e0 += BLOCK * U) {
+                float f[U];
+                SDF_UNROLL for (int k = 0; k < U; k++) f[k] = my_park[min(e0 + k * BLOCK, n9 - 1)];
+                int ax = e0 % 3;
+                SDF_UNROLL
+                for (int k = 0; k < U; k++) {
+                    const double s_ = ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2]), o_ = ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]);
+                    if (e0 + k * BLOCK < n9) SDF_SOUP_STORE(dst0 + e0 + k * BLOCK, (double)f[k] * s_ + o_);
+                    ax += BLOCK % 3; if (ax >= 3) ax -= 3;
+                }
             }
-            for (int e = nchunk * 12 + tid; e < n9; e += BLOCK) dst0[e] = (double)my_park[e] * sc[e % 3] + of[e % 3];
         }
         pend_w = -1;
         __syncthreads();   // (bcast is reused)
@@ -697,16 +715,19 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     mc_vertex(corner, lyz, lz, i0, i1, i2, tt[1], o + 3);
                     mc_vertex(corner, lyz, lz, i0, i1, i2, tt[2], o + 6);
                 }
-                if (parking) {
+                if (parking) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
+                    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
                     float *dst = park0 + (size_t)t * 9;
-                    SDF_UNROLL for (int q = 0; q < 9; q++) dst[q] = o[q];
+                    *reinterpret_cast<f4u *>(dst) = f4u{o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<f4u *>(dst + 4) = f4u{o[4], o[5], o[6], o[7]};
+                    dst[8] = o[8];
                 } else {
                     double *dst = dst0 + (size_t)t * 9;
                     SDF_UNROLL
                     for (int q = 0; q < 9; q += 3) {
-                        dst[q] = (double)o[q] * sc0 + of0;
-                        dst[q + 1] = (double)o[q + 1] * sc1 + of1;
-                        dst[q + 2] = (double)o[q + 2] * sc2 + of2;
+                        SDF_SOUP_STORE(dst + q, (double)o[q] * sc0 + of0);
+                        SDF_SOUP_STORE(dst + q + 1, (double)o[q + 1] * sc1 + of1);
+                        SDF_SOUP_STORE(dst + q + 2, (double)o[q + 2] * sc2 + of2);
                     }
                 }
             }
