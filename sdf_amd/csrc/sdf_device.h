@@ -512,25 +512,33 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             culled = n != 0xFFFF;
             if (culled) {
                 ntl = n;
-                // the samples of decided groups get +-1 (those of undecided groups are all evaluated afterwards,
-                // whatever is written to them here)
+                // Only SIGNS matter at the samples of decided groups (marching cubes reads values at the corners
+                // of cells with a sign change, and those lie in undecided groups): their bits of the sign-bit
+                // volume are set here straight from the group states -- no float is written for them -- and the
+                // evaluated samples OR theirs in as they are stored (1c).  A sample owned by an undecided group
+                // starts at 0; an evaluated sample owned by a decided group has the group's sign anyway.
                 const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
-                if (tt.regular) {
-                    // a thread per row of 33 samples along z: the 8 group states of the row in one read
-                    for (int r = tid; r < 33 * 33; r += BLOCK) {
-                        const int ix = fast_div(r, 1.0f / 33.0f), iy = r - 33 * ix;
-                        const unsigned long long st8 = *reinterpret_cast<const unsigned long long *>(gstate + ((min(ix, 31) >> 2) * 8 + (min(iy, 31) >> 2)) * 8);
-                        float *row = vol + r * 33;
-                        SDF_UNROLL
-                        for (int iz = 0; iz < 33; iz++) row[iz] = ((st8 >> (8 * (min(iz, 31) >> 2))) & 255ull) == 2ull ? -1.0f : 1.0f;
+                const int nwords = (nvox + 63) >> 6;
+                for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;   // (+2: the row extraction reads one word ahead)
+                __syncthreads();
+                const int glast = (c2 - 1) >> 2;                                // the last group along z owns the boundary sample too
+                for (int r = tid; r < lx * ly; r += BLOCK) {                    // a thread per row of lz samples along z
+                    const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
+                    const unsigned long long st8 = *reinterpret_cast<const unsigned long long *>(gstate + ((min(ix, c0 - 1) >> 2) * 8 + (min(iy, c1 - 1) >> 2)) * 8);
+                    unsigned long long rowmask = 0ull;
+                    SDF_UNROLL
+                    for (int gq = 0; gq < 8; gq++) {
+                        const int hi = gq == glast ? c2 : 4 * gq + 3;           // samples 4 gq .. hi
+                        if (gq <= glast && ((st8 >> (8 * gq)) & 255ull) == 1ull)
+                            rowmask |= ((2ull << hi) - 1ull) & ~((1ull << (4 * gq)) - 1ull);
                     }
-                } else {
-                    for (int i = tid; i < nvox; i += BLOCK) {
-                        const int ix = fast_div(i, tt.inv_lyz), r = i - ix * lyz, iy = fast_div(r, tt.inv_lz), iz = r - iy * tt.lz;
-                        vol[i] = gstate[((min(ix, c0 - 1) >> 2) * 8 + (min(iy, c1 - 1) >> 2)) * 8 + (min(iz, c2 - 1) >> 2)] == 2 ? -1.0f : 1.0f;
+                    if (rowmask) {
+                        const int o = r * lz, sh = o & 63;
+                        atomicOr(&bits[o >> 6], rowmask << sh);
+                        if (sh && (rowmask >> (64 - sh))) atomicOr(&bits[(o >> 6) + 1], rowmask >> (64 - sh));
                     }
                 }
-                __syncthreads();
+                // (no barrier: the evaluation below only ORs into the same words)
             }
         }
         if (tid == 0) atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
@@ -550,7 +558,12 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             for (int k = 0; k < NS; k++) {   // (the sample index is worked out again rather than kept across the interpreter)
                 int ix, iy, iz;
                 const bool valid = t0 + k < ntl && tt.sample(culled ? (int)tlist[t0 + k] : t0 + k, lane, ix, iy, iz);
-                if (valid) vol[ix * lyz + iy * tt.lz + iz] = (float)val.v[k];
+                if (valid) {
+                    const int i = ix * lyz + iy * tt.lz + iz;
+                    const float fv = (float)val.v[k];
+                    vol[i] = fv;
+                    if (culled && fv > 0.0f) atomicOr(&bits[i >> 6], 1ull << (i & 63));
+                }
             }
         }
         __syncthreads();
@@ -558,7 +571,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         SDF_SUBPROF(10);
         // ---- 1d. the sign-bit volume: one word per 64 consecutive samples (the marching phases classify
         // cells from these bits instead of re-reading 8 floats per cell) ----
-        for (int word = wave * 4; word < ((nvox + 63) >> 6); word += NWAVE * 4) {   // (four reads in flight per lane)
+        for (int word = wave * 4; !culled && word < ((nvox + 63) >> 6); word += NWAVE * 4) {   // (four reads in flight per lane)
             float f[4];
             SDF_UNROLL for (int k = 0; k < 4; k++) f[k] = vol[min((word + k) * 64 + lane, nvox - 1)];
             SDF_UNROLL
@@ -567,8 +580,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (lane == 0 && word + k < ((nvox + 63) >> 6)) bits[word + k] = m;
             }
         }
-        if (tid < 2) bits[((nvox + 63) >> 6) + tid] = 0ull;   // the row extraction reads one word ahead
-        __syncthreads();
+        if (!culled) {
+            if (tid < 2) bits[((nvox + 63) >> 6) + tid] = 0ull;   // the row extraction reads one word ahead
+            __syncthreads();
+        }
         SDF_SUBPROF(11);
 #undef SDF_SUBPROF
         SDF_PROF(1);
