@@ -130,6 +130,13 @@ int sdf_mesh_emit_host(sdf_mesh *mesh, double *h_out);
 /* T binary-STL records of 50 bytes (f32 normal, 3 x f32 vertex, u16 0), i.e. the body that
  * `write_binary_stl` writes after the 84-byte header (reference sdf/stl.py:4-24) */
 int sdf_mesh_emit_stl_host(sdf_mesh *mesh, void *h_out);
+/* Vertex weld on the device: what `np.unique(points, axis=0, return_inverse=True)` computes for the
+ * reference's non-STL export (reference sdf/core.py:160-164, `_mesh`).  sdf_mesh_weld sorts and
+ * deduplicates the soup rows in library memory and reports the number of unique rows;
+ * sdf_mesh_weld_fetch copies them out: h_points = n_unique x 3 float64 in lexicographic order,
+ * h_cells = T x 3 int64, the unique-row index of every soup row. */
+int sdf_mesh_weld(sdf_mesh *mesh, int64_t *n_unique);
+int sdf_mesh_weld_fetch(sdf_mesh *mesh, double *h_points, int64_t *h_cells);
 /* per-batch classification, n_batches bytes: 0 skipped, 1 empty, 2 nonempty, 3 other shard */
 int sdf_mesh_kinds(sdf_mesh *mesh, uint8_t *h_out);
 /* diagnostics: what the interval prepass decided, 16 words per batch in batch order like

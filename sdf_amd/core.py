@@ -81,9 +81,11 @@ def generate(
         sdf,
         step=None, bounds=None, samples=SAMPLES,
         workers=WORKERS, batch_size=BATCH_SIZE,
-        verbose=True, sparse=True, _stl=False):
+        verbose=True, sparse=True, _stl=False, _weld=False):
     """reference sdf/core.py:84-150.  (`_stl=True` is what `save` uses for .stl files: the soup
-    stays on the device and the 50-byte STL records come back instead of the points.)"""
+    stays on the device and the 50-byte STL records come back instead of the points; `_weld=True` is
+    what `save` uses for every other format: the soup is welded on the device and the indexed mesh
+    (unique points, cells) comes back.)"""
 
     from . import engine, dist
     start = time.time()
@@ -108,7 +110,7 @@ def generate(
         num_samples = overlapped(len(X)) * overlapped(len(Y)) * overlapped(len(Z))
         print('%d samples in %d batches with %d workers' % (num_samples, num_batches, workers))
 
-    records = None
+    records = welded = None
     if dist.world_size() > 1:
         points, stats = dist.generate_sharded(eng, tape, X, Y, Z, batch_size, sparse)
     else:
@@ -118,6 +120,9 @@ def generate(
             if _stl:
                 records = mesh.stl_records()
                 points = np.empty((3 * mesh.n_triangles, 0))     # only its length is used below
+            elif _weld:
+                welded = mesh.weld()
+                points = np.empty((3 * mesh.n_triangles, 0))
             else:
                 points = mesh.points()
         finally:
@@ -132,6 +137,11 @@ def generate(
     generate.last_stats = stats
     if _stl:
         return records if records is not None else stl.stl_records(points).view(np.uint8).reshape(-1)
+    if _weld:
+        if welded is None:      # (multi-process: the gathered soup is welded like the reference does it)
+            pts, cells = np.unique(points, axis=0, return_inverse=True)
+            welded = (pts, np.asarray(cells).reshape((-1, 3)))
+        return welded
     return points
 
 
@@ -146,16 +156,18 @@ def save(path, *args, **kwargs):
         records = generate(*args, _stl=True, **kwargs)
         stl.write_stl_records(path, records)
     else:
-        points = generate(*args, **kwargs)
-        mesh = _mesh(points)
-        mesh.write(path)
+        # the vertex weld (np.unique over 3T rows in the reference) runs on the device: sdf_mesh_weld
+        points, cells = generate(*args, _weld=True, **kwargs)
+        import meshio
+        meshio.Mesh(points, [('triangle', cells)]).write(path)
 
 
 def _mesh(points):
-    """vertex weld for non-STL formats (reference sdf/core.py:160-164; needs meshio)"""
+    """vertex weld of a host-side soup for non-STL formats (reference sdf/core.py:160-164; needs
+    meshio).  `save` does not come through here: it welds on the device (`generate(_weld=True)`)."""
     import meshio
     points, cells = np.unique(points, axis=0, return_inverse=True)
-    cells = [('triangle', cells.reshape((-1, 3)))]
+    cells = [('triangle', np.asarray(cells).reshape((-1, 3)))]
     return meshio.Mesh(points, cells)
 
 

@@ -18,6 +18,8 @@ $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f64 -c -
 $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f64_full -c -o build/mesh_f64_full.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=float -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f32 -c -o build/mesh_f32.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=float -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f32_full -c -o build/mesh_f32_full.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
+# (the weld uses hipCUB's radix sort and scan; it has no floating-point arithmetic of its own)
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c -o build/sdf_weld.o sdf_weld.hip "$@" & pids="$pids $!"
 for p in $pids; do wait $p; done
 exec $HIPCC --offload-arch=gfx950 -fPIC -shared -o libsdf_hip.so build/sdf_hip.o build/mesh_f64.o build/mesh_f64_full.o \
-    build/mesh_f32.o build/mesh_f32_full.o
+    build/mesh_f32.o build/mesh_f32_full.o build/sdf_weld.o

@@ -387,7 +387,14 @@ struct sdf_mesh {
     DevBuf counters;               // this call's MeshCounters block (pooled in the context)
     int work_begin = 0, work_end = 0;
     void *emitted_to = nullptr;    // caller buffer the soup was gathered into by sdf_generate_to_device
+    double *weld_pts = nullptr;    // sdf_mesh_weld: unique rows / row -> unique row (hipMalloc'ed by sdf_weld.hip)
+    long long *weld_inv = nullptr;
+    long long weld_n = -1;
 };
+
+namespace sdfk {
+int weld_device(hipStream_t stream, const double *pts, long long n, double **d_uniq, long long **d_inv, long long *n_unique);   // sdf_weld.hip
+}
 
 static bool tape_needs_full(const uint32_t *code, uint32_t n_words, const double *consts) {
     auto trig_ease = [](int id) {
@@ -998,6 +1005,32 @@ int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
     return 0;
 }
 
+int sdf_mesh_weld(sdf_mesh *m, int64_t *n_unique) {
+    if (!m || !n_unique) return fail("sdf_mesh_weld: NULL argument");
+    sdf_ctx *c = m->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (m->weld_n < 0) {
+        long long nu = 0;
+        const int rc = sdfk::weld_device(c->stream, (const double *)mesh_soup(m), 3ll * (long long)m->st.n_triangles, &m->weld_pts, &m->weld_inv, &nu);
+        if (rc) return fail(std::string("sdf_mesh_weld: ") + hipGetErrorString((hipError_t)rc));
+        m->weld_n = nu;
+    }
+    *n_unique = (int64_t)m->weld_n;
+    return 0;
+}
+
+int sdf_mesh_weld_fetch(sdf_mesh *m, double *h_points, int64_t *h_cells) {
+    if (!m || !h_points || !h_cells) return fail("sdf_mesh_weld_fetch: NULL argument");
+    if (m->weld_n < 0) return fail("sdf_mesh_weld_fetch: call sdf_mesh_weld first");
+    if (m->weld_n == 0) return 0;
+    sdf_ctx *c = m->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(h_points, m->weld_pts, (size_t)m->weld_n * 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_cells, m->weld_inv, (size_t)m->st.n_triangles * 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int sdf_mesh_kinds(sdf_mesh *m, uint8_t *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_kinds: NULL argument");
     if (m->st.n_batches == 0) return 0;
@@ -1032,6 +1065,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
     for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull}) b->release();
+    (void)hipFree(m->weld_pts); (void)hipFree(m->weld_inv);
     delete m;
     return 0;
 }

@@ -77,6 +77,8 @@ ABI = {
     'sdf_mesh_emit_device': (ctypes.c_int, [_vp, _vp]),
     'sdf_mesh_emit_host': (ctypes.c_int, [_vp, _f64p]),
     'sdf_mesh_emit_stl_host': (ctypes.c_int, [_vp, _vp]),
+    'sdf_mesh_weld': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    'sdf_mesh_weld_fetch': (ctypes.c_int, [_vp, _f64p, ctypes.POINTER(ctypes.c_int64)]),
     'sdf_mesh_kinds': (ctypes.c_int, [_vp, _u8p]),
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
@@ -189,6 +191,19 @@ class Mesh:
     def emit_device(self, device_ptr):
         """write the (3T,3) float64 soup into caller-owned device memory (e.g. a torch tensor)"""
         _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_device(self.handle, _vp(device_ptr)))
+
+    def weld(self):
+        """(unique points (U, 3) float64 in lexicographic order, cells (T, 3) int64): what
+        `np.unique(points, axis=0, return_inverse=True)` gives the reference's `_mesh`
+        (reference sdf/core.py:160-164), sorted and deduplicated on the device"""
+        nu = ctypes.c_int64(0)
+        _check(self.engine.lib, self.engine.lib.sdf_mesh_weld(self.handle, ctypes.byref(nu)))
+        pts = np.empty((nu.value, 3), np.float64)
+        cells = np.empty((self.n_triangles, 3), np.int64)
+        if nu.value:
+            _check(self.engine.lib, self.engine.lib.sdf_mesh_weld_fetch(self.handle, _dp(pts, _f64p),
+                                                                       _dp(cells, ctypes.POINTER(ctypes.c_int64))))
+        return pts, cells
 
     def stl_records(self):
         """T x 50-byte binary STL records (normals computed on the device)"""

@@ -608,3 +608,39 @@ def test_interval_passes_with_arrays_and_bends_random(seed, ns, eng):
     (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, f, X, Y, Z, sparse=seed % 3 != 0)
     assert s0['n_pruned_instrs'] == 0
     assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
+
+
+# ---- vertex weld on the device (reference sdf/core.py:160-164: np.unique(points, axis=0, return_inverse=True)) ----
+
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 20), ('ex_blobby', 2 ** 18), ('ex_weave', 2 ** 19)])
+def test_weld_matches_numpy_unique(name, samples, ns, eng):
+    f = fixtures.build(name, ns)
+    X, Y, Z, _ = core.grid_axes(core._estimate_bounds(f), samples=samples)
+    m = eng.generate(f, X, Y, Z, 32, True)
+    soup = m.points()
+    pts, cells = m.weld()
+    pts2, cells2 = m.weld()          # (cached in the mesh)
+    m.close()
+    want_pts, want_inv = np.unique(soup, axis=0, return_inverse=True)
+    assert pts.shape == want_pts.shape and np.array_equal(pts, want_pts)
+    assert cells.dtype == np.int64 and np.array_equal(cells, np.asarray(want_inv).reshape(-1, 3))
+    assert np.array_equal(pts, pts2) and np.array_equal(cells, cells2)
+    assert np.array_equal(pts[cells.reshape(-1)], soup)          # the indexed mesh reproduces the soup
+    # a closed surface: Euler characteristic of the welded mesh of the canonical example (genus 5)
+    if name == 'ex_example':
+        V, F = len(pts), len(cells)
+        E = len(np.unique(np.sort(np.concatenate([cells[:, [0, 1]], cells[:, [1, 2]], cells[:, [2, 0]]]), axis=1), axis=0))
+        assert V - E + F == 2 - 2 * 5
+
+
+def test_weld_handles_signed_zeros_and_empty(ns, eng):
+    # a soup with coordinates exactly +-0.0: both zeros are one coordinate (NumPy's comparison)
+    f = ns['box'](1.0)
+    A = np.arange(-1.0, 1.0001, 0.125)
+    m = eng.generate(f, A, A, A, 32, False)
+    soup = m.points(); pts, cells = m.weld(); m.close()
+    want_pts, want_inv = np.unique(soup, axis=0, return_inverse=True)
+    assert np.array_equal(pts, want_pts) and np.array_equal(cells.reshape(-1), np.asarray(want_inv).reshape(-1))
+    m = eng.generate(ns['sphere'](0.1).translate((5, 5, 5)), A, A, A, 32, False)
+    pts, cells = m.weld(); m.close()
+    assert pts.shape == (0, 3) and cells.shape == (0, 3)
