@@ -759,7 +759,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     }
 
     // ---- prepass: skip test for every batch, then the ordered work list (+ this shard's slice) ----
-    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    // (three event records per call, not one per interval: each is a marker packet the queue has to drain to;
+    // ms_prepass = ev[0] -> ev[2] includes the copy of the axes, ms_mesh = ev[2] -> ev[4], ms_total = ev[0] -> ev[4])
     // interval pass: per batch, which instructions never matter (float64 sampling only: the intervals
     // bound the float64 interpreter, not the float32 one).  The box of a batch is spanned by its first
     // and last coordinate per axis: monotone axes only.
@@ -829,10 +830,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     unsigned long long cap = 0;
     MeshCounters h;
     bool to_caller = d_out && cap_out > 0;
+    bool quiet = true;     // nothing but k_mesh follows ev[2] on the stream, and the host did not stall in between
     if (!to_caller) {
         if (t->hint_key == key && t->hint_total_tris) {
             cap = t->hint_total_tris + t->hint_total_tris / 4 + 4096;
         } else {
+            quiet = false;
             HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             const unsigned long long nshard0 = (unsigned long long)std::max(h.work_end - h.work_begin, 1);
@@ -846,6 +849,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             a.out = (double *)d_out; a.out_cap = (unsigned long long)cap_out;
         } else {
             if (!m->out.p && !c->arena_pool.empty()) { m->out = c->arena_pool.back(); c->arena_pool.pop_back(); }
+            if (m->out.bytes < (size_t)cap * 72) quiet = false;     // (an allocation: the stream idles meanwhile)
             if (m->out.ensure((size_t)cap * 72)) return 1;
             a.out = (double *)m->out.p; a.out_cap = m->out.bytes / 72;
         }
@@ -858,7 +862,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
-        if (c->parking && !c->park.p && c->park.ensure((size_t)c->n_cu * SDF_PARK_TRIS * 36)) return 1;
+        if (c->parking && !c->park.p) { quiet = false; if (c->park.ensure((size_t)c->n_cu * SDF_PARK_TRIS * 36)) return 1; }
         a.park = c->parking ? (float *)c->park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
         a.park_spins = (unsigned)c->park_spins;
         a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
@@ -866,14 +870,15 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.n_instr = (int)n_instr;
         if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, c->stream));
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
-        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        const bool own_start = attempt > 0 || a.prof || !quiet;   // (something was enqueued, or the host waited, since ev[2])
+        if (own_start) HIPCHK(hipEventRecord(c->ev[3], c->stream));
         if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs)) return 1;
         HIPCHK(hipEventRecord(c->ev[4], c->stream));
         MeshCounters *hp = (MeshCounters *)((char *)c->h_stage + SDF_STAGE_BYTES - 256);   // pinned
         HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         h = *hp;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[own_start ? 3 : 2], c->ev[4]));
         m->st.ms_mesh = ms;
         if (c->prof.p) {
             unsigned long long pc[16];
@@ -904,11 +909,9 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     m->pruned = pruning;
     m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
-    HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[2]));
     m->st.ms_prepass = ms;
-    HIPCHK(hipEventRecord(c->ev[5], c->stream));
-    HIPCHK(hipEventSynchronize(c->ev[5]));
-    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[5]));
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4]));
     m->st.ms_total = ms;
     return 0;
 }
