@@ -56,6 +56,7 @@ def main():
     ap.add_argument('--precision', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-check', action='store_true')
+    ap.add_argument('--sync', action='store_true', help='one step in flight: every call synchronises before the next is submitted')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -98,44 +99,61 @@ def main():
 
     state = {}
 
+    DEPTH = 1 if args.sync else 2      # steps in flight (single GPU): step i+1 is submitted before step i is collected
+    inflight = []
+
+    def collect():
+        mesh, buf = inflight.pop(0)
+        mesh.wait()
+        t = mesh.n_triangles
+        if not mesh.emitted:               # (the soup did not fit: it was meshed again into library memory)
+            big = torch.empty(max(t + t // 8, 1) * 9, dtype=torch.float64, device=dev)
+            mesh.emit_device(big.data_ptr())
+            state['bufs'][state['bufs'].index(buf)] = big
+        st = mesh.stats()
+        state['stats'] = st
+        state['tris'] = t
+        mesh_ms.append(st['ms_mesh'])
+        mesh.close()
+
     def one_step():
         if world == 1:
-            # the output buffer is sized from the previous step (first step: a guess); the ordered
-            # gather into it is part of the same submission; if it does not fit it is emitted again
-            buf = state.get('buf')
-            if buf is None:
-                buf = state['buf'] = torch.empty(9 * (1 << 22), dtype=torch.float64, device=dev)
-            mesh = eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9)
-            t = mesh.n_triangles
-            if not mesh.emitted:
-                buf = state['buf'] = torch.empty(max(t + t // 8, 1) * 9, dtype=torch.float64, device=dev)
-                mesh.emit_device(buf.data_ptr())
-            state['stats'] = mesh.stats()
-            state['tris'] = t
-            mesh.close()
+            # every step writes its ordered float64 soup into a device buffer of its own (DEPTH of them
+            # alternate), sized from the previous steps (first: a guess); the step is complete when its
+            # counters are back on the host (collect)
+            bufs = state.setdefault('bufs', [torch.empty(9 * (1 << 22), dtype=torch.float64, device=dev) for _ in range(DEPTH)])
+            buf = bufs[state.get('n', 0) % DEPTH]
+            state['n'] = state.get('n', 0) + 1
+            while len(inflight) >= DEPTH:
+                collect()
+            inflight.append((eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9, wait=False), buf))
         else:
             soup, st = dist.generate_sharded_device(eng, tape, X, Y, Z, 32, True, device=comm_dev)
             state['buf'] = soup
             state['stats'] = st
             state['tris'] = st['triangles']
+            mesh_ms.append(st['ms_mesh'])
 
     def sync():
+        while inflight:
+            collect()
         eng.synchronize()
         torch.cuda.synchronize()
         if td is not None:
             td.barrier()
             torch.cuda.synchronize()
 
+    mesh_ms = []
     for _ in range(args.warmup):
         one_step()
     sync()
-    mesh_ms = []
+    del mesh_ms[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-        mesh_ms.append(state['stats']['ms_mesh'])
-    sync()
+    sync()                                 # every one of the K steps is complete (collected) here
     dt = time.perf_counter() - t0
+    assert len(mesh_ms) == args.steps
     if td is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -145,6 +163,18 @@ def main():
     tris = int(state['tris'])
     ms_per_step = 1e3 * dt / args.steps
     value = grid_voxels * args.steps / dt
+
+    # latency of ONE call (submit -> counters back on the host), nothing else in flight
+    latency_ms = None
+    if world == 1:
+        sync()
+        n_lat = max(1, min(args.steps, 20))
+        buf = state['bufs'][0]
+        t1 = time.perf_counter()
+        for _ in range(n_lat):
+            mesh = eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9)
+            mesh.close()
+        latency_ms = 1e3 * (time.perf_counter() - t1) / n_lat
 
     # PCIe-inclusive variant (single GPU): same step + D2H of the soup into pageable host memory
     incl = None
@@ -238,6 +268,8 @@ def main():
         'triangles_per_sec': round(tris * args.steps / dt, 1),
         'eval_voxels_per_sec': round(int(st['n_eval_voxels']) * args.steps / dt, 1),
         'value_incl_d2h': round(incl, 1) if incl else None,
+        'steps_in_flight': DEPTH if world == 1 else 1,
+        'latency_ms_per_call': round(latency_ms, 4) if latency_ms else None,
         'device_ms': {'prepass': round(st['ms_prepass'], 4), 'mesh': round(k_ms, 4), 'emit': round(st.get('ms_emit', 0.0), 4)},
         'parity_check': check,
         'roofline': roofline,

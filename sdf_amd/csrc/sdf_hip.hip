@@ -343,6 +343,15 @@ struct DevBuf {
 };
 
 #define SDF_STAGE_BYTES (1u << 20)
+// Calls in flight on one context (sdf_generate_to_device_async): each owns a slot = its pinned staging
+// (axes on the way in, counters on the way out) and its events; a slot is reused only after the call that
+// held it has completed.
+#define SDF_CALL_SLOTS 4
+struct CallSlot {
+    hipEvent_t e0 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr;   // start, prepass end, k_mesh start (re-runs), k_mesh end
+    hipEvent_t done = nullptr;                                            // behind the counters' copy to the host
+    bool busy = false;
+};
 #define SDF_PARK_TRIS 8192   // triangles per workgroup staging slot of k_mesh (36 bytes each); larger batches wait instead
 
 struct sdf_ctx {
@@ -362,7 +371,9 @@ struct sdf_ctx {
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
     std::vector<DevBuf> arena_pool;   // soup buffers handed back by destroyed meshes
     std::vector<DevBuf> counter_pool; // 64-byte MeshCounters blocks handed back by destroyed meshes
-    void *h_stage = nullptr;          // pinned host staging: the axes on the way in, the counters on the way out
+    void *h_stage = nullptr;          // pinned host staging, SDF_CALL_SLOTS x SDF_STAGE_BYTES
+    CallSlot slots[SDF_CALL_SLOTS];
+    unsigned slot_seq = 0;
 };
 
 struct sdf_tape {
@@ -387,6 +398,19 @@ struct sdf_mesh {
     DevBuf counters;               // this call's MeshCounters block (pooled in the context)
     int work_begin = 0, work_end = 0;
     void *emitted_to = nullptr;    // caller buffer the soup was gathered into by sdf_generate_to_device
+    // sdf_generate_to_device_async: everything sdf_mesh_wait needs to finish the call
+    struct Pending {
+        bool active = false;
+        sdf_tape *tape = nullptr;
+        int slot = 0, nb = 0, bs = 0, sparse = 0, precision = 0;
+        bool pruning = false, own_start = false;
+        uint32_t n_instr = 0;
+        unsigned long long key = 0;
+        void *d_out = nullptr;
+        int64_t cap_out = 0, shard_index = 0, shard_count = 1;
+        std::vector<double> axes;      // host copy (a soup that does not fit is re-run synchronously)
+        int nx = 0, ny = 0, nz = 0;
+    } pend;
     double *weld_pts = nullptr;    // sdf_mesh_weld: unique rows / row -> unique row (hipMalloc'ed by sdf_weld.hip)
     long long *weld_inv = nullptr;
     long long weld_n = -1;
@@ -466,7 +490,11 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipHostMalloc(&c->h_stage, SDF_STAGE_BYTES, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&c->h_stage, (size_t)SDF_CALL_SLOTS * SDF_STAGE_BYTES, hipHostMallocDefault));
+    for (auto &cs : c->slots) {
+        HIPCHK(hipEventCreate(&cs.e0)); HIPCHK(hipEventCreate(&cs.e2)); HIPCHK(hipEventCreate(&cs.e3)); HIPCHK(hipEventCreate(&cs.e4));
+        HIPCHK(hipEventCreateWithFlags(&cs.done, hipEventDisableTiming));
+    }
     McTables t;
     memcpy(t.ntri, MC_NTRI, 256);
     memcpy(t.amb, MC_AMBIGUOUS, 256);
@@ -495,6 +523,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     for (auto &b : c->counter_pool) b.release();
     g_pool.drop_device(c->device);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &cs : c->slots) for (hipEvent_t e : {cs.e0, cs.e2, cs.e3, cs.e4, cs.done}) if (e) (void)hipEventDestroy(e);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -726,9 +755,36 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     return 0;
 }
 
+// the per-call statistics from the counters the meshing pass left (end of sdf_generate / sdf_mesh_wait)
+static int finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb, bool pruning, uint32_t n_instr, unsigned long long key,
+                        const CallSlot &cs) {
+    m->work_begin = h.work_begin; m->work_end = h.work_end;
+    m->st.n_skipped = nb - h.nwork;
+    m->st.n_work_begin = m->work_begin; m->st.n_work_end = m->work_end;
+    m->st.n_triangles = (int64_t)h.total;
+    m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
+    m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
+    m->st.n_pruned_instrs = pruning ? (int64_t)h.n_pruned : 0;
+    m->st.n_sampled_voxels = (int64_t)h.n_sampled;
+    m->pruned = pruning;
+    m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
+    t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, cs.e0, cs.e2));
+    m->st.ms_prepass = ms;
+    HIPCHK(hipEventElapsedTime(&ms, cs.e0, cs.e4));
+    m->st.ms_total = ms;
+    return 0;
+}
+
 static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
-                         int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out) {
+                         int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out,
+                         bool async_mode = false) {
     sdf_ctx *c = t->ctx;
+    const int slot = (int)(c->slot_seq++ % SDF_CALL_SLOTS);
+    CallSlot &cs = c->slots[slot];
+    if (cs.busy) { HIPCHK(hipEventSynchronize(cs.done)); cs.busy = false; }     // (the call that held the slot is over)
+    char *stage = (char *)c->h_stage + (size_t)slot * SDF_STAGE_BYTES;
     GridDesc &g = m->g;
     g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
     g.nbx = (nx + bs - 1) / bs; g.nby = (ny + bs - 1) / bs; g.nbz = (nz + bs - 1) / bs;
@@ -746,10 +802,11 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     if (m->counters.ensure(sizeof(MeshCounters))) return 1;
     double *dX = (double *)m->axes.p, *dY = dX + nx, *dZ = dY + ny;
     g.X = dX; g.Y = dY; g.Z = dZ;
-    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(hipEventRecord(cs.e0, c->stream));
     const size_t axis_bytes = (size_t)(nx + ny + nz) * 8;
+    if (async_mode && axis_bytes > SDF_STAGE_BYTES - 256) return fail("sdf_generate_to_device_async: axes too long for the staging slot");
     if (axis_bytes <= SDF_STAGE_BYTES - 256) {   // one copy from pinned memory instead of three from pageable
-        double *hs = (double *)c->h_stage;
+        double *hs = (double *)stage;
         memcpy(hs, X, (size_t)nx * 8); memcpy(hs + nx, Y, (size_t)ny * 8); memcpy(hs + nx + ny, Z, (size_t)nz * 8);
         HIPCHK(hipMemcpyAsync(dX, hs, axis_bytes, hipMemcpyHostToDevice, c->stream));
     } else {
@@ -815,7 +872,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                            ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(hipEventRecord(cs.e2, c->stream));
 
     // ---- meshing.  The whole chain (prepass -> k_mesh) is enqueued without a host round trip: the
     // work-list length stays on the device and k_mesh writes the ordered float64 soup itself.  The
@@ -871,14 +928,25 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, c->stream));
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         const bool own_start = attempt > 0 || a.prof || !quiet;   // (something was enqueued, or the host waited, since ev[2])
-        if (own_start) HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        if (own_start) HIPCHK(hipEventRecord(cs.e3, c->stream));
         if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs)) return 1;
-        HIPCHK(hipEventRecord(c->ev[4], c->stream));
-        MeshCounters *hp = (MeshCounters *)((char *)c->h_stage + SDF_STAGE_BYTES - 256);   // pinned
+        HIPCHK(hipEventRecord(cs.e4, c->stream));
+        MeshCounters *hp = (MeshCounters *)(stage + SDF_STAGE_BYTES - 256);   // pinned
         HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        if (async_mode && attempt == 0) {   // the caller collects the result with sdf_mesh_wait
+            HIPCHK(hipEventRecord(cs.done, c->stream));
+            cs.busy = true;
+            sdf_mesh::Pending &pd = m->pend;
+            pd.active = true; pd.tape = t; pd.slot = slot; pd.nb = nb; pd.bs = bs; pd.sparse = sparse; pd.precision = precision;
+            pd.pruning = pruning; pd.own_start = own_start; pd.n_instr = n_instr; pd.key = key;
+            pd.d_out = d_out; pd.cap_out = cap_out; pd.shard_index = shard_index; pd.shard_count = shard_count;
+            pd.nx = nx; pd.ny = ny; pd.nz = nz;
+            pd.axes.assign(X, X + nx); pd.axes.insert(pd.axes.end(), Y, Y + ny); pd.axes.insert(pd.axes.end(), Z, Z + nz);
+            return 0;
+        }
         HIPCHK(hipStreamSynchronize(c->stream));
         h = *hp;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[own_start ? 3 : 2], c->ev[4]));
+        HIPCHK(hipEventElapsedTime(&ms, own_start ? cs.e3 : cs.e2, cs.e4));
         m->st.ms_mesh = ms;
         if (c->prof.p) {
             unsigned long long pc[16];
@@ -898,22 +966,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         m->emitted_to = to_caller ? d_out : nullptr;
         break;
     }
-    m->work_begin = h.work_begin; m->work_end = h.work_end;
-    m->st.n_skipped = nb - h.nwork;
-    m->st.n_work_begin = m->work_begin; m->st.n_work_end = m->work_end;
-    m->st.n_triangles = (int64_t)h.total;
-    m->st.n_empty = h.n_empty; m->st.n_nonempty = h.n_nonempty;
-    m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
-    m->st.n_pruned_instrs = pruning ? (int64_t)h.n_pruned : 0;
-    m->st.n_sampled_voxels = (int64_t)h.n_sampled;
-    m->pruned = pruning;
-    m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
-    t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
-    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[2]));
-    m->st.ms_prepass = ms;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4]));
-    m->st.ms_total = ms;
-    return 0;
+    return finish_stats(t, m, h, nb, pruning, n_instr, key, cs);
 }
 
 extern "C" {
@@ -922,7 +975,7 @@ int sdf_mesh_destroy(sdf_mesh *m);
 
 static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
                           int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out,
-                          sdf_mesh **out) {
+                          sdf_mesh **out, bool async_mode = false) {
     if (!t || !X || !Y || !Z || !out) return fail("sdf_generate: NULL argument");
     *out = nullptr;
     if (bs < 1 || bs > 32) return fail("sdf_generate: batch_size must be in 1..32 (the (batch_size+1)^3 float32 tile lives in LDS)");
@@ -933,7 +986,7 @@ static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y,
     HIPCHK(hipSetDevice(c->device));
     sdf_mesh *m = new sdf_mesh();
     m->ctx = c;
-    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out)) {
+    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out, async_mode)) {
         const std::string keep = g_err;
         sdf_mesh_destroy(m);
         g_err = keep;
@@ -958,19 +1011,69 @@ int sdf_generate_to_device(sdf_tape *t, const double *X, int nx, const double *Y
     return 0;
 }
 
+int sdf_generate_to_device_async(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
+                                 int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out,
+                                 int64_t cap_tris, sdf_mesh **out) {
+    if (!d_out || cap_tris <= 0) return fail("sdf_generate_to_device_async: output buffer is NULL or empty");
+    return generate_entry(t, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_tris, out, true);
+}
+
+int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
+    if (!m) return fail("sdf_mesh_wait: NULL argument");
+    sdf_mesh::Pending &pd = m->pend;
+    if (pd.active) {
+        sdf_ctx *c = m->ctx;
+        HIPCHK(hipSetDevice(c->device));
+        CallSlot &cs = c->slots[pd.slot];
+        HIPCHK(hipEventSynchronize(cs.done));
+        cs.busy = false; pd.active = false;
+        const MeshCounters h = *(const MeshCounters *)((char *)c->h_stage + (size_t)pd.slot * SDF_STAGE_BYTES + SDF_STAGE_BYTES - 256);
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, pd.own_start ? cs.e3 : cs.e2, cs.e4));
+        m->st.ms_mesh = ms;
+        if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
+        if (h.overflow) {
+            // the soup did not fit the caller's buffer: the call is repeated synchronously into library memory
+            // (sized from the count just learned)
+            pd.tape->hint_key = pd.key; pd.tape->hint_total_tris = std::max<unsigned long long>(h.total, 1);
+            const double *X = pd.axes.data(), *Y = X + pd.nx, *Z = Y + pd.ny;
+            if (generate_impl(pd.tape, m, X, pd.nx, Y, pd.ny, Z, pd.nz, pd.bs, pd.sparse, pd.shard_index, pd.shard_count, pd.precision,
+                              nullptr, 0, false))
+                return 1;
+            m->st.n_retries += 1;
+        } else {
+            m->emitted_to = pd.d_out;
+            m->st.n_retries = 0;
+            if (finish_stats(pd.tape, m, h, pd.nb, pd.pruning, pd.n_instr, pd.key, cs)) return 1;
+        }
+        pd.axes.clear(); pd.axes.shrink_to_fit();
+    }
+    if (emitted) *emitted = (m->emitted_to != nullptr || m->st.n_triangles == 0) ? 1 : 0;
+    return 0;
+}
+
+// every reader of a mesh first collects a call that is still in flight
+#define MESH_READY(m) do { if ((m)->pend.active && sdf_mesh_wait((m), nullptr)) return 1; } while (0)
+
 int sdf_mesh_stats(sdf_mesh *m, sdf_stats *out) {
     if (!m || !out) return fail("sdf_mesh_stats: NULL argument");
+    MESH_READY(m);
     *out = m->st;
     return 0;
 }
 
-int64_t sdf_mesh_triangles(sdf_mesh *m) { return m ? m->st.n_triangles : 0; }
+int64_t sdf_mesh_triangles(sdf_mesh *m) {
+    if (!m) return 0;
+    if (m->pend.active && sdf_mesh_wait(m, nullptr)) return -1;
+    return m->st.n_triangles;
+}
 
 // where the soup of a mesh lives: the caller's buffer of sdf_generate_to_device, or the library's
 static const void *mesh_soup(const sdf_mesh *m) { return m->emitted_to ? m->emitted_to : m->out.p; }
 
 int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
     if (!m || !d_out) return fail("sdf_mesh_emit_device: NULL argument");
+    MESH_READY(m);
     sdf_ctx *c = m->ctx;
     if (m->st.n_triangles == 0 || d_out == mesh_soup(m)) return 0;
     HIPCHK(hipSetDevice(c->device));
@@ -986,6 +1089,7 @@ int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
 
 int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_emit_host: NULL argument");
+    MESH_READY(m);
     if (m->st.n_triangles == 0) return 0;
     HIPCHK(hipSetDevice(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, mesh_soup(m), (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToHost, m->ctx->stream));
@@ -995,6 +1099,7 @@ int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) {
 
 int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_emit_stl_host: NULL argument");
+    MESH_READY(m);
     const long long nt = m->st.n_triangles;
     if (nt == 0) return 0;
     sdf_ctx *c = m->ctx;
@@ -1010,6 +1115,7 @@ int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
 
 int sdf_mesh_weld(sdf_mesh *m, int64_t *n_unique) {
     if (!m || !n_unique) return fail("sdf_mesh_weld: NULL argument");
+    MESH_READY(m);
     sdf_ctx *c = m->ctx;
     HIPCHK(hipSetDevice(c->device));
     if (m->weld_n < 0) {
@@ -1036,6 +1142,7 @@ int sdf_mesh_weld_fetch(sdf_mesh *m, double *h_points, int64_t *h_cells) {
 
 int sdf_mesh_kinds(sdf_mesh *m, uint8_t *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_kinds: NULL argument");
+    MESH_READY(m);
     if (m->st.n_batches == 0) return 0;
     HIPCHK(hipSetDevice(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, m->kinds.p, (size_t)m->st.n_batches, hipMemcpyDeviceToHost, m->ctx->stream));
@@ -1046,6 +1153,7 @@ int sdf_mesh_kinds(sdf_mesh *m, uint8_t *h_out) {
 
 int sdf_mesh_prune_masks(sdf_mesh *m, uint32_t *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_prune_masks: NULL argument");
+    MESH_READY(m);
     if (!m->pruned) return fail("sdf_mesh_prune_masks: this mesh was generated without the interval prepass");
     const size_t n = (size_t)m->st.n_batches;
     if (n == 0) return 0;
@@ -1060,6 +1168,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
     sdf_ctx *c = m->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (m->pend.active) { c->slots[m->pend.slot].busy = false; m->pend.active = false; }   // (abandoned; the stream is idle now)
     if (m->out.p) {   // keep one soup buffer around for the next call
         if (c->arena_pool.empty()) c->arena_pool.push_back(m->out);
         else if (c->arena_pool.back().bytes < m->out.bytes) { c->arena_pool.back().release(); c->arena_pool.back() = m->out; }

@@ -72,6 +72,10 @@ ABI = {
     'sdf_generate_to_device': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _vp, _c_i64,
                                               ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_vp)]),
+    'sdf_generate_to_device_async': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                    ctypes.c_int, _vp, ctypes.c_int64, ctypes.POINTER(_vp)]),
+    'sdf_mesh_wait': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     'sdf_mesh_stats': (ctypes.c_int, [_vp, ctypes.POINTER(SdfStats)]),
     'sdf_mesh_triangles': (_c_i64, [_vp]),
     'sdf_mesh_emit_device': (ctypes.c_int, [_vp, _vp]),
@@ -155,6 +159,13 @@ class Mesh:
     @property
     def n_triangles(self):
         return int(self.engine.lib.sdf_mesh_triangles(self.handle))
+
+    def wait(self):
+        """collect a call submitted with generate(wait=False); returns `emitted`"""
+        e = ctypes.c_int(0)
+        _check(self.engine.lib, self.engine.lib.sdf_mesh_wait(self.handle, ctypes.byref(e)))
+        self.emitted = bool(e.value)
+        return self.emitted
 
     def stats(self):
         st = SdfStats()
@@ -301,14 +312,27 @@ class Engine:
                 return out[:nt.value].reshape(-1, 3)
             cap = nt.value
 
-    def generate(self, sdf, X, Y, Z, batch_size=32, sparse=True, shard=(0, 1), out_ptr=None, out_cap=0):
+    def generate(self, sdf, X, Y, Z, batch_size=32, sparse=True, shard=(0, 1), out_ptr=None, out_cap=0, wait=True):
         """mesh the grid X x Y x Z.  With out_ptr / out_cap (device memory for 9 * out_cap float64)
         the ordered soup is gathered into it inside the same submission (`mesh.emitted` tells
-        whether it fitted); otherwise it stays in the mesh until `points()` / `emit_device()`."""
+        whether it fitted); otherwise it stays in the mesh until `points()` / `emit_device()`.
+        wait=False (needs out_ptr): the call is only enqueued; `mesh.wait()` -- or any read of the
+        mesh -- collects it, so a caller can submit the next job while this one runs."""
         dt = self.tape_for(sdf)
         X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
         h = _vp()
         emitted = ctypes.c_int(0)
+        if not wait:
+            if not out_ptr:
+                raise ValueError('generate(wait=False) needs an output buffer (out_ptr / out_cap)')
+            _check(self.lib, self.lib.sdf_generate_to_device_async(
+                dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y), _dp(Z, _f64p), len(Z), int(batch_size),
+                1 if sparse else 0, int(shard[0]), int(shard[1]), self.precision, _vp(out_ptr), int(out_cap),
+                ctypes.byref(h)))
+            m = Mesh(self, h)
+            m._tape = dt
+            m.emitted = None          # unknown until wait()
+            return m
         if out_ptr:
             _check(self.lib, self.lib.sdf_generate_to_device(
                 dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y), _dp(Z, _f64p), len(Z), int(batch_size),

@@ -644,3 +644,45 @@ def test_weld_handles_signed_zeros_and_empty(ns, eng):
     m = eng.generate(ns['sphere'](0.1).translate((5, 5, 5)), A, A, A, 32, False)
     pts, cells = m.weld(); m.close()
     assert pts.shape == (0, 3) and cells.shape == (0, 3)
+
+
+# ---- calls in flight: sdf_generate_to_device_async / sdf_mesh_wait ----
+
+def test_async_generate_matches_sync(ns, eng):
+    import torch
+    f = fixtures.build('ex_example', ns)
+    g = fixtures.build('ex_blobby', ns)
+    A = np.arange(-1.2, 1.2, 2.4 / 160)
+    B = np.arange(-4.4, 4.4, 8.8 / 130)
+    want = []
+    for model, ax in ((f, A), (g, B)):
+        m = eng.generate(model, ax, ax, ax, 32, True)
+        want.append((m.points(), m.kinds(), m.stats())); m.close()
+    bufs = [torch.empty(9 * (1 << 20), dtype=torch.float64, device='cuda:0') for _ in range(6)]
+    # six calls in flight on one context (more than it has slots), two models alternating
+    meshes = [eng.generate((f, g)[i % 2], (A, B)[i % 2], (A, B)[i % 2], (A, B)[i % 2], 32, True,
+                           out_ptr=bufs[i].data_ptr(), out_cap=bufs[i].numel() // 9, wait=False) for i in range(6)]
+    for i, m in reversed(list(enumerate(meshes))):          # collected out of order
+        assert m.wait() is True
+        p0, k0, s0 = want[i % 2]
+        t = m.n_triangles
+        assert t == s0['triangles'] and np.array_equal(m.kinds(), k0)
+        assert np.array_equal(bufs[i][:9 * t].cpu().numpy().reshape(-1, 3), p0)
+        st = m.stats()
+        assert (st['skipped'], st['empty'], st['nonempty']) == (s0['skipped'], s0['empty'], s0['nonempty'])
+        assert st['ms_mesh'] > 0
+        m.close()
+    # a buffer that is too small: the call is repeated into library memory, nothing is written past the end
+    small = torch.full((9 * 1000 + 9,), -7.0, dtype=torch.float64, device='cuda:0')
+    m = eng.generate(f, A, A, A, 32, True, out_ptr=small.data_ptr(), out_cap=1000, wait=False)
+    assert m.wait() is False and m.n_triangles == want[0][2]['triangles']
+    assert np.array_equal(m.points(), want[0][0]) and float(small[-1]) == -7.0
+    m.close()
+    # a mesh that is read without wait() collects itself; one that is dropped in flight is harmless
+    m = eng.generate(f, A, A, A, 32, True, out_ptr=bufs[0].data_ptr(), out_cap=bufs[0].numel() // 9, wait=False)
+    assert m.n_triangles == want[0][2]['triangles']
+    m.close()
+    m = eng.generate(f, A, A, A, 32, True, out_ptr=bufs[0].data_ptr(), out_cap=bufs[0].numel() // 9, wait=False)
+    m.close()
+    m = eng.generate(f, A, A, A, 32, True)
+    assert np.array_equal(m.points(), want[0][0]); m.close()
