@@ -81,7 +81,8 @@ struct MeshArgs {
 };
 
 // dynamic LDS layout of k_mesh
-enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_PEND = 1184, MESH_LDS_VOL = 1248 };
+enum { MESH_PARK_DEPTH = 4 };   // batches a workgroup may have parked before it has to wait for the oldest one's place
+enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_PEND = 1184, MESH_LDS_VOL = 1184 + 64 * MESH_PARK_DEPTH };   // PEND: per parked batch 6 doubles + 2 ints
 
 __device__ __forceinline__ void batch_origin(const GridDesc &g, int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {
     // itertools.product(Xs, Ys, Zs): Z fastest (reference sdf/core.py:119)
@@ -432,44 +433,62 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (w_ == work_end - 1 && excl != ~0ull) a.ctr->total = excl + total_;
     };
     // the parked batch of this workgroup (all values workgroup-uniform)
-    float *my_park = a.park ? a.park + (size_t)blockIdx.x * (size_t)a.park_cap * 9 : nullptr;
-    int pend_w = -1, pend_total = 0;
-    double *pend_xf = reinterpret_cast<double *>(smem + MESH_LDS_PEND);   // its offset[3], scale[3]
-    auto place_parked = [&](unsigned long long pre_pend) {
-        if (pend_w < 0) return;
-        if (tid < 64) {
-            const unsigned long long excl = ordered_base(a.status, pend_w, work_begin, (unsigned long long)pend_total, MESH_SPIN_FOREVER, pre_pend);
-            if (tid == 0) {
-                settle(pend_w, excl, (unsigned long long)pend_total);
-                reinterpret_cast<unsigned long long *>(bcast + 4)[0] = excl;
-            }
-        }
-        __syncthreads();
-        const unsigned long long pbase = reinterpret_cast<unsigned long long *>(bcast + 4)[0];
-        if (pbase != ~0ull && pbase + (unsigned long long)pend_total <= a.out_cap) {
-            double *dst0 = a.out + pbase * 9ull;
-            const double pof0 = pend_xf[0], pof1 = pend_xf[1], pof2 = pend_xf[2], psc0 = pend_xf[3], psc1 = pend_xf[4], psc2 = pend_xf[5];
-            // consecutive lanes move consecutive coordinates (4-byte loads, 8-byte stores: whole cache lines per
-            // instruction on both sides); coordinate e belongs to axis e % 3, so the axis of a thread's k-th
-            // coordinate is (its first axis + k * (BLOCK % 3)) % 3.  Eight loads in flight per thread.
-            static_assert(BLOCK % 3 == 1 || BLOCK % 3 == 2, "axis rotation below");
-            const int n9 = pend_total * 9;
-            const double sc[3] = {psc0, psc1, psc2}, of[3] = {pof0, pof1, pof2};
-            constexpr int U = 8;
-            for (int e0 = tid; e0 < n9; e0 += BLOCK * U) {
-                float f[U];
-                SDF_UNROLL for (int k = 0; k < U; k++) f[k] = my_park[min(e0 + k * BLOCK, n9 - 1)];
-                int ax = e0 % 3;
-                SDF_UNROLL
-                for (int k = 0; k < U; k++) {
-                    const double s_ = ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2]), o_ = ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]);
-                    if (e0 + k * BLOCK < n9) SDF_SOUP_STORE(dst0 + e0 + k * BLOCK, (double)f[k] * s_ + o_);
-                    ax += BLOCK % 3; if (ax >= 3) ax -= 3;
+    // The parked batches of this workgroup: a FIFO of up to MESH_PARK_DEPTH, each in its own staging slot (all
+    // values workgroup-uniform).  Sampling times differ a lot between batches (pruned tapes, culled tiles): with
+    // ONE slot a workgroup that met a slow predecessor twice in a row stood still -- 12 % of the kernel's
+    // cycles were spent in the look-back of the parked batch.  A batch is placed as soon as its predecessors
+    // have published (checked once per batch of this workgroup, oldest first); only a full FIFO waits.
+    float *my_park = a.park ? a.park + (size_t)blockIdx.x * (size_t)MESH_PARK_DEPTH * (size_t)a.park_cap * 9 : nullptr;
+    int pq_head = 0, pq_count = 0;
+    unsigned char *pend_base = smem + MESH_LDS_PEND;   // entry k: double xf[6] (offset[3], scale[3]), int w, int total
+    auto pend_xf = [&](int k) { return reinterpret_cast<double *>(pend_base + 64 * k); };
+    auto pend_wt = [&](int k) { return reinterpret_cast<int *>(pend_base + 64 * k + 48); };
+    // place the parked batches whose predecessors have published, oldest first; `must`: wait for ALL of them
+    auto place_parked = [&](unsigned long long pre_pend, bool must) {
+        bool first = true;
+        while (pq_count > 0) {
+            const int pend_w = pend_wt(pq_head)[0], pend_total = pend_wt(pq_head)[1];
+            const bool block = must || pq_count == MESH_PARK_DEPTH;
+            if (tid < 64) {
+                const unsigned long long pre = first ? pre_pend : lookback_prefetch(a.status, pend_w, work_begin);
+                const unsigned long long excl = ordered_base(a.status, pend_w, work_begin, (unsigned long long)pend_total,
+                                                             block ? MESH_SPIN_FOREVER : a.park_spins, pre);
+                if (tid == 0) {
+                    if (excl != MESH_NOT_READY) settle(pend_w, excl, (unsigned long long)pend_total);
+                    reinterpret_cast<unsigned long long *>(bcast + 4)[0] = excl;
                 }
             }
+            first = false;
+            __syncthreads();
+            const unsigned long long pbase = reinterpret_cast<unsigned long long *>(bcast + 4)[0];
+            if (pbase == MESH_NOT_READY) { __syncthreads(); break; }   // (bcast is reused)
+            if (pbase != ~0ull && pbase + (unsigned long long)pend_total <= a.out_cap) {
+                double *dst0 = a.out + pbase * 9ull;
+                const float *src = my_park + (size_t)pq_head * (size_t)a.park_cap * 9;
+                const double *xf = pend_xf(pq_head);
+                const double pof0 = xf[0], pof1 = xf[1], pof2 = xf[2], psc0 = xf[3], psc1 = xf[4], psc2 = xf[5];
+                // consecutive lanes move consecutive coordinates (4-byte loads, 8-byte stores: whole cache lines per
+                // instruction on both sides); coordinate e belongs to axis e % 3, so the axis of a thread's k-th
+                // coordinate is (its first axis + k * (BLOCK % 3)) % 3.  Eight loads in flight per thread.
+                static_assert(BLOCK % 3 == 1 || BLOCK % 3 == 2, "axis rotation below");
+                const int n9 = pend_total * 9;
+                const double sc[3] = {psc0, psc1, psc2}, of[3] = {pof0, pof1, pof2};
+                constexpr int U = 8;
+                for (int e0 = tid; e0 < n9; e0 += BLOCK * U) {
+                    float f[U];
+                    SDF_UNROLL for (int k = 0; k < U; k++) f[k] = src[min(e0 + k * BLOCK, n9 - 1)];
+                    int ax = e0 % 3;
+                    SDF_UNROLL
+                    for (int k = 0; k < U; k++) {
+                        const double s_ = ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2]), o_ = ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]);
+                        if (e0 + k * BLOCK < n9) SDF_SOUP_STORE(dst0 + e0 + k * BLOCK, (double)f[k] * s_ + o_);
+                        ax += BLOCK % 3; if (ax >= 3) ax -= 3;
+                    }
+                }
+            }
+            pq_head = (pq_head + 1) % MESH_PARK_DEPTH; pq_count--;
+            __syncthreads();   // (bcast is reused)
         }
-        pend_w = -1;
-        __syncthreads();   // (bcast is reused)
     };
     for (;;) {
         SDF_FRESH();
@@ -595,7 +614,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         unsigned long long pre_own = 0, pre_pend = 0;
         if (tid < 64) {
             pre_own = lookback_prefetch(a.status, w, work_begin);
-            if (pend_w >= 0) pre_pend = lookback_prefetch(a.status, pend_w, work_begin);
+            if (pq_count > 0) pre_pend = lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin);
         }
         const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
         const int nrows = (c0 > 0 && c1 > 0 && c2 > 0) ? c0 * c1 : 0;
@@ -655,7 +674,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
         // ---- a parked batch is older than this one: its predecessors have long published, place it ----
         { const long long tp0 = a.prof ? clock64() : 0;
-        place_parked(pre_pend);
+        place_parked(pre_pend, false);
         if (a.prof && tid == 0) atomicAdd(&a.prof[6], (unsigned long long)(clock64() - tp0)); }
         // ---- ordered allocation (wave 0): take the position if every predecessor has published its
         // count, else park this batch instead of waiting for them ----
@@ -675,9 +694,14 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // batch, offset = its first sample, per axis
         const double of0 = axes[0], of1 = axes[33], of2 = axes[66];
         const double sc0 = axes[1] - of0, sc1 = axes[34] - of1, sc2 = axes[67] - of2;
+        const int park_slot = (pq_head + pq_count) % MESH_PARK_DEPTH;   // (the FIFO has room: a full one was waited for above)
         if (parking) {
-            pend_w = w; pend_total = total;
-            if (tid == 0) { pend_xf[0] = of0; pend_xf[1] = of1; pend_xf[2] = of2; pend_xf[3] = sc0; pend_xf[4] = sc1; pend_xf[5] = sc2; }
+            if (tid == 0) {
+                double *xf = pend_xf(park_slot);
+                xf[0] = of0; xf[1] = of1; xf[2] = of2; xf[3] = sc0; xf[4] = sc1; xf[5] = sc2;
+                pend_wt(park_slot)[0] = w; pend_wt(park_slot)[1] = total;
+            }
+            pq_count++;
             if (a.prof && tid == 0) atomicAdd(&a.prof[7], 1ull);
         }
         SDF_PROF(2);
@@ -715,7 +739,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             __syncthreads();
             SDF_PROF(3);
             double *dst0 = a.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
-            float *park0 = my_park + (size_t)lo * 9;
+            float *park0 = my_park + ((size_t)park_slot * (size_t)a.park_cap + (size_t)lo) * 9;
             for (int t = tid; t < cn; t += BLOCK) {
                 const unsigned e = list[t];
                 const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
@@ -752,7 +776,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         __syncthreads();   // vol / bcast are reused by the next batch
     }
     SDF_FRESH();
-    place_parked(pend_w >= 0 && tid < 64 ? lookback_prefetch(a.status, pend_w, work_begin) : 0ull);
+    place_parked(pq_count > 0 && tid < 64 ? lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin) : 0ull, true);
     SDF_PROF(5);
 #undef SDF_FRESH
 #undef SDF_PROF

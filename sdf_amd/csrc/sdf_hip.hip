@@ -919,7 +919,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
-        if (c->parking && !c->park.p) { quiet = false; if (c->park.ensure((size_t)c->n_cu * SDF_PARK_TRIS * 36)) return 1; }
+        if (c->parking && !c->park.p) { quiet = false; if (c->park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
         a.park = c->parking ? (float *)c->park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
         a.park_spins = (unsigned)c->park_spins;
         a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
