@@ -13,10 +13,13 @@ work) so the work list needs no communication.
 RCCL has no all-gather-v: counts are all-gathered first, buffers are padded to the
 largest count and exchanged with one `all_gather_into_tensor`, then compacted.
 """
+import os
+
 import numpy as np
 
 
 _PAD_HINT = {}     # (tape, grid, shard) -> padded triangle count of the previous exchange
+_UNEVEN_BROKEN = []   # non-empty once an all_gather of unequal sizes was refused: the padded exchange is used from then on
 
 
 def _dist():
@@ -100,21 +103,38 @@ def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None,
         counts = allc[:, 0]
         t_pad = int(counts.max())
 
-        # 2) the exchange step: padded all-gather of the triangle buffers, then compaction
+        # 2) the exchange step: one padded all-gather of the triangle buffers, then compaction.
+        # SDF_DIST_UNEVEN=1 (opt-in: not measurable on the one-GPU boxes this was built on) lets RCCL gather
+        # the unequal shards straight into views of the final soup instead (torch runs that as grouped
+        # broadcasts): no padding, no compaction copy.
         _PAD_HINT[key] = t_pad
         if t_pad:
-            if local is not None and getattr(mesh, 'emitted', False) and local.numel() >= t_pad * 9:
-                local = local[:t_pad * 9]          # (the tail beyond this rank's count is padding)
-            else:
-                local = _local_tensor(mesh, t_pad, device)
-            gathered = torch.empty(world * t_pad * 9, dtype=torch.float64, device=device)
-            td.all_gather_into_tensor(gathered, local, group=group)
-            gathered = gathered.view(world, t_pad * 9)
-            if all(int(c) == t_pad for c in counts):
-                soup = gathered.reshape(-1)
-            else:
-                parts = [gathered[i, :int(counts[i]) * 9] for i in range(world) if counts[i]]
-                soup = torch.cat(parts) if parts else gathered[0, :0]
+            soup = None
+            if (device.type == 'cuda' and td.get_backend(group) == 'nccl' and local is not None
+                    and getattr(mesh, 'emitted', False) and int(counts.min()) > 0 and not _UNEVEN_BROKEN
+                    and os.environ.get('SDF_DIST_UNEVEN') == '1'):
+                try:
+                    total = int(counts.sum())
+                    soup = torch.empty(total * 9, dtype=torch.float64, device=device)
+                    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64) * 9
+                    outs = [soup[int(offs[i]):int(offs[i + 1])] for i in range(world)]
+                    td.all_gather(outs, local[:t_local * 9], group=group)
+                except Exception:              # (raised by every rank alike: sizes are checked before anything is sent)
+                    _UNEVEN_BROKEN.append(True)
+                    soup = None
+            if soup is None:
+                if local is not None and getattr(mesh, 'emitted', False) and local.numel() >= t_pad * 9:
+                    local = local[:t_pad * 9]          # (the tail beyond this rank's count is padding)
+                else:
+                    local = _local_tensor(mesh, t_pad, device)
+                gathered = torch.empty(world * t_pad * 9, dtype=torch.float64, device=device)
+                td.all_gather_into_tensor(gathered, local, group=group)
+                gathered = gathered.view(world, t_pad * 9)
+                if all(int(c) == t_pad for c in counts):
+                    soup = gathered.reshape(-1)
+                else:
+                    parts = [gathered[i, :int(counts[i]) * 9] for i in range(world) if counts[i]]
+                    soup = torch.cat(parts) if parts else gathered[0, :0]
         else:
             soup = torch.empty(0, dtype=torch.float64, device=device)
     finally:
