@@ -17,6 +17,7 @@
 #ifndef SDF_HIP_H
 #define SDF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -148,6 +149,11 @@ int sdf_mesh_emit_stl_host(sdf_mesh *mesh, void *h_out);
  * h_cells = T x 3 int64, the unique-row index of every soup row. */
 int sdf_mesh_weld(sdf_mesh *mesh, int64_t *n_unique);
 int sdf_mesh_weld_fetch(sdf_mesh *mesh, double *h_points, int64_t *h_cells);
+/* Pinned host memory for the results above: copies into it run at the link rate (fresh pageable memory:
+ * ~10 GB/s).  Blocks are recycled through a small free list inside the library (pinning is slow), so
+ * free what you allocate.  Any "host" pointer of this API may point into such a block. */
+int sdf_host_alloc(size_t bytes, void **out);
+int sdf_host_free(void *p);
 /* per-batch classification, n_batches bytes: 0 skipped, 1 empty, 2 nonempty, 3 other shard */
 int sdf_mesh_kinds(sdf_mesh *mesh, uint8_t *h_out);
 /* diagnostics: what the interval prepass decided, 16 words per batch in batch order like

@@ -83,6 +83,8 @@ ABI = {
     'sdf_mesh_emit_stl_host': (ctypes.c_int, [_vp, _vp]),
     'sdf_mesh_weld': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     'sdf_mesh_weld_fetch': (ctypes.c_int, [_vp, _f64p, ctypes.POINTER(ctypes.c_int64)]),
+    'sdf_host_alloc': (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    'sdf_host_free': (ctypes.c_int, [_vp]),
     'sdf_mesh_kinds': (ctypes.c_int, [_vp, _u8p]),
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
@@ -148,6 +150,37 @@ class DeviceTape:
                                                     tape.n_instr))
 
 
+class _PinnedBlock:
+    """a block of the library's pinned host memory (sdf_host_alloc) that an ndarray can sit on: the
+    array keeps this object as its base, and the block goes back to the library's free list when the
+    last view of it is gone"""
+
+    def __init__(self, lib, nbytes):
+        p = _vp()
+        _check(lib, lib.sdf_host_alloc(max(int(nbytes), 1), ctypes.byref(p)))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+        self._fin = weakref.finalize(self, lib.sdf_host_free, _vp(self.ptr))
+
+    @property
+    def __array_interface__(self):
+        return {'shape': (self.nbytes,), 'typestr': '|u1', 'data': (self.ptr, False), 'version': 3}
+
+
+def pinned_empty(lib, shape, dtype):
+    """np.empty in pinned host memory (results of large device-to-host copies land here: PCIe rate
+    instead of the ~10 GB/s of fresh pageable memory); falls back to np.empty when pinning fails"""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    if n < (1 << 20):
+        return np.empty(shape, dtype)
+    try:
+        blk = _PinnedBlock(lib, n)
+    except SdfHipError:
+        return np.empty(shape, dtype)
+    return np.asarray(blk)[:n].view(dtype).reshape(shape)
+
+
 class Mesh:
     """result of one `generate` call (`sdf_mesh*`): triangle soup resident on the device"""
 
@@ -194,7 +227,7 @@ class Mesh:
     def points(self):
         """(3T, 3) float64 world-space soup in reference order, copied to the host"""
         t = self.n_triangles
-        out = np.empty((3 * t, 3), np.float64)
+        out = pinned_empty(self.engine.lib, (3 * t, 3), np.float64)
         if t:
             _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_host(self.handle, _dp(out, _f64p)))
         return out
@@ -209,8 +242,8 @@ class Mesh:
         (reference sdf/core.py:160-164), sorted and deduplicated on the device"""
         nu = ctypes.c_int64(0)
         _check(self.engine.lib, self.engine.lib.sdf_mesh_weld(self.handle, ctypes.byref(nu)))
-        pts = np.empty((nu.value, 3), np.float64)
-        cells = np.empty((self.n_triangles, 3), np.int64)
+        pts = pinned_empty(self.engine.lib, (nu.value, 3), np.float64)
+        cells = pinned_empty(self.engine.lib, (self.n_triangles, 3), np.int64)
         if nu.value:
             _check(self.engine.lib, self.engine.lib.sdf_mesh_weld_fetch(self.handle, _dp(pts, _f64p),
                                                                        _dp(cells, ctypes.POINTER(ctypes.c_int64))))
@@ -219,7 +252,7 @@ class Mesh:
     def stl_records(self):
         """T x 50-byte binary STL records (normals computed on the device)"""
         t = self.n_triangles
-        out = np.empty(50 * t, np.uint8)
+        out = pinned_empty(self.engine.lib, (50 * t,), np.uint8)
         if t:
             _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_stl_host(self.handle, out.ctypes.data_as(_vp)))
         return out

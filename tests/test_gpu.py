@@ -686,3 +686,32 @@ def test_async_generate_matches_sync(ns, eng):
     m.close()
     m = eng.generate(f, A, A, A, 32, True)
     assert np.array_equal(m.points(), want[0][0]); m.close()
+
+
+def test_results_land_in_recycled_pinned_memory(ns, eng):
+    """large results come back in the library's pinned host blocks (sdf_host_alloc); a block returns to the
+    free list when the last view of the array is gone and is handed out again"""
+    f = fixtures.build('ex_example', ns)
+    A = np.arange(-1.2, 1.2, 2.4 / 200)
+    m = eng.generate(f, A, A, A, 32, True)
+    p1 = m.points()
+    assert p1.nbytes > (1 << 20) and p1.base is not None          # (a view of a pinned block)
+    want = p1.copy()
+    root = p1
+    while isinstance(root.base, np.ndarray):
+        root = root.base
+    addr = root.base.ptr
+    del p1, root
+    import gc; gc.collect()
+    p2 = m.points()                                               # the same block again
+    root = p2
+    while isinstance(root.base, np.ndarray):
+        root = root.base
+    assert root.base.ptr == addr and np.array_equal(p2, want)
+    rec = m.stl_records()
+    view = p2[:10]
+    del p2
+    gc.collect()
+    assert np.array_equal(view, want[:10])                        # a live view keeps its block
+    assert len(rec) == 50 * m.n_triangles
+    m.close()
