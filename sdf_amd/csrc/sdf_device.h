@@ -623,46 +623,129 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         unsigned row_mask[RPT];
         unsigned long long row_bits[RPT][4];   // sign bits of the four sample rows (o0, o1) of a cell row
         int total = 0, my_amb = 0;
+        // sign strings of the four sample rows around cell row (i0, i1) and the mask of its surface cells
+        auto row_signs = [&](int i0, int i1, unsigned long long *rb) -> unsigned {
+            SDF_UNROLL
+            for (int q = 0; q < 4; q++) {   // q = 2 * o0 + o1
+                const int o = (i0 + (q >> 1)) * lyz + (i1 + (q & 1)) * lz;
+                const unsigned long long w0 = bits[o >> 6], w1 = bits[(o >> 6) + 1];
+                const int sh = o & 63;
+                rb[q] = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+            }
+            // a cell (columns i2, i2 + 1) has a surface unless its 8 bits are all equal
+            const unsigned long long any = rb[0] | rb[1] | rb[2] | rb[3];
+            const unsigned long long all = rb[0] & rb[1] & rb[2] & rb[3];
+            const unsigned long long ones = all & (all >> 1), zeros = ~any & ~(any >> 1);
+            return (unsigned)(~(ones | zeros)) & (c2 >= 32 ? 0xFFFFFFFFu : ((1u << c2) - 1u));
+        };
+        // ---- 2a. surface cells per row, their running count over the rows (the order of the soup) ----
+        int ncells = 0, row_cell0[RPT];
         SDF_UNROLL
         for (int k = 0; k < RPT; k++) {
             const int r = tid + k * BLOCK;
-            int n = 0;
             unsigned mask = 0;
             SDF_UNROLL for (int q = 0; q < 4; q++) row_bits[k][q] = 0ull;
             if (r < nrows) {
                 const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
-                SDF_UNROLL
-                for (int q = 0; q < 4; q++) {   // q = 2 * o0 + o1
-                    const int o = (i0 + (q >> 1)) * lyz + (i1 + (q & 1)) * lz;
-                    const unsigned long long w0 = bits[o >> 6], w1 = bits[(o >> 6) + 1];
-                    const int sh = o & 63;
-                    row_bits[k][q] = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-                }
-                // a cell (columns i2, i2 + 1) has a surface unless its 8 bits are all equal
-                const unsigned long long any = row_bits[k][0] | row_bits[k][1] | row_bits[k][2] | row_bits[k][3];
-                const unsigned long long all = row_bits[k][0] & row_bits[k][1] & row_bits[k][2] & row_bits[k][3];
-                const unsigned long long ones = all & (all >> 1), zeros = ~any & ~(any >> 1);
-                mask = (unsigned)(~(ones | zeros)) & (c2 >= 32 ? 0xFFFFFFFFu : ((1u << c2) - 1u));
-                unsigned m = mask;
+                mask = row_signs(i0, i1, row_bits[k]);
+            }
+            row_mask[k] = mask;
+            int tot;
+            row_cell0[k] = ncells + block_exclusive_scan<BLOCK>(__popc(mask), wave_sums, tot);
+            ncells += tot;
+        }
+        // ---- 2b. ONE THREAD PER SURFACE CELL (up to MESH_CELL_CHUNKS * BLOCK of them).  The row's thread only
+        // SCATTERS its cells -- (row, column, sign configuration) into a table at the cell's running index, a few
+        // ALU instructions and one LDS write each, nothing to wait for; then thread s takes cell s: looks up its
+        // triangles and, after a scan, writes them into the triangle list right away.  A thread per ROW used to
+        // walk its surface cells one dependent LDS look-up after the other, here and again when the list was
+        // built: a surface that runs along the rows (a flat face: 32 surface cells in each of a few rows, none
+        // in the others) made both phases wait for a handful of lanes -- a tenth of the kernel.  Batches with
+        // more cells, or more triangles than the list holds, take the per-row path below.  (The table lives in
+        // the list region: every thread has read its entry before the scan's barriers, the list is written
+        // behind them.) ----
+        bool list_ready = false;
+        constexpr int MESH_CELL_CHUNKS = 2;
+        if (ncells <= MESH_CELL_CHUNKS * BLOCK && (size_t)a.list_cap >= (size_t)MESH_CELL_CHUNKS * BLOCK) {
+            SDF_UNROLL
+            for (int k = 0; k < RPT; k++) {
+                const int r = tid + k * BLOCK;
+                unsigned m = row_mask[k];
+                int pos = row_cell0[k];
                 while (m) {
                     const int i2 = __ffs((int)m) - 1;
                     m &= m - 1u;
-                    const unsigned e = ntri_lds[cell_config(row_bits[k], i2)];
+                    list[pos++] = (unsigned)r | ((unsigned)i2 << 10) | (cell_config(row_bits[k], i2) << 15);
+                }
+            }
+            __syncthreads();
+            unsigned cinfo[MESH_CELL_CHUNKS];
+            int cn[MESH_CELL_CHUNKS], coff[MESH_CELL_CHUNKS];
+            SDF_UNROLL
+            for (int k = 0; k < MESH_CELL_CHUNKS; k++) {
+                const int sidx = tid + k * BLOCK;
+                int n = 0;
+                unsigned info = 0;
+                if (sidx < ncells) {
+                    const unsigned ce = list[sidx];
+                    const int r = (int)(ce & 1023u), i2 = (int)((ce >> 10) & 31u), i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
+                    const unsigned cfg = ce >> 15;
+                    const unsigned e = ntri_lds[cfg];
                     if (e & 128u) {   // ambiguous configuration: Lewiner's tests pick the tiling (rare)
                         double lv[8];
                         int off;
                         mc33_load_cell(vol + i0 * lyz + i1 * lz + i2, lyz, lz, lv);
-                        n += mc33_cell(lv, a.mc->mc33, &off);
+                        n = mc33_cell(lv, a.mc->mc33, &off);
                         my_amb++;
                     } else {
-                        n += (int)(e & 7u);
+                        n = (int)(e & 7u);
+                    }
+                    // entry: cell (15 bits) | ambiguous (1) | configuration (8) | triangle in cell (4)
+                    info = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((e & 128u) << 5) | (cfg << 4);
+                }
+                int tot = 0;
+                coff[k] = total;
+                if (k * BLOCK < ncells) { coff[k] += block_exclusive_scan<BLOCK>(n, wave_sums, tot); total += tot; }   // (uniform)
+                cinfo[k] = info; cn[k] = n;
+            }
+            if (total <= a.list_cap) {
+                SDF_UNROLL
+                for (int k = 0; k < MESH_CELL_CHUNKS; k++)
+                    for (int j = 0; j < cn[k]; j++) list[coff[k] + j] = cinfo[k] | (unsigned)j;
+                list_ready = true;        // (made visible by the barriers of the allocation below)
+            }
+        }
+        SDF_UNROLL for (int k = 0; k < RPT; k++) { row_tris[k] = 0; row_off[k] = 0; }
+        if (!list_ready) {
+            // ---- 2c. per-row counting: a thread owns the i2-rows of cells (i0, i1) = row tid + k * BLOCK ----
+            total = 0; my_amb = 0;
+            SDF_UNROLL
+            for (int k = 0; k < RPT; k++) {
+                const int r = tid + k * BLOCK;
+                int n = 0;
+                if (r < nrows) {
+                    const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
+                    unsigned m = row_mask[k];
+                    while (m) {
+                        const int i2 = __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        const unsigned e = ntri_lds[cell_config(row_bits[k], i2)];
+                        if (e & 128u) {
+                            double lv[8];
+                            int off;
+                            mc33_load_cell(vol + i0 * lyz + i1 * lz + i2, lyz, lz, lv);
+                            n += mc33_cell(lv, a.mc->mc33, &off);
+                            my_amb++;
+                        } else {
+                            n += (int)(e & 7u);
+                        }
                     }
                 }
+                row_tris[k] = n;
+                int tot;
+                row_off[k] = total + block_exclusive_scan<BLOCK>(n, wave_sums, tot);
+                total += tot;
             }
-            row_tris[k] = n; row_mask[k] = mask;
-            int tot;
-            row_off[k] = total + block_exclusive_scan<BLOCK>(n, wave_sums, tot);
-            total += tot;
         }
         // ---- the batch's count is public from here on; bookkeeping that needs no position ----
         if (tid < 64) publish_count(a.status, w, work_begin, (unsigned long long)total);
@@ -712,7 +795,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             const int cn = min(a.list_cap, total - lo);
             SDF_UNROLL
             for (int k = 0; k < RPT; k++) {
-                if (row_tris[k] == 0 || row_off[k] >= lo + cn || row_off[k] + row_tris[k] <= lo) continue;
+                if (list_ready || row_tris[k] == 0 || row_off[k] >= lo + cn || row_off[k] + row_tris[k] <= lo) continue;
                 const int r = tid + k * BLOCK;
                 const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
                 const float *row = vol + i0 * lyz + i1 * lz;
