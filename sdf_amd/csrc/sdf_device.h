@@ -288,7 +288,7 @@ struct TileTasks {
 // scratch: u16 task count, tlist (u16 each), CULL_GSTATE: group states | from CULL_COUNT + 16: the states
 // of the 8^3-cell boxes (64 bytes) and the list of groups to evaluate (512 u16)
 enum { CULL_GSTATE = 1152, CULL_COUNT = 1664, CULL_RECORD = 1664, CULL_SCRATCH = 2816 };   // a batch's record in global memory: bytes [0, CULL_RECORD)
-template <int BLOCK, bool FULL>
+template <int BLOCK, bool FULL, bool RARE>
 __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *consts, int n_instr_w, int lx, int ly, int lz,
                                        const double *axes, double *ia_state, int ia_bytes, unsigned char *scratch, int *wave_sums,
                                        int ia_np, int ia_nd) {
@@ -306,7 +306,7 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
         if (by.lo > by.hi) { const double t = by.lo; by.lo = by.hi; by.hi = t; }
         if (bz.lo > bz.hi) { const double t = bz.lo; bz.lo = bz.hi; bz.hi = t; }
         if (ia::bad(bx) || ia::bad(by) || ia::bad(bz)) { bx = by = bz = ia::top(); }
-        const Ival v = ia_run_tape<false, FULL>(wcode, consts, nullptr, nullptr, n_instr_w, bx, by, bz, true,
+        const Ival v = ia_run_tape<false, FULL, RARE>(wcode, consts, nullptr, nullptr, n_instr_w, bx, by, bz, true,
                                           IaShared{ia_state, ia_np, per_pass}, ia_nd, nullptr);
         return v.lo > 1e-30 ? 1 : (v.hi < -1e-30 ? 2 : 0);
     };

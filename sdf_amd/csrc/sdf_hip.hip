@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
 // One workgroup per work item of this shard: which sampling tasks of the batch have to be evaluated
 // (cull_tasks, sdf_device.h).  The record goes to global memory; k_mesh picks it up.
 #define CULL_BLOCK 256
-template <bool FULL>
+template <bool FULL, bool RARE>
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict_
     __syncthreads();
     const uint32_t *wcode = code + (size_t)b * (size_t)tape_stride * 2;
     const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
-    const int ntl = cull_tasks<CULL_BLOCK, FULL>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd);
+    const int ntl = cull_tasks<CULL_BLOCK, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd);
     if (tid == 0) reinterpret_cast<unsigned short *>(scratch)[0] = ntl < 0 ? (unsigned short)0xFFFF : (unsigned short)ntl;
     __syncthreads();
     for (int i = tid; i < CULL_RECORD / 4; i += CULL_BLOCK)
@@ -386,6 +386,7 @@ struct sdf_tape {
     uint32_t n_p = 0, n_d = 0;
     uint16_t *d_rstart = nullptr, *d_lstart = nullptr;   // operand ranges of the prunable combines (or NULL)
     bool ia_complete = false;                            // every op has an interval form (sdf_interval.h ia_has_form)
+    bool ia_rare = false;                                // ... one of them a leaf of ia_leaf_rare (the k_cull variant that knows them)
     unsigned long long hint_key = 0, hint_total_tris = 0;   // arena sizing: last call of this tape
 };
 
@@ -564,7 +565,10 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     t->ctx = c; t->n_words = n_words; t->n_consts = n_consts;
     t->full = tape_needs_full(code, n_words, consts);
     t->ia_complete = true;
-    for (uint32_t i = 0; i < n_words; i += 2) t->ia_complete = t->ia_complete && ia_has_form(code[i] & 255u);
+    for (uint32_t i = 0; i < n_words; i += 2) {
+        t->ia_complete = t->ia_complete && ia_has_form(code[i] & 255u);
+        t->ia_rare = t->ia_rare || ia_is_rare_leaf(code[i] & 255u);
+    }
     t->n_p = n_p; t->n_d = n_d;
     // two more constants behind the tape's own: a K slot and +0.0, the operand of the `acc + (+0.0)` that a
     // decided smooth combine turns into (sdf_interval.h compact_tape); an instruction with constant
@@ -864,7 +868,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const int ia_np = (int)std::max(t->n_p, 1u), ia_nd = (int)std::max(t->n_d, 1u);
         const size_t ia_bytes = std::min<size_t>((size_t)CULL_BLOCK * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
-        auto kc = t->full ? k_cull<true> : k_cull<false>;
+        auto kc = t->full ? (t->ia_rare ? k_cull<true, true> : k_cull<true, false>) : (t->ia_rare ? k_cull<false, true> : k_cull<false, false>);
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kc, dim3(nb), dim3(CULL_BLOCK), lds, c->stream,
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,

@@ -130,6 +130,31 @@ SDF_IA Ival mul(const Ival &a, const Ival &b) {
     return wide(fmin(fmin(p0, p1), fmin(p2, p3)), fmax(fmax(p0, p1), fmax(p2, p3)));
 }
 SDF_IA Ival rint_(const Ival &a) { return wide(rint(a.lo), rint(a.hi)); }
+SDF_IA Ival hull(const Ival &a, const Ival &b) { return (bad(a) || bad(b)) ? top() : Ival{fmin(a.lo, b.lo), fmax(a.hi, b.hi)}; }
+// a / b for b > 0: the rounded quotient is monotone in each argument, so the corners span it
+SDF_IA Ival div_pos(const Ival &a, const Ival &b) {
+    if (bad(a) || bad(b) || !(b.lo > 0.0)) return top();
+    const double q0 = a.lo / b.lo, q1 = a.lo / b.hi, q2 = a.hi / b.lo, q3 = a.hi / b.hi;
+    if (q0 != q0 || q1 != q1 || q2 != q2 || q3 != q3) return top();
+    return wide(fmin(fmin(q0, q1), fmin(q2, q3)), fmax(fmax(q0, q1), fmax(q2, q3)));
+}
+// np.sign over an interval: -1, 0 or 1 at each end (monotone)
+SDF_IA Ival sign_(const Ival &a) {
+    if (bad(a)) return Ival{-1.0, 1.0};
+    return Ival{a.lo > 0.0 ? 1.0 : (a.lo < 0.0 ? -1.0 : 0.0), a.hi > 0.0 ? 1.0 : (a.hi < 0.0 ? -1.0 : 0.0)};
+}
+// p - clip(p, lo, hi): non-decreasing in p (p - lo below, 0 inside, p - hi above), one rounding per value
+SDF_IA Ival sub_clip(const Ival &p, double lo, double hi) {
+    if (bad(p) || lo != lo || hi != hi) return top();
+    return wide(p.lo - fmin(fmax(p.lo, lo), hi), p.hi - fmin(fmax(p.hi, lo), hi));
+}
+// cond ? a : b where cond = (l > r): decided when the intervals do not overlap, else both are possible
+SDF_IA Ival sel_gt(const Ival &l, const Ival &r, const Ival &a, const Ival &b) {
+    if (bad(l) || bad(r)) return top();
+    if (l.lo > r.hi) return a;
+    if (l.hi <= r.lo) return b;
+    return hull(a, b);
+}
 // s_clip(x, lo, hi) of sdf_interp.h for non-NaN x: min(max(x, lo), hi), monotone in x
 SDF_IA Ival clipc(const Ival &a, double lo, double hi) {
     if (lo != lo || hi != hi) return top();
@@ -245,6 +270,9 @@ __host__ __device__ inline bool ia_has_form(uint32_t op) {
     switch (op) {
     case OP_END: case OP_L_SPHERE: case OP_L_PLANE: case OP_L_BOX: case OP_L_ROUNDED_BOX: case OP_L_TORUS: case OP_L_CYLINDER:
     case OP_L_ROUNDED_CYLINDER: case OP_L_CAPSULE: case OP_L_OCTAHEDRON: case OP_L_CIRCLE: case OP_L_LINE: case OP_L_RECTANGLE:
+    case OP_L_WIREFRAME_BOX: case OP_L_CAPPED_CYLINDER: case OP_L_ROUNDED_CONE: case OP_L_ELLIPSOID: case OP_L_TETRAHEDRON:
+    case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: case OP_L_ROUNDED_RECTANGLE: case OP_L_EQUILATERAL_TRIANGLE: case OP_L_HEXAGON:
+    case OP_L_ROUNDED_X: case OP_L_VESICA:
     case OP_COMB: case OP_TRANSLATE: case OP_SCALE: case OP_ROTATE: case OP_ELONGATE: case OP_TRANSLATE2: case OP_SCALE2:
     case OP_ROTATE2: case OP_ELONGATE2: case OP_REVOLVE: case OP_SETZ0: case OP_SAVE_P: case OP_LOAD_P: case OP_PUSH_D: case OP_NOP:
     case OP_NEG: case OP_ADDC: case OP_SUBC: case OP_MULC: case OP_SHELL: case OP_ADD_DS: case OP_EXT_PRE: case OP_EXT_POST:
@@ -256,7 +284,7 @@ __host__ __device__ inline bool ia_has_form(uint32_t op) {
     }
 }
 
-__device__ __forceinline__ Ival ia_box_like(const Ival &qx, const Ival &qy, const Ival &qz) {
+SDF_IA Ival ia_box_like(const Ival &qx, const Ival &qy, const Ival &qz) {
     using namespace ia;
     const Ival mx = max_(max_(qx, qy), qz);
     return add(len3(maxc(qx, 0.0), maxc(qy, 0.0), maxc(qz, 0.0)), minc(mx, 0.0));
@@ -264,7 +292,7 @@ __device__ __forceinline__ Ival ia_box_like(const Ival &qx, const Ival &qy, cons
 
 // value interval of a leaf (the formulas of sdf_interp.h, operation by operation), or the whole
 // line for leaves without an interval form
-__device__ __noinline__ Ival ia_leaf(uint32_t op, const double *c, const Ival &x, const Ival &y, const Ival &z) {
+__host__ __device__ __attribute__((noinline)) inline Ival ia_leaf(uint32_t op, const double *c, const Ival &x, const Ival &y, const Ival &z) {
     using namespace ia;
     switch (op) {
     case OP_L_SPHERE: return subc(len3(subc(x, c[1]), subc(y, c[2]), subc(z, c[3])), c[0]);
@@ -290,6 +318,132 @@ __device__ __noinline__ Ival ia_leaf(uint32_t op, const double *c, const Ival &x
     case OP_L_RECTANGLE: {
         const Ival qx = subc(abs_(subc(x, c[0])), c[2]), qy = subc(abs_(subc(y, c[1])), c[3]);
         return add(len2(maxc(qx, 0.0), maxc(qy, 0.0)), minc(max_(qx, qy), 0.0));
+    }
+    default: return top();
+
+    }
+}
+
+// The less common leaves, in a function of their own: a kernel's register budget is that of its
+// hungriest callee, and these would cost the cell-group pass (k_cull) a wave of occupancy on every tape.
+// Kernels are instantiated with and without them (RARE); the host picks by the tape's content.
+SDF_IA bool ia_is_rare_leaf(uint32_t op) {
+    switch (op) {
+    case OP_L_WIREFRAME_BOX: case OP_L_CAPPED_CYLINDER: case OP_L_ROUNDED_CONE: case OP_L_ELLIPSOID: case OP_L_TETRAHEDRON:
+    case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: case OP_L_ROUNDED_RECTANGLE: case OP_L_EQUILATERAL_TRIANGLE: case OP_L_HEXAGON:
+    case OP_L_ROUNDED_X: case OP_L_VESICA:
+        return true;
+    default: return false;
+    }
+}
+__host__ __device__ __attribute__((noinline)) inline Ival ia_leaf_rare(uint32_t op, const double *c, const Ival &x, const Ival &y, const Ival &z) {
+    using namespace ia;
+    switch (op) {
+    // The leaves below are compositions of the interval operations above, step by step in the order of
+    // sdf_interp.h: every step encloses the rounded result of its operation over the step's argument
+    // intervals, so the composition encloses the leaf (dependencies between sub-expressions only cost
+    // tightness).  A data-dependent choice (vsel) is decided when the intervals of its condition do not
+    // overlap and is the hull of both arms otherwise.
+    case OP_L_WIREFRAME_BOX: {
+        const double t2 = c[3];
+        const Ival px = subc(subc(abs_(x), c[0]), t2), py = subc(subc(abs_(y), c[1]), t2), pz = subc(subc(abs_(z), c[2]), t2);
+        const Ival qx = subc(abs_(addc(px, t2)), t2), qy = subc(abs_(addc(py, t2)), t2), qz = subc(abs_(addc(pz, t2)), t2);
+        const Ival g0 = add(len3(maxc(px, 0.0), maxc(qy, 0.0), maxc(qz, 0.0)), minc(max_(px, max_(qy, qz)), 0.0));
+        const Ival g1 = add(len3(maxc(qx, 0.0), maxc(py, 0.0), maxc(qz, 0.0)), minc(max_(qx, max_(py, qz)), 0.0));
+        const Ival g2 = add(len3(maxc(qx, 0.0), maxc(qy, 0.0), maxc(pz, 0.0)), minc(max_(qx, max_(qy, pz)), 0.0));
+        return min_(min_(g0, g1), g2);
+    }
+    case OP_L_CAPPED_CYLINDER: {
+        const double bax = c[3], bay = c[4], baz = c[5], baba = c[6];
+        if (!(baba > 0.0)) return top();
+        const Ival pax = subc(x, c[0]), pay = subc(y, c[1]), paz = subc(z, c[2]);
+        const Ival paba = dot3c(pax, pay, paz, bax, bay, baz);
+        const Ival xx = subc(len3(sub(mulc(pax, baba), mulc(paba, bax)), sub(mulc(pay, baba), mulc(paba, bay)),
+                                  sub(mulc(paz, baba), mulc(paba, baz))), c[8]);
+        const Ival yy = subc(abs_(subc(paba, c[9])), c[9]);
+        const Ival x2 = sqr(xx), y2 = mulc(sqr(yy), baba);
+        const Ival zero = pt(0.0);
+        const Ival din = neg(min_(x2, y2));
+        const Ival dout = add(sel_gt(xx, zero, x2, zero), sel_gt(yy, zero, y2, zero));
+        const Ival d = sel_gt(zero, max_(xx, yy), din, dout);          // max(xx, yy) < 0
+        if (bad(d)) return top();
+        // sign(d) * sqrt(|d|) / baba is non-decreasing in d
+        const double lo = (d.lo > 0.0 ? 1.0 : (d.lo < 0.0 ? -1.0 : 0.0)) * sqrt(fabs(d.lo)) / baba;
+        const double hi = (d.hi > 0.0 ? 1.0 : (d.hi < 0.0 ? -1.0 : 0.0)) * sqrt(fabs(d.hi)) / baba;
+        return wide(lo, hi);
+    }
+    case OP_L_ROUNDED_CONE: {
+        const double r1 = c[0], r2 = c[1], h = c[2], b = c[3], a = c[4], ah = c[5];
+        const Ival qx = len2(x, y), qy = z;
+        const Ival k = dot2c(qx, qy, -b, a);
+        const Ival c1 = subc(len2(qx, qy), r1), c2 = subc(len2(qx, subc(qy, h)), r2), c3 = subc(dot2c(qx, qy, a, b), r1);
+        if (bad(k) || ah != ah) return top();
+        Ival r{0.0, 0.0};                                               // the hull of the arms k can reach
+        bool any = false;
+        if (k.lo < 0.0) { r = c1; any = true; }
+        if (k.hi >= 0.0) {
+            if (k.hi > ah) { r = any ? hull(r, c2) : c2; any = true; }
+            if (fmax(k.lo, 0.0) <= ah) { r = any ? hull(r, c3) : c3; any = true; }
+        }
+        return any ? fix(r) : top();
+    }
+    case OP_L_ELLIPSOID: {
+        const Ival k0 = len3(divc(x, c[0]), divc(y, c[1]), divc(z, c[2]));
+        const Ival k1 = len3(divc(x, c[3]), divc(y, c[4]), divc(z, c[5]));
+        return div_pos(mul(k0, subc(k0, 1.0)), k1);
+    }
+    case OP_L_TETRAHEDRON:
+        return divc(subc(max_(sub(abs_(add(x, y)), z), add(abs_(sub(x, y)), z)), c[0]), c[1]);
+    case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: {
+        const double r = c[0], X = c[1], Y = c[2], Z = c[3];
+        const Ival ax = abs_(divc(x, r)), ay = abs_(divc(y, r)), az = abs_(divc(z, r));
+        const Ival a = dot3c(ax, ay, az, X, Y, Z), b = dot3c(ax, ay, az, Z, X, Y), cc = dot3c(ax, ay, az, Y, Z, X);
+        const Ival m = subc(max_(max_(a, b), cc), X);
+        if (op == OP_L_DODECAHEDRON) return mulc(m, r);
+        return mulc(max_(m, subc(dot3c(ax, ay, az, c[4], c[4], c[4]), X)), r);
+    }
+    case OP_L_ROUNDED_RECTANGLE: {
+        if (bad(x) || bad(y)) return top();
+        // the corner radius of the quadrant the point is in: x > 0 / y > 0 decide it (d2.py:116-134)
+        const bool xt = x.hi > 0.0, xf = !(x.lo > 0.0), yt = y.hi > 0.0, yf = !(y.lo > 0.0);
+        double rl = __builtin_inf(), rh = -__builtin_inf();
+        if (xt && yt) { rl = fmin(rl, c[2]); rh = fmax(rh, c[2]); }
+        if (xt && yf) { rl = fmin(rl, c[3]); rh = fmax(rh, c[3]); }
+        if (xf && yf) { rl = fmin(rl, c[4]); rh = fmax(rh, c[4]); }
+        if (xf && yt) { rl = fmin(rl, c[5]); rh = fmax(rh, c[5]); }
+        if (!(rl <= rh)) return top();
+        const Ival r{rl, rh};
+        const Ival qx = add(subc(abs_(x), c[0]), r), qy = add(subc(abs_(y), c[1]), r);
+        return sub(add(minc(max_(qx, qy), 0.0), len2(maxc(qx, 0.0), maxc(qy, 0.0))), r);
+    }
+    case OP_L_EQUILATERAL_TRIANGLE: {
+        const double k = c[0];
+        Ival px = subc(abs_(x), 1.0), py = addc(y, c[1]);
+        const Ival w = add(px, mulc(py, k));
+        const Ival nx = divc(sub(px, mulc(py, k)), 2.0), ny = divc(sub(mulc(px, -k), py), 2.0);
+        const Ival zero = pt(0.0);
+        const Ival sx = sel_gt(w, zero, nx, px), sy = sel_gt(w, zero, ny, py);
+        px = sub_clip(sx, -2.0, 0.0); py = sy;
+        return mul(neg(len2(px, py)), sign_(py));
+    }
+    case OP_L_HEXAGON: {
+        const double r = c[0], k0 = c[1], k1 = c[2];
+        Ival px = abs_(x), py = abs_(y);
+        const Ival m = minc(add(mulc(px, k0), mulc(py, k1)), 0.0);
+        px = sub(px, mulc(m, c[4])); py = sub(py, mulc(m, c[5]));
+        px = sub_clip(px, c[6], c[7]); py = subc(py, 0.0 + r);
+        return mul(len2(px, py), sign_(py));
+    }
+    case OP_L_ROUNDED_X: {
+        const Ival px = abs_(x), py = abs_(y);
+        const Ival qq = mulc(minc(add(px, py), c[0]), 0.5);
+        return subc(len2(sub(px, qq), sub(py, qq)), c[1]);
+    }
+    case OP_L_VESICA: {
+        const double r = c[0], d = c[1], b = c[2];
+        const Ival px = abs_(x), py = abs_(y);
+        const Ival v1 = len2(px, subc(py, b)), v2 = subc(len2(subc(px, -d), py), r);
+        return sel_gt(mulc(subc(py, b), d), mulc(px, b), v1, v2);
     }
     default: return top();
     }
@@ -371,7 +525,7 @@ __device__ __forceinline__ uint32_t mask_word(const uint32_t *m, int idx) {
 // lanes of the wave run the same tape (uniform control flow).  With DECIDE the 8 lanes of a batch
 // agree on which operands to drop with a ballot and every one of them records it: masks[0..8) skip
 // bits, masks[8..16) forced bits (without DECIDE rstart / lstart / masks are not touched).
-template <bool DECIDE, bool FULL>
+template <bool DECIDE, bool FULL, bool RARE>
 __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, const double *__restrict__ consts,
                                             const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart, int n_instr,
                                             Ival x, Ival y, Ival z, bool live, IaShared sh, int n_d, uint32_t *masks) {
@@ -402,7 +556,11 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
         const bool is_leaf = op >= OP_L_SPHERE && op < OP_COMB;
         if (is_leaf || op == OP_COMB) {
             const Ival left = is_leaf ? acc : dload(sa);
-            const Ival right = is_leaf ? ia_leaf(op, c, x, y, z) : acc;
+            Ival right = acc;
+            if (is_leaf) {
+                if (RARE && ia_is_rare_leaf(op)) right = ia_leaf_rare(op, c, x, y, z);
+                else right = ia_leaf(op, c, x, y, z);
+            }
             int rs = 0xFFFF, ls = 0xFFFF;
             if constexpr (DECIDE) { rs = rstart[ip]; ls = lstart[ip]; }
             if (DECIDE && rs != 0xFFFF && ls != 0xFFFF && rs <= ip && ls <= rs) {

@@ -43,7 +43,7 @@ __device__ __forceinline__ void prune_block(const uint32_t *__restrict__ code, c
     }
     uint32_t masks[16];
     for (int k = 0; k < 16; k++) masks[k] = 0;
-    ia_run_tape<true, FULL>(code, pa.consts, pa.rstart, pa.lstart, pa.n_instr, bx, by, bz, live, IaShared{lds, pa.n_p, PRUNE_BLOCK}, pa.n_d, masks);
+    ia_run_tape<true, FULL, true>(code, pa.consts, pa.rstart, pa.lstart, pa.n_instr, bx, by, bz, live, IaShared{lds, pa.n_p, PRUNE_BLOCK}, pa.n_d, masks);
     const bool store = live && oct == 0;
     unsigned long long *out = pa.tapes_out + (size_t)(live ? b : 0) * pa.tape_stride;
     const int n = compact_tape(reinterpret_cast<const unsigned long long *>(code), pa.n_instr, masks, out, store, pa.zero_off);

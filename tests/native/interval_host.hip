@@ -130,6 +130,117 @@ int main() {
             tight_sum += 0; 
         }
     }
+    // ---- leaves composed of interval steps: point values (the formulas of sdf_interp.h) inside ia_leaf's interval ----
+    {
+        auto smin = [](double a, double b) { return (a < b || a != a) ? a : b; };
+        auto smax = [](double a, double b) { return (a >= b || a != a) ? a : b; };
+        auto sclip = [](double x, double lo, double hi) { double t = (x != x || x > lo) ? x : lo; return (t != t || t < hi) ? t : hi; };
+        auto ssign = [](double x) { return x != x ? x : (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0)); };
+        auto l2 = [](double x, double y) { return std::sqrt(x * x + y * y); };
+        auto l3 = [](double x, double y, double z) { return std::sqrt((x * x + y * y) + z * z); };
+        auto d3 = [](double ax, double ay, double az, double bx, double by, double bz) { return std::fma(az, bz, std::fma(ay, by, ax * bx)); };
+        auto d2 = [](double ax, double ay, double bx, double by) { return std::fma(ay, by, ax * bx); };
+        auto leaf = [&](uint32_t op, const double *c, double x, double y, double z) -> double {
+            switch (op) {
+            case OP_L_WIREFRAME_BOX: {
+                const double t2 = c[3];
+                const double px = fabs(x) - c[0] - t2, py = fabs(y) - c[1] - t2, pz = fabs(z) - c[2] - t2;
+                const double qx = fabs(px + t2) - t2, qy = fabs(py + t2) - t2, qz = fabs(pz + t2) - t2;
+                auto g = [&](double a, double b, double cc) { return l3(smax(a, 0), smax(b, 0), smax(cc, 0)) + smin(smax(a, smax(b, cc)), 0); };
+                return smin(smin(g(px, qy, qz), g(qx, py, qz)), g(qx, qy, pz)); }
+            case OP_L_CAPPED_CYLINDER: {
+                const double bax = c[3], bay = c[4], baz = c[5], baba = c[6];
+                const double pax = x - c[0], pay = y - c[1], paz = z - c[2];
+                const double paba = d3(pax, pay, paz, bax, bay, baz);
+                const double xx = l3(pax * baba - bax * paba, pay * baba - bay * paba, paz * baba - baz * paba) - c[8];
+                const double yy = fabs(paba - c[9]) - c[9];
+                const double x2 = xx * xx, y2 = yy * yy * baba;
+                const double din = -smin(x2, y2);
+                const double dout = (xx > 0 ? x2 : 0.0) + (yy > 0 ? y2 : 0.0);
+                const double d = smax(xx, yy) < 0 ? din : dout;
+                return ssign(d) * std::sqrt(fabs(d)) / baba; }
+            case OP_L_ROUNDED_CONE: {
+                const double r1 = c[0], r2 = c[1], h = c[2], b = c[3], a = c[4], ah = c[5];
+                const double qx = l2(x, y), qy = z;
+                const double k = d2(qx, qy, -b, a);
+                const double c1 = l2(qx, qy) - r1, c2 = l2(qx - 0.0, qy - h) - r2, c3 = d2(qx, qy, a, b) - r1;
+                return k < 0 ? c1 : (k > ah ? c2 : c3); }
+            case OP_L_ELLIPSOID: {
+                const double k0 = l3(x / c[0], y / c[1], z / c[2]), k1 = l3(x / c[3], y / c[4], z / c[5]);
+                return k0 * (k0 - 1.0) / k1; }
+            case OP_L_TETRAHEDRON: return (smax(fabs(x + y) - z, fabs(x - y) + z) - c[0]) / c[1];
+            case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: {
+                const double r = c[0], X = c[1], Y = c[2], Z = c[3];
+                const double ax = fabs(x / r), ay = fabs(y / r), az = fabs(z / r);
+                const double a = d3(ax, ay, az, X, Y, Z), b = d3(ax, ay, az, Z, X, Y), cc = d3(ax, ay, az, Y, Z, X);
+                if (op == OP_L_DODECAHEDRON) return (smax(smax(a, b), cc) - X) * r;
+                return smax(smax(smax(a, b), cc) - X, d3(ax, ay, az, c[4], c[4], c[4]) - X) * r; }
+            case OP_L_ROUNDED_RECTANGLE: {
+                const bool xp = x > 0, yp = y > 0;
+                double r = 0;
+                if (xp && yp) r = c[2]; if (xp && !yp) r = c[3]; if (!xp && !yp) r = c[4]; if (!xp && yp) r = c[5];
+                const double qx = fabs(x) - c[0] + r, qy = fabs(y) - c[1] + r;
+                return smin(smax(qx, qy), 0) + l2(smax(qx, 0), smax(qy, 0)) - r; }
+            case OP_L_EQUILATERAL_TRIANGLE: {
+                const double k = c[0];
+                double px = fabs(x) - 1.0, py = y + c[1];
+                const bool w = px + k * py > 0;
+                const double nx = (px - k * py) / 2.0, ny = (-k * px - py) / 2.0;
+                if (w) { px = nx; py = ny; }
+                px = px - sclip(px, -2.0, 0.0);
+                return -l2(px, py) * ssign(py); }
+            case OP_L_HEXAGON: {
+                const double r = c[0], k0 = c[1], k1 = c[2];
+                double px = fabs(x), py = fabs(y);
+                const double m = smin(k0 * px + k1 * py, 0);
+                px = px - c[4] * m; py = py - c[5] * m;
+                px = px - sclip(px, c[6], c[7]); py = py - (0.0 + r);
+                return l2(px, py) * ssign(py); }
+            case OP_L_ROUNDED_X: {
+                const double px = fabs(x), py = fabs(y);
+                const double qq = smin(px + py, c[0]) * 0.5;
+                return l2(px - qq, py - qq) - c[1]; }
+            case OP_L_VESICA: {
+                const double r = c[0], d = c[1], b = c[2];
+                const double px = fabs(x), py = fabs(y);
+                return (py - b) * d > px * b ? l2(px - 0.0, py - b) : l2(px - (-d), py - 0.0) - r; }
+            default: return 0.0;
+            }
+        };
+        const uint32_t ops[] = {OP_L_WIREFRAME_BOX, OP_L_CAPPED_CYLINDER, OP_L_ROUNDED_CONE, OP_L_ELLIPSOID, OP_L_TETRAHEDRON, OP_L_DODECAHEDRON,
+                                OP_L_ICOSAHEDRON, OP_L_ROUNDED_RECTANGLE, OP_L_EQUILATERAL_TRIANGLE, OP_L_HEXAGON, OP_L_ROUNDED_X, OP_L_VESICA};
+        long decided = 0, boxes = 0;
+        for (uint32_t op : ops) {
+            for (int it = 0; it < 60000; it++) {
+                double c[12];
+                for (int k = 0; k < 12; k++) c[k] = pick(0.1, 1.2);
+                if (op == OP_L_CAPPED_CYLINDER) {      // a, ba, baba, -, radius, baba / 2 (d3.py:184-204)
+                    for (int k = 0; k < 6; k++) c[k] = pick(-1, 1);
+                    c[6] = (c[3] * c[3] + c[4] * c[4]) + c[5] * c[5]; c[8] = pick(0.05, 0.6) * c[6]; c[9] = c[6] * 0.5;
+                    if (!(c[6] > 1e-3)) continue;
+                }
+                if (op == OP_L_ROUNDED_CONE) { c[3] = pick(-0.9, 0.9); c[4] = std::sqrt(1 - c[3] * c[3]); c[5] = c[4] * c[2]; }
+                if (op == OP_L_HEXAGON) { c[1] = -0.866025404; c[2] = 0.5; c[4] = 2 * c[1]; c[5] = 2 * c[2]; c[6] = -0.577350269 * c[0]; c[7] = 0.577350269 * c[0]; }
+                if (op == OP_L_EQUILATERAL_TRIANGLE) { c[0] = 1.7320508; c[1] = pick(0.1, 1.0); }
+                if (op == OP_L_VESICA) { c[1] = pick(0.05, 0.9) * c[0]; c[2] = std::sqrt(c[0] * c[0] - c[1] * c[1]); }
+                const double sz = std::pow(10.0, pick(-3.5, 0.3));
+                const double cx = it % 4 ? pick(-2, 2) : 0.0, cy = it % 5 ? pick(-2, 2) : 0.0, cz = it % 6 ? pick(-2, 2) : 0.0;
+                Ival X{cx - sz * U(rng), cx + sz * U(rng)}, Y{cy - sz * U(rng), cy + sz * U(rng)}, Z{cz - sz * U(rng), cz + sz * U(rng)};
+                if (it % 9 == 0) X.hi = X.lo;
+                const Ival v = ia_leaf(op, c, X, Y, Z);
+                boxes++; if (v.lo > 0 || v.hi < 0) decided++;
+                for (int k = 0; k < 14; k++) {
+                    const double px = k & 1 ? (k < 8 ? X.lo : pick(X.lo, X.hi)) : (k < 8 ? X.hi : pick(X.lo, X.hi));
+                    const double py = k & 2 ? (k < 8 ? Y.lo : pick(Y.lo, Y.hi)) : (k < 8 ? Y.hi : pick(Y.lo, Y.hi));
+                    const double pz = k & 4 ? (k < 8 ? Z.lo : pick(Z.lo, Z.hi)) : (k < 8 ? Z.hi : pick(Z.lo, Z.hi));
+                    const double pv = leaf(op, c, px, py, pz);
+                    CHECK(pv != pv || in(v, pv), "leaf %u: box x[%.17g,%.17g] y[%.17g,%.17g] z[%.17g,%.17g] p(%.17g,%.17g,%.17g) v=%.17g not in [%.17g,%.17g]",
+                          op, X.lo, X.hi, Y.lo, Y.hi, Z.lo, Z.hi, px, py, pz, pv, v.lo, v.hi);
+                }
+            }
+        }
+        printf("leaf boxes %ld, sign decided for %ld\n", boxes, decided);
+    }
     // ---- interval product ----
     for (int it = 0; it < 100000; it++) {
         const Ival a{pick(-3, 3), 0}, b{pick(-3, 3), 0};

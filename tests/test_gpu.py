@@ -715,3 +715,50 @@ def test_results_land_in_recycled_pinned_memory(ns, eng):
     assert np.array_equal(view, want[:10])                        # a live view keeps its block
     assert len(rec) == 50 * m.n_triangles
     m.close()
+
+
+def _random_leaf_tree(rng, ns):
+    """booleans of the leaves whose interval forms are compositions of interval steps (sdf_interval.h ia_leaf)"""
+    r = lambda lo, hi: float(rng.uniform(lo, hi))
+    v3 = lambda s: tuple(float(t) for t in rng.uniform(-s, s, 3))
+
+    def leaf():
+        k = int(rng.integers(0, 12))
+        if k == 0: f = ns['wireframe_box']((r(0.5, 1.2), r(0.5, 1.2), r(0.5, 1.2)), r(0.03, 0.12))
+        elif k == 1: f = ns['capped_cylinder'](v3(0.6), v3(0.6), r(0.1, 0.4))
+        elif k == 2: f = ns['rounded_cone'](r(0.2, 0.5), r(0.05, 0.3), r(0.4, 1.0))
+        elif k == 3: f = ns['ellipsoid']((r(0.4, 1.2), r(0.3, 0.9), r(0.3, 1.0)))
+        elif k == 4: f = ns['tetrahedron'](r(0.4, 0.9))
+        elif k == 5: f = ns['dodecahedron'](r(0.4, 0.9))
+        elif k == 6: f = ns['icosahedron'](r(0.4, 0.9))
+        elif k == 7: f = ns['rounded_rectangle'](np.array((r(0.5, 1.4), r(0.4, 1.0))), (r(0.02, 0.2), r(0.02, 0.2), r(0.0, 0.2), r(0.02, 0.15))).extrude(r(0.2, 0.9))
+        elif k == 8: f = ns['equilateral_triangle']().scale(r(0.4, 0.8)).extrude(r(0.2, 0.9))
+        elif k == 9: f = ns['hexagon'](r(0.3, 0.8)).extrude(r(0.2, 0.9))
+        elif k == 10: f = ns['rounded_x'](r(0.5, 1.0), r(0.05, 0.2)).extrude(r(0.2, 0.8))
+        else: f = ns['vesica'](r(0.6, 1.0), r(0.1, 0.5)).revolve(r(0.0, 0.4)) if rng.random() < 0.5 else ns['vesica'](r(0.6, 1.0), r(0.1, 0.5)).extrude(r(0.2, 0.8))
+        t = int(rng.integers(0, 4))
+        if t == 0: f = f.translate(v3(0.5))
+        elif t == 1: f = f.rotate(r(0, 3.0), v3(1.0))
+        elif t == 2: f = f.orient(v3(1.0)).translate(v3(0.3))
+        return f
+
+    f = leaf()
+    for _ in range(int(rng.integers(1, 4))):
+        g = leaf()
+        c = int(rng.integers(0, 5))
+        f = (f | g) if c == 0 else ((f - g) if c == 1 else ((f & g) if c == 2 else (ns['union'](f, g, k=r(0.05, 0.25)) if c == 3 else ns['difference'](f, g, k=r(0.05, 0.2)))))
+    return f
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_interval_forms_of_composed_leaves_random(seed, ns, oracle_lib, eng):
+    rng = np.random.default_rng(9000 + seed)
+    f = _random_leaf_tree(rng, ns)
+    n = 95 + 6 * (seed % 3)
+    X = np.arange(-1.6, 1.6, 3.2 / n); Y = np.arange(-1.5, 1.5, 3.0 / n) + 0.002; Z = np.arange(-1.4, 1.4, 2.8 / n) - 0.001
+    (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, f, X, Y, Z, sparse=seed % 2 == 0)
+    assert s0['n_pruned_instrs'] == 0
+    assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
+    assert s1['n_sampled_voxels'] < s1['n_eval_voxels'] or s1['n_eval_voxels'] == 0   # (every op of these trees has an interval form)
+    o = oracle_lib.generate(f, X, Y, Z, 32, seed % 2 == 0)
+    assert np.array_equal(k1, o.kinds) and np.array_equal(p1, o.points)
