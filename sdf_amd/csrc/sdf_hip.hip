@@ -62,12 +62,11 @@ __global__ __launch_bounds__(256) void k_eval_grid(const uint32_t *__restrict__ 
 // reference sdf/core.py:28-43.  16 lanes per batch: lane 0 = centre, lanes 1..8 = corners in
 // itertools.product((x0,x1),(y0,y1),(z0,z1)) order.  kinds[b] = 0 (skipped) or 255 (pending).
 // Workgroups >= pa.first_block run the interval pass of the same batches instead (sdf_prune.h).
-template <typename T, bool FULL>
-__global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
-                                              int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa) {
-    extern __shared__ double prune_lds[];
+template <typename T, bool FULL, bool RARE>
+__device__ __forceinline__ void skip_body(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
+                                              int nbatches, unsigned char *__restrict__ kinds, const PruneArgs &pa, double *prune_lds) {
     if ((int)blockIdx.x >= pa.first_block) {   // (uniform)
-        prune_block<FULL>(code, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
+        prune_block<FULL, RARE>(code, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
         return;
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,6 +96,21 @@ __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code,
         const bool skip = !(r <= d) && all_same;
         kinds[b] = skip ? 0 : 255;
     }
+}
+
+// (two entry points: tapes with one of the less common leaves of ia_leaf_rare get the interval pass that knows
+// them, the others keep the leaner one -- a kernel's registers and scratch are those of its hungriest callee)
+template <typename T, bool FULL>
+__global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
+                                              int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa) {
+    extern __shared__ double prune_lds[];
+    skip_body<T, FULL, false>(code, consts, g, nbatches, kinds, pa, prune_lds);
+}
+template <typename T, bool FULL>
+__global__ __launch_bounds__(256) void k_skip_rare(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
+                                                   int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa) {
+    extern __shared__ double prune_lds[];
+    skip_body<T, FULL, true>(code, consts, g, nbatches, kinds, pa, prune_lds);
 }
 
 // One workgroup per work item of this shard: which sampling tasks of the batch have to be evaluated
@@ -851,10 +865,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     }
     if (skip_blocks + prune_blocks) {
         if (prune_lds > 32768) {   // (more dynamic LDS than the default limit: tapes with many saved-point slots)
-            const void *fn = t->full ? reinterpret_cast<const void *>(k_skip<double, true>) : reinterpret_cast<const void *>(k_skip<double, false>);
+            const void *fn = t->ia_rare ? (t->full ? reinterpret_cast<const void *>(k_skip_rare<double, true>) : reinterpret_cast<const void *>(k_skip_rare<double, false>))
+                                        : (t->full ? reinterpret_cast<const void *>(k_skip<double, true>) : reinterpret_cast<const void *>(k_skip<double, false>));
             HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
         }
-        LAUNCH_TAPE(k_skip, dim3(skip_blocks + prune_blocks), dim3(256), prune_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
+        if (t->ia_rare) LAUNCH_TAPE(k_skip_rare, dim3(skip_blocks + prune_blocks), dim3(256), prune_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
+        else LAUNCH_TAPE(k_skip, dim3(skip_blocks + prune_blocks), dim3(256), prune_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
     }
     if (!sparse) HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,

@@ -22,7 +22,7 @@ struct PruneArgs {
 // (lane = octant of the batch's box of sample coordinates), PRUNE_BLOCK / 8 batches per workgroup.
 // It runs for EVERY batch, next to the skip test rather than after it: the work list is not known
 // yet, and a launch of its own behind k_compact would sit on the critical path.
-template <bool FULL>
+template <bool FULL, bool RARE>
 __device__ __forceinline__ void prune_block(const uint32_t *__restrict__ code, const PruneArgs &pa, const GridDesc &g,
                                             int nbatches, int block, double *lds) {
     const int gid = block * PRUNE_BLOCK + threadIdx.x;
@@ -43,7 +43,7 @@ __device__ __forceinline__ void prune_block(const uint32_t *__restrict__ code, c
     }
     uint32_t masks[16];
     for (int k = 0; k < 16; k++) masks[k] = 0;
-    ia_run_tape<true, FULL, true>(code, pa.consts, pa.rstart, pa.lstart, pa.n_instr, bx, by, bz, live, IaShared{lds, pa.n_p, PRUNE_BLOCK}, pa.n_d, masks);
+    ia_run_tape<true, FULL, RARE>(code, pa.consts, pa.rstart, pa.lstart, pa.n_instr, bx, by, bz, live, IaShared{lds, pa.n_p, PRUNE_BLOCK}, pa.n_d, masks);
     const bool store = live && oct == 0;
     unsigned long long *out = pa.tapes_out + (size_t)(live ? b : 0) * pa.tape_stride;
     const int n = compact_tape(reinterpret_cast<const unsigned long long *>(code), pa.n_instr, masks, out, store, pa.zero_off);
