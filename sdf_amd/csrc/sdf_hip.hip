@@ -117,11 +117,10 @@ __global__ __launch_bounds__(256) void k_skip_rare(const uint32_t *__restrict__ 
 // (cull_tasks, sdf_device.h).  The record goes to global memory; k_mesh picks it up.
 #define CULL_BLOCK 256
 template <bool FULL, bool RARE>
-__global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
+__device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
+                                                     unsigned char *__restrict__ out, unsigned char *cull_smem) {
     int *wave_sums = reinterpret_cast<int *>(cull_smem);                       // 64 B
     double *axes = reinterpret_cast<double *>(cull_smem + 64);                 // 3 * 33 doubles
     unsigned char *scratch = cull_smem + 896;                                  // CULL_SCRATCH bytes
@@ -145,6 +144,24 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict_
     __syncthreads();
     for (int i = tid; i < CULL_RECORD / 4; i += CULL_BLOCK)
         reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD)[i] = reinterpret_cast<const unsigned *>(scratch)[i];
+}
+
+template <bool FULL, bool RARE>
+__global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
+                                                     const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
+                                                     int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
+                                                     unsigned char *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
+    cull_body<FULL, RARE>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem);
+}
+// the variant for tapes without trigonometry and without the rarer leaves fits 80 VGPRs without spilling:
+// six waves per SIMD instead of five (the others would spill 64-160 bytes per lane at that budget)
+__global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
+                                                     const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
+                                                     int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
+                                                     unsigned char *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
+    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem);
 }
 
 // ordered compaction of the pending batches into the work list (single workgroup)
@@ -884,7 +901,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const int ia_np = (int)std::max(t->n_p, 1u), ia_nd = (int)std::max(t->n_d, 1u);
         const size_t ia_bytes = std::min<size_t>((size_t)CULL_BLOCK * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
-        auto kc = t->full ? (t->ia_rare ? k_cull<true, true> : k_cull<true, false>) : (t->ia_rare ? k_cull<false, true> : k_cull<false, false>);
+        auto kc = t->full ? (t->ia_rare ? k_cull<true, true> : k_cull<true, false>) : (t->ia_rare ? k_cull<false, true> : k_cull_lean);
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kc, dim3(nb), dim3(CULL_BLOCK), lds, c->stream,
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
