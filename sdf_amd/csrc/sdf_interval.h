@@ -272,7 +272,7 @@ __host__ __device__ inline bool ia_has_form(uint32_t op) {
     case OP_L_ROUNDED_CYLINDER: case OP_L_CAPSULE: case OP_L_OCTAHEDRON: case OP_L_CIRCLE: case OP_L_LINE: case OP_L_RECTANGLE:
     case OP_L_WIREFRAME_BOX: case OP_L_CAPPED_CYLINDER: case OP_L_ROUNDED_CONE: case OP_L_ELLIPSOID: case OP_L_TETRAHEDRON:
     case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: case OP_L_ROUNDED_RECTANGLE: case OP_L_EQUILATERAL_TRIANGLE: case OP_L_HEXAGON:
-    case OP_L_ROUNDED_X: case OP_L_VESICA:
+    case OP_L_ROUNDED_X: case OP_L_VESICA: case OP_L_CAPPED_CONE: case OP_L_PYRAMID: case OP_L_POLYGON:
     case OP_COMB: case OP_TRANSLATE: case OP_SCALE: case OP_ROTATE: case OP_ELONGATE: case OP_TRANSLATE2: case OP_SCALE2:
     case OP_ROTATE2: case OP_ELONGATE2: case OP_REVOLVE: case OP_SETZ0: case OP_SAVE_P: case OP_LOAD_P: case OP_PUSH_D: case OP_NOP:
     case OP_NEG: case OP_ADDC: case OP_SUBC: case OP_MULC: case OP_SHELL: case OP_ADD_DS: case OP_EXT_PRE: case OP_EXT_POST:
@@ -331,7 +331,7 @@ SDF_IA bool ia_is_rare_leaf(uint32_t op) {
     switch (op) {
     case OP_L_WIREFRAME_BOX: case OP_L_CAPPED_CYLINDER: case OP_L_ROUNDED_CONE: case OP_L_ELLIPSOID: case OP_L_TETRAHEDRON:
     case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: case OP_L_ROUNDED_RECTANGLE: case OP_L_EQUILATERAL_TRIANGLE: case OP_L_HEXAGON:
-    case OP_L_ROUNDED_X: case OP_L_VESICA:
+    case OP_L_ROUNDED_X: case OP_L_VESICA: case OP_L_CAPPED_CONE: case OP_L_PYRAMID: case OP_L_POLYGON:
         return true;
     default: return false;
     }
@@ -444,6 +444,77 @@ __host__ __device__ __attribute__((noinline)) inline Ival ia_leaf_rare(uint32_t 
         const Ival px = abs_(x), py = abs_(y);
         const Ival v1 = len2(px, subc(py, b)), v2 = subc(len2(subc(px, -d), py), r);
         return sel_gt(mulc(subc(py, b), d), mulc(px, b), v1, v2);
+    }
+    case OP_L_CAPPED_CONE: {   // d3.py:217-237
+        const double bax = c[3], bay = c[4], baz = c[5], ra = c[6], rb = c[7], baba = c[8], rba = c[9], k = c[10];
+        if (!(baba > 0.0)) return top();
+        const Ival pax = subc(x, c[0]), pay = subc(y, c[1]), paz = subc(z, c[2]);
+        const Ival papa = add(add(sqr(pax), sqr(pay)), sqr(paz));
+        const Ival paba = divc(dot3c(pax, pay, paz, bax, bay, baz), baba);
+        // xx = sqrt(papa - paba * paba * baba) cancels: its argument is the squared distance from the axis,
+        // |pa x ba|^2 / baba, which the cross product bounds without cancellation; the interpreter's value differs
+        // from that real number by at most a few roundings of papa.  Too close to the axis to keep the computed
+        // argument positive: no statement.
+        const Ival crx = sub(mulc(pay, baz), mulc(paz, bay)), cry = sub(mulc(paz, bax), mulc(pax, baz)), crz = sub(mulc(pax, bay), mulc(pay, bax));
+        const Ival A = divc(add(add(sqr(crx), sqr(cry)), sqr(crz)), baba);
+        if (bad(A) || bad(papa) || !finite_(papa) || !finite_(A)) return top();
+        const double delta = 1e-13 * papa.hi;
+        if (!(A.lo - delta > 0.0)) return top();
+        const Ival xx{sqrt(A.lo - delta), sqrt(A.hi + delta)};
+        const Ival half = pt(0.5), zero = pt(0.0);
+        const Ival cax = maxc(sub(xx, sel_gt(half, paba, pt(ra), pt(rb))), 0.0);          // paba < 0.5 ? ra : rb
+        const Ival cay = subc(abs_(subc(paba, 0.5)), 0.5);
+        const Ival f = clip01(divc(add(mulc(subc(xx, ra), rba), mulc(paba, baba)), k));
+        const Ival cbx = sub(subc(xx, ra), mulc(f, rba)), cby = sub(paba, f);
+        const Ival m = min_(add(sqr(cax), mulc(sqr(cay), baba)), add(sqr(cbx), mulc(sqr(cby), baba)));
+        const Ival r = sqrt_(m);
+        if (bad(cbx) || bad(cay) || bad(r)) return top();
+        if (cbx.hi < 0.0 && cay.hi < 0.0) return neg(r);
+        if (cbx.lo >= 0.0 || cay.lo >= 0.0) return r;
+        return Ival{-r.hi, r.hi};
+    }
+    case OP_L_PYRAMID: {       // d3.py:261-282
+        const double h = c[0], m2 = c[1], m2q = c[2];
+        if (!(m2 > 0.0)) return top();
+        const Ival b0 = subc(abs_(x), 0.5), b1 = subc(abs_(y), 0.5);
+        const Ival px = max_(b0, b1), py = z, pz = min_(b0, b1);                            // (the swap picks the larger one)
+        const Ival qx = pz, qy = sub(mulc(py, h), mulc(px, 0.5)), qz = add(mulc(px, h), mulc(py, 0.5));
+        const Ival sv = maxc(neg(qx), 0.0);
+        const Ival tt = clip01(divc(sub(qy, mulc(pz, 0.5)), m2q));
+        const Ival a = add(mulc(sqr(add(qx, sv)), m2), sqr(qy));
+        const Ival b = add(mulc(sqr(add(qx, mulc(tt, 0.5))), m2), sqr(sub(qy, mulc(tt, m2))));
+        const Ival zero = pt(0.0);
+        const Ival dd2 = sel_gt(min_(qy, sub(mulc(neg(qx), m2), mulc(qy, 0.5))), zero, zero, min_(a, b));
+        return mul(sqrt_(divc(add(dd2, sqr(qz)), m2)), sign_(max_(qz, neg(py))));
+    }
+    case OP_L_POLYGON: {       // d2.py:175-196
+        const int np_ = (int)c[0];
+        const double *pv = c + 1;
+        if (np_ < 1 || bad(x) || bad(y) || !finite_(x) || !finite_(y)) return top();
+        Ival d = add(sqr(subc(x, pv[0])), sqr(subc(y, pv[1])));
+        double sgn = 1.0;                                    // the interpreter's winding sign at the corner (x.lo, y.lo)
+        double scale2 = x.hi * x.hi + y.hi * y.hi + x.lo * x.lo + y.lo * y.lo;
+        for (int i = 0; i < np_; i++) {
+            const int j = (i + np_ - 1) % np_;
+            const double vix = pv[2 * i], viy = pv[2 * i + 1], vjx = pv[2 * j], vjy = pv[2 * j + 1];
+            const double ex = vjx - vix, ey = vjy - viy;
+            const Ival wx = subc(x, vix), wy = subc(y, viy);
+            const double ee = fma(ey, ey, ex * ex);
+            const Ival cl = clip01(divc(dot2c(wx, wy, ex, ey), ee));
+            const Ival bx = sub(wx, mulc(cl, ex)), by = sub(wy, mulc(cl, ey));
+            d = min_(d, add(sqr(bx), sqr(by)));
+            const double pwx = x.lo - vix, pwy = y.lo - viy;
+            const bool c1 = y.lo >= viy, c2 = y.lo < vjy, c3 = ex * pwy > ey * pwx;
+            if ((c1 && c2 && c3) || (!c1 && !c2 && !c3)) sgn = -sgn;
+            scale2 += vix * vix + viy * viy;
+        }
+        const Ival r = sqrt_(d);
+        if (bad(d) || bad(r) || !(scale2 == scale2)) return top();
+        // The winding sign only changes across the polygon's boundary (the y-range tests of neighbouring edges are
+        // exact complements; the side test of an edge only counts inside its y-range, i.e. at the edge itself): a box
+        // that stays clear of the boundary by more than the rounding of those tests has one sign, the corner's.
+        if (d.lo > 1e-24 * (1.0 + scale2)) return sgn > 0.0 ? r : neg(r);
+        return Ival{-r.hi, r.hi};
     }
     default: return top();
     }

@@ -204,20 +204,74 @@ int main() {
                 const double r = c[0], d = c[1], b = c[2];
                 const double px = fabs(x), py = fabs(y);
                 return (py - b) * d > px * b ? l2(px - 0.0, py - b) : l2(px - (-d), py - 0.0) - r; }
+            case OP_L_CAPPED_CONE: {
+                const double ra = c[6], rb = c[7], baba = c[8], rba = c[9], k = c[10];
+                const double pax = x - c[0], pay = y - c[1], paz = z - c[2];
+                const double papa = (pax * pax + pay * pay) + paz * paz;
+                const double paba = d3(pax, pay, paz, c[3], c[4], c[5]) / baba;
+                const double xx = std::sqrt(papa - paba * paba * baba);
+                const double cax = smax(0.0, xx - (paba < 0.5 ? ra : rb));
+                const double cay = fabs(paba - 0.5) - 0.5;
+                const double f = sclip((rba * (xx - ra) + paba * baba) / k, 0.0, 1.0);
+                const double cbx = xx - ra - f * rba, cby = paba - f;
+                const double sg = (cbx < 0 && cay < 0) ? -1.0 : 1.0;
+                return sg * std::sqrt(smin(cax * cax + cay * cay * baba, cbx * cbx + cby * cby * baba)); }
+            case OP_L_PYRAMID: {
+                const double h = c[0], m2 = c[1], m2q = c[2];
+                const double b0 = fabs(x) - 0.5, b1 = fabs(y) - 0.5;
+                const bool sw = b1 > b0;
+                const double a0 = sw ? b1 : b0, a1 = sw ? b0 : b1;
+                const double px = a0, py = z, pz = a1;
+                const double qx = pz, qy = h * py - 0.5 * px, qz = h * px + 0.5 * py;
+                const double sv = smax(-qx, 0.0);
+                const double tt = sclip((qy - 0.5 * pz) / m2q, 0.0, 1.0);
+                const double a = m2 * ((qx + sv) * (qx + sv)) + qy * qy;
+                const double b = m2 * ((qx + 0.5 * tt) * (qx + 0.5 * tt)) + (qy - m2 * tt) * (qy - m2 * tt);
+                const double dd2 = smin(qy, -qx * m2 - qy * 0.5) > 0 ? 0.0 : smin(a, b);
+                return std::sqrt((dd2 + qz * qz) / m2) * ssign(smax(qz, -py)); }
+            case OP_L_POLYGON: {
+                const int np_ = (int)c[0];
+                const double *pv = c + 1;
+                const double dx = x - pv[0], dy = y - pv[1];
+                double d = dx * dx + dy * dy, sg = 1.0;
+                for (int i = 0; i < np_; i++) {
+                    const int j = (i + np_ - 1) % np_;
+                    const double vix = pv[2 * i], viy = pv[2 * i + 1], vjx = pv[2 * j], vjy = pv[2 * j + 1];
+                    const double ex = vjx - vix, ey = vjy - viy, wx = x - vix, wy = y - viy;
+                    const double ee = std::fma(ey, ey, ex * ex);
+                    const double cl = sclip(d2(wx, wy, ex, ey) / ee, 0.0, 1.0);
+                    const double bx = wx - ex * cl, by = wy - ey * cl;
+                    d = smin(d, bx * bx + by * by);
+                    const bool c1 = y >= viy, c2 = y < vjy, c3 = ex * wy > ey * wx;
+                    if ((c1 && c2 && c3) || (!c1 && !c2 && !c3)) sg = -sg;
+                }
+                return sg * std::sqrt(d); }
             default: return 0.0;
             }
         };
-        const uint32_t ops[] = {OP_L_WIREFRAME_BOX, OP_L_CAPPED_CYLINDER, OP_L_ROUNDED_CONE, OP_L_ELLIPSOID, OP_L_TETRAHEDRON, OP_L_DODECAHEDRON,
+        const uint32_t ops[] = {OP_L_CAPPED_CONE, OP_L_PYRAMID, OP_L_POLYGON,OP_L_WIREFRAME_BOX, OP_L_CAPPED_CYLINDER, OP_L_ROUNDED_CONE, OP_L_ELLIPSOID, OP_L_TETRAHEDRON, OP_L_DODECAHEDRON,
                                 OP_L_ICOSAHEDRON, OP_L_ROUNDED_RECTANGLE, OP_L_EQUILATERAL_TRIANGLE, OP_L_HEXAGON, OP_L_ROUNDED_X, OP_L_VESICA};
         long decided = 0, boxes = 0;
         for (uint32_t op : ops) {
             for (int it = 0; it < 60000; it++) {
-                double c[12];
-                for (int k = 0; k < 12; k++) c[k] = pick(0.1, 1.2);
+                double c[16];
+                for (int k = 0; k < 16; k++) c[k] = pick(0.1, 1.2);
                 if (op == OP_L_CAPPED_CYLINDER) {      // a, ba, baba, -, radius, baba / 2 (d3.py:184-204)
                     for (int k = 0; k < 6; k++) c[k] = pick(-1, 1);
                     c[6] = (c[3] * c[3] + c[4] * c[4]) + c[5] * c[5]; c[8] = pick(0.05, 0.6) * c[6]; c[9] = c[6] * 0.5;
                     if (!(c[6] > 1e-3)) continue;
+                }
+                if (op == OP_L_CAPPED_CONE) {            // a, ba, ra, rb, baba, rba, k (d3.py:217-237)
+                    for (int k = 0; k < 6; k++) c[k] = pick(-1, 1);
+                    c[6] = pick(0.1, 0.8); c[7] = pick(0.0, 0.6);
+                    c[8] = (c[3] * c[3] + c[4] * c[4]) + c[5] * c[5]; c[9] = c[7] - c[6]; c[10] = c[9] * c[9] + c[8];
+                    if (!(c[8] > 1e-3)) continue;
+                }
+                if (op == OP_L_PYRAMID) { c[0] = pick(0.3, 2.0); c[1] = c[0] * c[0] + 0.25; c[2] = c[1] + 0.25; }
+                if (op == OP_L_POLYGON) {                // a star-ish polygon of 3..7 vertices
+                    const int n = 3 + (int)(rng() % 5);
+                    c[0] = n;
+                    for (int k = 0; k < n; k++) { const double a = 2 * M_PI * k / n + pick(-0.2, 0.2), rr = pick(0.4, 1.5); c[1 + 2 * k] = rr * cos(a); c[2 + 2 * k] = rr * sin(a); }
                 }
                 if (op == OP_L_ROUNDED_CONE) { c[3] = pick(-0.9, 0.9); c[4] = std::sqrt(1 - c[3] * c[3]); c[5] = c[4] * c[2]; }
                 if (op == OP_L_HEXAGON) { c[1] = -0.866025404; c[2] = 0.5; c[4] = 2 * c[1]; c[5] = 2 * c[2]; c[6] = -0.577350269 * c[0]; c[7] = 0.577350269 * c[0]; }
@@ -227,7 +281,7 @@ int main() {
                 const double cx = it % 4 ? pick(-2, 2) : 0.0, cy = it % 5 ? pick(-2, 2) : 0.0, cz = it % 6 ? pick(-2, 2) : 0.0;
                 Ival X{cx - sz * U(rng), cx + sz * U(rng)}, Y{cy - sz * U(rng), cy + sz * U(rng)}, Z{cz - sz * U(rng), cz + sz * U(rng)};
                 if (it % 9 == 0) X.hi = X.lo;
-                const Ival v = ia_leaf(op, c, X, Y, Z);
+                const Ival v = ia_is_rare_leaf(op) ? ia_leaf_rare(op, c, X, Y, Z) : ia_leaf(op, c, X, Y, Z);
                 boxes++; if (v.lo > 0 || v.hi < 0) decided++;
                 for (int k = 0; k < 14; k++) {
                     const double px = k & 1 ? (k < 8 ? X.lo : pick(X.lo, X.hi)) : (k < 8 ? X.hi : pick(X.lo, X.hi));
@@ -240,6 +294,7 @@ int main() {
             }
         }
         printf("leaf boxes %ld, sign decided for %ld\n", boxes, decided);
+        CHECK(decided * 2 > boxes, "the leaf intervals decide fewer than half of the boxes: are the forms reached?");
     }
     // ---- interval product ----
     for (int it = 0; it < 100000; it++) {

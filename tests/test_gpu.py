@@ -723,8 +723,13 @@ def _random_leaf_tree(rng, ns):
     v3 = lambda s: tuple(float(t) for t in rng.uniform(-s, s, 3))
 
     def leaf():
-        k = int(rng.integers(0, 12))
-        if k == 0: f = ns['wireframe_box']((r(0.5, 1.2), r(0.5, 1.2), r(0.5, 1.2)), r(0.03, 0.12))
+        k = int(rng.integers(0, 15))
+        if k == 12: f = ns['capped_cone'](v3(0.6), v3(0.6), r(0.15, 0.5), r(0.0, 0.4))
+        elif k == 13: f = ns['pyramid'](r(0.5, 1.4)).scale(r(0.6, 1.0))
+        elif k == 14:
+            n = int(rng.integers(3, 8)); a0 = rng.uniform(0, 6.28)
+            f = ns['polygon']([(float(rr * np.cos(a0 + 6.283 * i / n)), float(rr * np.sin(a0 + 6.283 * i / n))) for i, rr in enumerate(rng.uniform(0.4, 1.2, n))]).extrude(r(0.2, 0.9))
+        elif k == 0: f = ns['wireframe_box']((r(0.5, 1.2), r(0.5, 1.2), r(0.5, 1.2)), r(0.03, 0.12))
         elif k == 1: f = ns['capped_cylinder'](v3(0.6), v3(0.6), r(0.1, 0.4))
         elif k == 2: f = ns['rounded_cone'](r(0.2, 0.5), r(0.05, 0.3), r(0.4, 1.0))
         elif k == 3: f = ns['ellipsoid']((r(0.4, 1.2), r(0.3, 0.9), r(0.3, 1.0)))
@@ -750,7 +755,7 @@ def _random_leaf_tree(rng, ns):
     return f
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(24))
 def test_interval_forms_of_composed_leaves_random(seed, ns, oracle_lib, eng):
     rng = np.random.default_rng(9000 + seed)
     f = _random_leaf_tree(rng, ns)
