@@ -201,6 +201,17 @@ SDF_IA void circ_prep(const Ival &x, const Ival &y, double da, Ival &d, Ival &a)
     if (!(lo > 1e-9) || !(da - hi > 1e-9)) return;          // (too close to a boundary to trust kl)
     a = Ival{lo - 1e-12, hi + 1e-12};
 }
+// range of atan2(y, x) over a box: [-pi, pi] when the box touches the origin or the negative x axis, else the
+// corners' (see circ_prep), widened
+SDF_IA Ival atan2_range(const Ival &x, const Ival &y) {
+    const double pi = 3.141592653589793;
+    if (!finite_(x) || !finite_(y)) return top();
+    if (x.lo <= 0.0 && y.lo <= 0.0 && y.hi >= 0.0) return Ival{-pi, pi};
+    const double t0 = ia_atan2(y.lo, x.lo), t1 = ia_atan2(y.lo, x.hi), t2 = ia_atan2(y.hi, x.lo), t3 = ia_atan2(y.hi, x.hi);
+    const double tl = fmin(fmin(t0, t1), fmin(t2, t3)) - 1e-12, th = fmax(fmax(t0, t1), fmax(t2, t3)) + 1e-12;
+    if (!(tl <= th)) return Ival{-pi, pi};
+    return Ival{fmax(tl, -pi), fmin(th, pi)};
+}
 // second half (L_CIRC_SET): p = (cos(a - delta) * d, sin(a - delta) * d, z)
 SDF_IA void circ_set(const Ival &d, const Ival &a, double delta, Ival &x, Ival &y) {
     x = y = top();
@@ -278,7 +289,7 @@ __host__ __device__ inline bool ia_has_form(uint32_t op) {
     case OP_NEG: case OP_ADDC: case OP_SUBC: case OP_MULC: case OP_SHELL: case OP_ADD_DS: case OP_EXT_PRE: case OP_EXT_POST:
     case OP_REP_PREP: case OP_REP_SET: case OP_CIRC_PREP: case OP_CIRC_SET: case OP_BEND_LINEAR:
     case OP_TWIST: case OP_BEND: case OP_BEND_RADIAL: case OP_TRANS_LIN_PRE: case OP_TRANS_RAD_PRE: case OP_TRANS_MIX:
-    case OP_EXTTO_PRE: case OP_EXTTO_MIX: case OP_SLICE_POST:
+    case OP_EXTTO_PRE: case OP_EXTTO_MIX: case OP_SLICE_POST: case OP_WRAP_AROUND:
         return true;
     default: return false;
     }
@@ -730,8 +741,18 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
             else if (A.lo > 0.0) acc = A;
             else acc = Ival{fmin(A.lo, B.lo), fmax(A.hi, B.hi)};
             break; }
-        case OP_TWIST: case OP_BEND: case OP_BEND_RADIAL: case OP_TRANS_RAD_PRE:   // trig-capable builds only
+        case OP_TWIST: case OP_BEND: case OP_BEND_RADIAL: case OP_TRANS_RAD_PRE: case OP_WRAP_AROUND:   // trig-capable builds only
             if constexpr (FULL) {
+                if (op == OP_WRAP_AROUND) {                 // L_WRAP_AROUND (d3.py:483-502)
+                    const double pi = 3.141592653589793;
+                    Ival r = finite_(x) && finite_(y) ? pad(len2(x, y), 1e-12, 1e-300) : top();
+                    if (!bad(r)) r.lo = fmax(r.lo, 0.0);
+                    const Ival d = subc(r, c[9]);
+                    const Ival u = divc(addc(atan2_range(x, y), pi), 2.0 * pi);
+                    const Ival tt = bad(u) ? top() : ease01((int)c[10], Ival{fmax(u.lo, 0.0), fmin(u.hi, 1.0)});
+                    const Ival nx = add(addc(mulc(tt, c[3]), c[0]), mulc(d, c[6])), ny = add(addc(mulc(tt, c[4]), c[1]), mulc(d, c[7]));
+                    x = nx; y = ny;
+                } else
                 if (op == OP_TWIST || op == OP_BEND) {      // L_TWIST / L_BEND (d3.py:407-433): rotation by c0 * z resp. c0 * x
                     Ival sn, cs;
                     sincos_range(mulc(op == OP_TWIST ? z : x, c[0]), sn, cs);

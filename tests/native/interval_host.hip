@@ -64,6 +64,22 @@ int main() {
             CHECK(in(X1, q1x) && in(Y1, q1y), "set(0): p(%g,%g) -> (%.17g,%.17g) not in x[%.17g,%.17g] y[%.17g,%.17g]", px, py, q1x, q1y, X1.lo, X1.hi, Y1.lo, Y1.hi);
         }
     }
+    // ---- atan2 over a box (wrap_around) ----
+    for (int it = 0; it < 200000; it++) {
+        const double sz = std::pow(10.0, pick(-4, 0.5));
+        double cx = pick(-3, 3), cy = it % 3 ? pick(-3, 3) : 0.0;
+        if (it % 7 == 0) cx = 0;
+        Ival x{cx - sz * U(rng), cx + sz * U(rng)}, y{cy - sz * U(rng), cy + sz * U(rng)};
+        if (it % 5 == 0) { y.lo = 0.0; y.hi = fabs(y.hi); }
+        if (it % 11 == 0) { y.hi = -0.0; y.lo = -fabs(y.lo); }
+        const Ival a = ia::atan2_range(x, y);
+        for (int s2 = 0; s2 < 12; s2++) {
+            double px = s2 & 1 ? x.lo : x.hi, py = s2 & 2 ? y.lo : y.hi;
+            if (s2 >= 4) { px = pick(x.lo, x.hi); py = pick(y.lo, y.hi); }
+            if (s2 >= 8 && 0.0 >= y.lo && 0.0 <= y.hi) py = s2 & 1 ? 0.0 : -0.0;
+            CHECK(in(a, std::atan2(py, px)), "atan2: box x[%.17g,%.17g] y[%.17g,%.17g] p(%.17g,%.17g) a=%.17g not in [%.17g,%.17g]", x.lo, x.hi, y.lo, y.hi, px, py, std::atan2(py, px), a.lo, a.hi);
+        }
+    }
     // ---- sin / cos ranges over arbitrary angle intervals ----
     for (int it = 0; it < 200000; it++) {
         const double l = pick(-7, 7), w = std::pow(10.0, pick(-6, 1));

@@ -566,11 +566,12 @@ def _random_array_tree(rng, ns):
         elif k == 1: f = ns['rounded_box']((r(0.2, 0.8), r(0.1, 0.4), r(0.1, 0.4)), r(0.01, 0.05))
         elif k == 2: f = ns['capsule']((-r(0.1, 0.4), 0, 0), (r(0.1, 0.4), 0, r(-0.2, 0.2)), r(0.05, 0.15))
         else: f = ns['cylinder'](r(0.05, 0.2)) & ns['slab'](z0=-r(0.1, 0.5), z1=r(0.1, 0.5))
-        w = int(rng.integers(0, 10))
+        w = int(rng.integers(0, 11))
         eases = (ns['ease'].linear, ns['ease'].in_out_quad, ns['ease'].out_cubic, ns['ease'].in_out_circ,
                  ns['ease'].in_out_square, ns['ease'].out_bounce, ns['ease'].in_sine)
         e2 = eases[int(rng.integers(0, len(eases)))]
-        if w == 5: f = f.twist(r(-3.0, 3.0))
+        if w == 10: f = f.wrap_around(-r(0.5, 1.2), r(0.5, 1.2), e=e2)
+        elif w == 5: f = f.twist(r(-3.0, 3.0))
         elif w == 6: f = f.bend(r(-2.0, 2.0))
         elif w == 7: f = f.bend_radial(r(0.1, 0.4), r(0.5, 1.0), r(-0.4, 0.4), e2)
         elif w == 8: f = f.transition_linear(ns['sphere'](r(0.2, 0.5)), (0, 0, -r(0.1, 0.5)), (0, 0, r(0.1, 0.5)), e2)
