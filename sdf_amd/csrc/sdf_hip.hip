@@ -113,6 +113,17 @@ __global__ __launch_bounds__(256) void k_skip_rare(const uint32_t *__restrict__ 
     skip_body<T, FULL, true>(code, consts, g, nbatches, kinds, pa, prune_lds);
 }
 
+// The interval pass of sdf_prune.h as a kernel of its own, over this shard's work list: for grids with many
+// batches, most of which the skip test removes (weave at 2^33: 266 k batches, 38 k survive), pruning only the
+// survivors is worth the extra launch behind k_compact; small grids keep it fused into k_skip's launch, where
+// it costs nothing on the critical path.
+template <bool FULL, bool RARE>
+__global__ __launch_bounds__(PRUNE_BLOCK) void k_prune_list(const uint32_t *__restrict__ code, GridDesc g, int nbatches, PruneArgs pa) {
+    extern __shared__ double prune_list_lds[];
+    if ((long long)blockIdx.x * (PRUNE_BLOCK / 8) >= (long long)(pa.ctr->work_end - pa.ctr->work_begin)) return;   // (uniform)
+    prune_block<FULL, RARE>(code, pa, g, nbatches, (int)blockIdx.x, prune_list_lds);
+}
+
 // One workgroup per work item of this shard: which sampling tasks of the batch have to be evaluated
 // (cull_tasks, sdf_device.h).  The record goes to global memory; k_mesh picks it up.
 #define CULL_BLOCK 256
@@ -397,6 +408,7 @@ struct sdf_ctx {
     int prune = 1;                    // SDF_PRUNE=0 switches the interval prepass off (diagnostics)
     int parking = 1;                  // SDF_PARK=0: k_mesh waits for its predecessors instead of parking a batch (diagnostics)
     int cull = 1;                     // SDF_CULL=0: k_mesh samples every voxel of a batch instead of deciding cell groups by intervals
+    int prune_list_min = 8192;        // SDF_PRUNE_LIST_MIN: from this many batches on the interval prepass runs behind k_compact, over the work list
     int park_spins = 1;               // SDF_PARK_SPINS: polls before parking (tuning; measured: waiting never pays)
     DevBuf park;                      // k_mesh's staging slots, one per CU (allocated by the first sdf_generate)
     int mesh_slots = -1;              // SDF_MESH_SLOTS override of the register-file variant (tuning)
@@ -538,6 +550,7 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
     if (const char *e = getenv("SDF_PRUNE")) c->prune = atoi(e);
     if (const char *e = getenv("SDF_PARK")) c->parking = atoi(e);
+    if (const char *e = getenv("SDF_PRUNE_LIST_MIN")) c->prune_list_min = std::max(atoi(e), 0);
     if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
     if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(128)) return 1; }
@@ -868,6 +881,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     const int tape_stride = (int)((n_instr + 2 + 7) & ~7u);
     PruneArgs pa = {};
     pa.first_block = 0x7fffffff;
+    // many batches: the interval pass runs behind k_compact, for the surviving batches only (k_prune_list)
+    const bool prune_listed = pruning && sparse && nb >= c->prune_list_min;
     unsigned skip_blocks = sparse ? (unsigned)(((long long)nb * 16 + 255) / 256) : 0u, prune_blocks = 0;
     size_t prune_lds = 0;
     if (pruning) {
@@ -875,25 +890,36 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         pa.consts = (const double *)t->d_c64; pa.rstart = t->d_rstart; pa.lstart = t->d_lstart;
         pa.n_instr = (int)n_instr; pa.n_p = std::max(t->n_p, 1u); pa.n_d = std::max(t->n_d, 1u);
         pa.masks_out = (uint32_t *)m->prune.p; pa.tapes_out = (unsigned long long *)m->tapes.p; pa.tape_stride = tape_stride;
-        pa.first_block = (int)skip_blocks;
         pa.zero_off = t->n_consts;
-        prune_blocks = (unsigned)(((long long)nb * 8 + PRUNE_BLOCK - 1) / PRUNE_BLOCK);
         prune_lds = prune_lds_bytes(pa.n_p, pa.n_d);
+        if (!prune_listed) {         // fused into k_skip's launch: every batch
+            pa.first_block = (int)skip_blocks;
+            prune_blocks = (unsigned)(((long long)nb * 8 + PRUNE_BLOCK - 1) / PRUNE_BLOCK);
+        }
     }
     if (skip_blocks + prune_blocks) {
-        if (prune_lds > 32768) {   // (more dynamic LDS than the default limit: tapes with many saved-point slots)
+        if (prune_lds > 32768 && prune_blocks) {   // (more dynamic LDS than the default limit: tapes with many saved-point slots)
             const void *fn = t->ia_rare ? (t->full ? reinterpret_cast<const void *>(k_skip_rare<double, true>) : reinterpret_cast<const void *>(k_skip_rare<double, false>))
                                         : (t->full ? reinterpret_cast<const void *>(k_skip<double, true>) : reinterpret_cast<const void *>(k_skip<double, false>));
             HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
         }
-        if (t->ia_rare) LAUNCH_TAPE(k_skip_rare, dim3(skip_blocks + prune_blocks), dim3(256), prune_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
-        else LAUNCH_TAPE(k_skip, dim3(skip_blocks + prune_blocks), dim3(256), prune_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
+        const size_t skip_lds = prune_blocks ? prune_lds : 0;
+        if (t->ia_rare) LAUNCH_TAPE(k_skip_rare, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
+        else LAUNCH_TAPE(k_skip, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
     }
     if (!sparse) HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
                        (MeshCounters *)m->counters.p, (unsigned long long *)m->status.p, (long long)shard_index,
                        (long long)shard_count);
     HIPCHK(hipGetLastError());
+    if (prune_listed) {
+        pa.worklist = (const int *)m->worklist.p; pa.ctr = (const MeshCounters *)m->counters.p;
+        auto kp = t->full ? (t->ia_rare ? k_prune_list<true, true> : k_prune_list<true, false>) : (t->ia_rare ? k_prune_list<false, true> : k_prune_list<false, false>);
+        if (prune_lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
+        hipLaunchKernelGGL(kp, dim3((unsigned)(((long long)nb * 8 + PRUNE_BLOCK - 1) / PRUNE_BLOCK)), dim3(PRUNE_BLOCK), prune_lds, c->stream,
+                           (const uint32_t *)t->d_code, g, nb, pa);
+        HIPCHK(hipGetLastError());
+    }
     // second interval pass, per surviving batch: the groups of 4^3 cells the surface cannot be in are not sampled
     const bool culling = c->cull && intervals_ok && t->ia_complete;
     if (culling) {

@@ -16,6 +16,8 @@ struct PruneArgs {
     int tape_stride;
     int first_block;                 // workgroups >= first_block of the prepass kernel run the interval pass
     uint32_t zero_off;               // consts[zero_off + 1] == +0.0 (appended by sdf_tape_create)
+    const int *worklist;             // k_prune_list: the batches to prune are this shard's slice of the work list
+    const MeshCounters *ctr;         //               (NULL: every batch, by index)
 };
 
 // The interval pass of one workgroup of the prepass kernel (k_skip, sdf_hip.hip): 8 lanes per batch
@@ -26,8 +28,14 @@ template <bool FULL, bool RARE>
 __device__ __forceinline__ void prune_block(const uint32_t *__restrict__ code, const PruneArgs &pa, const GridDesc &g,
                                             int nbatches, int block, double *lds) {
     const int gid = block * PRUNE_BLOCK + threadIdx.x;
-    const int b = gid >> 3, oct = gid & 7;
-    const bool live = b < nbatches;
+    const int oct = gid & 7;
+    int b = gid >> 3;
+    bool live = b < nbatches;
+    if (pa.worklist) {               // (work items of this shard instead of all batches)
+        const int w = pa.ctr->work_begin + (gid >> 3);
+        live = w < pa.ctr->work_end;
+        b = live ? pa.worklist[w] : 0;
+    }
     Ival bx = ia::pt(0.0), by = ia::pt(0.0), bz = ia::pt(0.0);
     if (live) {
         int ox, oy, oz, lx, ly, lz;

@@ -768,3 +768,14 @@ def test_interval_forms_of_composed_leaves_random(seed, ns, oracle_lib, eng):
     assert s1['n_sampled_voxels'] < s1['n_eval_voxels'] or s1['n_eval_voxels'] == 0   # (every op of these trees has an interval form)
     o = oracle_lib.generate(f, X, Y, Z, 32, seed % 2 == 0)
     assert np.array_equal(k1, o.kinds) and np.array_equal(p1, o.points)
+
+
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 28), ('ex_blobby', 2 ** 29)])
+def test_pruning_over_the_work_list_on_large_grids(name, samples, ns, eng):
+    """from 8192 batches on the interval prepass runs behind k_compact, over the surviving batches only
+    (k_prune_list): same soup as without the passes, and the tapes did get pruned"""
+    f = fixtures.build(name, ns)
+    X, Y, Z, _ = core.grid_axes(core._estimate_bounds(f), samples=samples)
+    (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, f, X, Y, Z)
+    assert s1['batches'] >= 8192 and s0['n_pruned_instrs'] == 0 and s1['n_pruned_instrs'] > 0
+    assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
