@@ -1,5 +1,5 @@
 // sdf_interval.h -- the tape in interval arithmetic: which instructions can a batch skip
-// (prepass, sdf_prune.h), and where inside a batch can the surface not be (k_mesh, sdf_device.h)?
+// (prepass, sdf_prune.h), and where inside a batch can the surface not be (k_cull, sdf_device.h cull_tasks)?
 //
 // Inside one 33^3 batch most of a CSG tree is irrelevant: far from the cylinders of the canonical
 // example, `max(sphere & box, -cylinders)` is decided by its left operand at EVERY sample, so the
@@ -15,16 +15,21 @@
 // instead of the model's tape -- a pruned instruction costs nothing at all there.  Tapes longer
 // than 256 instructions are not pruned.
 //
-// This never changes a result.  Every interval operation below performs the SAME floating-point
-// operations, in the same order, as the float64 interpreter (sdf_interp.h) does for that op, on
-// the interval's end points: +, -, *, /, sqrt and fma are correctly rounded, hence monotone in each
-// argument, so the range of an operation over a box of arguments is spanned by its values at the
-// corners -- the interval contains every value the interpreter can produce for a sample in the
-// box (no outward rounding is needed, and none is done).  An operand is only dropped when its interval lies STRICTLY on the losing
-// side of the other's, in which case min / max returns the other operand bit for bit.  Anything
-// that could be NaN, and every op without an interval form (trig, repeat, ...), yields the whole
-// real line, which never licenses a skip.  The parity tests (bit-identical soups against the CPU
-// checker and the reference goldens, plus a random-CSG sweep) run with the prepass active.
+// This never changes a result.  The basic interval operations perform the SAME floating-point operations,
+// in the same order, as the float64 interpreter (sdf_interp.h) does for that op, on the interval's end
+// points: +, -, *, /, sqrt, fma and rint are correctly rounded, hence monotone in each argument, so the range
+// of an operation over a box of arguments is spanned by its values at the corners -- the interval contains
+// every value the interpreter can produce for a sample in the box (no outward rounding is needed, and none
+// is done).  Ops that go through libm on the device (hypot / atan2 / sin / cos: circular_array, twist, bend,
+// wrap_around, ...) or whose floating-point form is not monotone term by term (easing curves, the smooth
+// min / max) take the exact range of the real function widened by 1e-12; the rarer leaves are compositions
+// of interval steps (ia_leaf_rare).  An operand of a hard min / max is only dropped when its interval lies
+// STRICTLY on the losing side of the other's, in which case min / max returns the other operand bit for
+// bit; an operand of a smooth one only in its exact direction (ia_decide).  Anything that could be NaN, and
+// the few ops without an interval form (sampled textures, non-monotone easings), yields the whole real
+// line, which never licenses a skip.  The parity tests (bit-identical soups against the CPU checker and the
+// reference goldens, random CSG / array / leaf sweeps with the passes on and off) run with the prepass
+// active; tests/test_interval_host.py checks the enclosure property of the primitives on the CPU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
