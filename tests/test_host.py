@@ -155,3 +155,17 @@ def test_shard_bounds_partition_the_work_list():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
+
+
+def test_pinned_result_buffers_fall_back_to_pageable_memory_without_a_device():
+    """results land in the library's pinned blocks on a GPU box (tests/test_gpu.py); where pinning is not
+    possible the same call hands out an ordinary array"""
+    import numpy as np
+    from sdf_amd import engine
+    lib = engine.load_library()
+    small = engine.pinned_empty(lib, (10, 3), np.float64)              # below 1 MiB: never pinned
+    assert small.shape == (10, 3) and small.base is None
+    big = engine.pinned_empty(lib, (1 << 18, 3), np.float64)           # 6 MiB
+    assert big.shape == (1 << 18, 3) and big.dtype == np.float64
+    big[:] = 1.0                                                       # writable either way
+    assert float(big.sum()) == 3.0 * (1 << 18)
