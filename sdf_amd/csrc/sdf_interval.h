@@ -26,7 +26,7 @@
 // of interval steps (ia_leaf_rare).  An operand of a hard min / max is only dropped when its interval lies
 // STRICTLY on the losing side of the other's, in which case min / max returns the other operand bit for
 // bit; an operand of a smooth one only in its exact direction (ia_decide).  Anything that could be NaN, and
-// the few ops without an interval form (sampled textures, non-monotone easings), yields the whole real
+// the few ops without an interval form (non-monotone easings), yields the whole real
 // line, which never licenses a skip.  The parity tests (bit-identical soups against the CPU checker and the
 // reference goldens, random CSG / array / leaf sweeps with the passes on and off) run with the prepass
 // active; tests/test_interval_host.py checks the enclosure property of the primitives on the CPU.
@@ -288,7 +288,7 @@ __host__ __device__ inline bool ia_has_form(uint32_t op) {
     case OP_L_ROUNDED_CYLINDER: case OP_L_CAPSULE: case OP_L_OCTAHEDRON: case OP_L_CIRCLE: case OP_L_LINE: case OP_L_RECTANGLE:
     case OP_L_WIREFRAME_BOX: case OP_L_CAPPED_CYLINDER: case OP_L_ROUNDED_CONE: case OP_L_ELLIPSOID: case OP_L_TETRAHEDRON:
     case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: case OP_L_ROUNDED_RECTANGLE: case OP_L_EQUILATERAL_TRIANGLE: case OP_L_HEXAGON:
-    case OP_L_ROUNDED_X: case OP_L_VESICA: case OP_L_CAPPED_CONE: case OP_L_PYRAMID: case OP_L_POLYGON:
+    case OP_L_ROUNDED_X: case OP_L_VESICA: case OP_L_CAPPED_CONE: case OP_L_PYRAMID: case OP_L_POLYGON: case OP_L_TEXTURE2D:
     case OP_COMB: case OP_TRANSLATE: case OP_SCALE: case OP_ROTATE: case OP_ELONGATE: case OP_TRANSLATE2: case OP_SCALE2:
     case OP_ROTATE2: case OP_ELONGATE2: case OP_REVOLVE: case OP_SETZ0: case OP_SAVE_P: case OP_LOAD_P: case OP_PUSH_D: case OP_NOP:
     case OP_NEG: case OP_ADDC: case OP_SUBC: case OP_MULC: case OP_SHELL: case OP_ADD_DS: case OP_EXT_PRE: case OP_EXT_POST:
@@ -347,7 +347,7 @@ SDF_IA bool ia_is_rare_leaf(uint32_t op) {
     switch (op) {
     case OP_L_WIREFRAME_BOX: case OP_L_CAPPED_CYLINDER: case OP_L_ROUNDED_CONE: case OP_L_ELLIPSOID: case OP_L_TETRAHEDRON:
     case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: case OP_L_ROUNDED_RECTANGLE: case OP_L_EQUILATERAL_TRIANGLE: case OP_L_HEXAGON:
-    case OP_L_ROUNDED_X: case OP_L_VESICA: case OP_L_CAPPED_CONE: case OP_L_PYRAMID: case OP_L_POLYGON:
+    case OP_L_ROUNDED_X: case OP_L_VESICA: case OP_L_CAPPED_CONE: case OP_L_PYRAMID: case OP_L_POLYGON: case OP_L_TEXTURE2D:
         return true;
     default: return false;
     }
@@ -502,6 +502,32 @@ __host__ __device__ __attribute__((noinline)) inline Ival ia_leaf_rare(uint32_t 
         const Ival zero = pt(0.0);
         const Ival dd2 = sel_gt(min_(qy, sub(mulc(neg(qx), m2), mulc(qy, 0.5))), zero, zero, min_(a, b));
         return mul(sqrt_(divc(add(dd2, sqr(qz)), m2)), sign_(max_(qz, neg(py))));
+    }
+    case OP_L_TEXTURE2D: {     // text.py:116-153: bilinear look-up inside the picture, a rectangle's distance outside
+        // c: x0 y0 x1 y1 | pw ph px py | tw th | fallback rectangle (cx cy hx hy) | texture[th][tw]
+        const int tw = (int)c[8], th = (int)c[9];
+        const double *tex = c + 14;
+        if (tw < 2 || th < 2 || bad(x) || bad(y)) return top();
+        const Ival u = divc(subc(x, c[0]), c[2] - c[0]);
+        const Ival vv = csub(1.0, divc(subc(y, c[1]), c[3] - c[1]));
+        const Ival ti = addc(mulc(u, c[4]), c[6]), tj = addc(mulc(vv, c[5]), c[7]);
+        const Ival qx = subc(abs_(subc(x, c[10])), c[12]), qy = subc(abs_(subc(y, c[11])), c[13]);
+        const Ival q = add(len2(maxc(qx, 0.0), maxc(qy, 0.0)), minc(max_(qx, qy), 0.0));
+        if (bad(ti) || bad(tj) || !finite_(ti) || !finite_(tj)) return top();
+        const double wi = (double)(tw - 1), hj = (double)(th - 1);
+        if (ti.hi < 0.0 || ti.lo >= wi || tj.hi < 0.0 || tj.lo >= hj) return q;          // outside for every point of the box
+        // inside, the four weights lie in [0, 1] and add up to 1: the value is a convex combination of the four
+        // texels around the point (to a few roundings); over the box: of the texels the box can reach
+        const int i0 = (int)floor(fmax(ti.lo, 0.0)), i1 = (int)fmin(floor(fmin(ti.hi, wi)) + 1.0, wi);
+        const int j0 = (int)floor(fmax(tj.lo, 0.0)), j1 = (int)fmin(floor(fmin(tj.hi, hj)) + 1.0, hj);
+        if ((long long)(i1 - i0 + 1) * (long long)(j1 - j0 + 1) > 1024) return top();     // (a box that large decides nothing anyway)
+        double lo = __builtin_inf(), hi = -__builtin_inf();
+        for (int j = j0; j <= j1; j++)
+            for (int i = i0; i <= i1; i++) { const double p = tex[(size_t)j * tw + i]; lo = fmin(lo, p); hi = fmax(hi, p); if (p != p) return top(); }
+        if (!(lo <= hi)) return top();
+        const Ival d = pad(Ival{lo, hi}, 1e-12, 1e-300);
+        const bool all_inside = ti.lo >= 0.0 && ti.hi < wi && tj.lo >= 0.0 && tj.hi < hj;
+        return all_inside ? d : hull(d, q);
     }
     case OP_L_POLYGON: {       // d2.py:175-196
         const int np_ = (int)c[0];

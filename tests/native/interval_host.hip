@@ -262,20 +262,45 @@ int main() {
                     if ((c1 && c2 && c3) || (!c1 && !c2 && !c3)) sg = -sg;
                 }
                 return sg * std::sqrt(d); }
+            case OP_L_TEXTURE2D: {
+                const int tw = (int)c[8], th = (int)c[9];
+                const double *tex = c + 14;
+                const double u = (x - c[0]) / (c[2] - c[0]);
+                double vv = (y - c[1]) / (c[3] - c[1]);
+                vv = 1.0 - vv;
+                const double fi = u * c[4] + c[6], fj = vv * c[5] + c[7];
+                const double gi = fi == fi ? sclip(std::floor(fi), -2.0, (double)tw) : 0.0, gj = fj == fj ? sclip(std::floor(fj), -2.0, (double)th) : 0.0;
+                const int a0 = (int)gi, b0 = (int)gj;
+                const int ix0 = std::min(std::max(a0, 0), tw - 1), ix1 = std::min(std::max(a0 + 1, 0), tw - 1);
+                const int iy0 = std::min(std::max(b0, 0), th - 1), iy1 = std::min(std::max(b0 + 1, 0), th - 1);
+                const double pa = tex[iy0 * tw + ix0], pb = tex[iy1 * tw + ix0], pc = tex[iy0 * tw + ix1], pd = tex[iy1 * tw + ix1];
+                const double wa = ((double)ix1 - fi) * ((double)iy1 - fj), wb = ((double)ix1 - fi) * (fj - (double)iy0);
+                const double wc = (fi - (double)ix0) * ((double)iy1 - fj), wd = (fi - (double)ix0) * (fj - (double)iy0);
+                const double d = wa * pa + wb * pb + wc * pc + wd * pd;
+                const double qx = fabs(x - c[10]) - c[12], qy = fabs(y - c[11]) - c[13];
+                const double q = l2(smax(qx, 0), smax(qy, 0)) + smin(smax(qx, qy), 0);
+                const bool outside = (fi < 0) || (fi >= (double)(tw - 1)) || (fj < 0) || (fj >= (double)(th - 1));
+                return outside ? q : d; }
             default: return 0.0;
             }
         };
-        const uint32_t ops[] = {OP_L_CAPPED_CONE, OP_L_PYRAMID, OP_L_POLYGON,OP_L_WIREFRAME_BOX, OP_L_CAPPED_CYLINDER, OP_L_ROUNDED_CONE, OP_L_ELLIPSOID, OP_L_TETRAHEDRON, OP_L_DODECAHEDRON,
+        const uint32_t ops[] = {OP_L_TEXTURE2D, OP_L_CAPPED_CONE, OP_L_PYRAMID, OP_L_POLYGON,OP_L_WIREFRAME_BOX, OP_L_CAPPED_CYLINDER, OP_L_ROUNDED_CONE, OP_L_ELLIPSOID, OP_L_TETRAHEDRON, OP_L_DODECAHEDRON,
                                 OP_L_ICOSAHEDRON, OP_L_ROUNDED_RECTANGLE, OP_L_EQUILATERAL_TRIANGLE, OP_L_HEXAGON, OP_L_ROUNDED_X, OP_L_VESICA};
         long decided = 0, boxes = 0;
         for (uint32_t op : ops) {
             for (int it = 0; it < 60000; it++) {
-                double c[16];
+                double c[14 + 24 * 20];
                 for (int k = 0; k < 16; k++) c[k] = pick(0.1, 1.2);
                 if (op == OP_L_CAPPED_CYLINDER) {      // a, ba, baba, -, radius, baba / 2 (d3.py:184-204)
                     for (int k = 0; k < 6; k++) c[k] = pick(-1, 1);
                     c[6] = (c[3] * c[3] + c[4] * c[4]) + c[5] * c[5]; c[8] = pick(0.05, 0.6) * c[6]; c[9] = c[6] * 0.5;
                     if (!(c[6] > 1e-3)) continue;
+                }
+                if (op == OP_L_TEXTURE2D) {              // a 24 x 20 picture over [-1.5, 1.5] x [-1, 1] with a margin of 2 pixels
+                    const int tw = 24, th = 20;
+                    c[0] = -1.5; c[1] = -1.0; c[2] = 1.5; c[3] = 1.0; c[4] = tw - 5; c[5] = th - 5; c[6] = 2; c[7] = 2; c[8] = tw; c[9] = th;
+                    c[10] = 0; c[11] = 0; c[12] = 1.5; c[13] = 1.0;
+                    for (int k = 0; k < tw * th; k++) c[14 + k] = pick(-0.5, 0.5) + 0.02 * (k % tw);
                 }
                 if (op == OP_L_CAPPED_CONE) {            // a, ba, ra, rb, baba, rba, k (d3.py:217-237)
                     for (int k = 0; k < 6; k++) c[k] = pick(-1, 1);

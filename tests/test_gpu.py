@@ -779,3 +779,20 @@ def test_pruning_over_the_work_list_on_large_grids(name, samples, ns, eng):
     (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, f, X, Y, Z)
     assert s1['batches'] >= 8192 and s0['n_pruned_instrs'] == 0 and s1['n_pruned_instrs'] > 0
     assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
+
+
+@pytest.mark.parametrize('name', ['frame', 'blobs', 'noise'])
+def test_interval_passes_on_texture_leaf_are_bit_identical(name, ns, oracle_lib, eng):
+    """the sampled-field leaf has an interval form too (the texels a box can reach): culled + pruned execution
+    against the plain one and against the CPU checker"""
+    from test_oracle import _pictures
+    arr, kw = _pictures()[name]
+    g = ns['image'](arr, **kw).extrude(0.4) - ns['sphere'](0.15).translate((0.2, 0.1, 0.2))
+    bounds = core._estimate_bounds(g)
+    X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** 19)
+    (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, g, X, Y, Z)
+    assert s0['n_sampled_voxels'] == s0['n_eval_voxels']
+    assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
+    assert s1['n_sampled_voxels'] < s1['n_eval_voxels']
+    o = oracle_lib.generate(g, X, Y, Z, 32, True)
+    assert np.array_equal(k1, o.kinds) and np.array_equal(p1, o.points)
