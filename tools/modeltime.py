@@ -10,12 +10,13 @@ from sdf_amd import core, engine
 import fixtures
 ns = {k: getattr(s, k) for k in dir(s) if not k.startswith('_')}
 eng = engine.get_engine(0)
-jobs = sys.argv[1:] or ['example:27', 'gearlike:27', 'gearlike:30', 'blobby:27', 'blobby:30', 'weave:24', 'weave:27', 'knurling:24']
+on_only = '--on-only' in sys.argv
+jobs = [a for a in sys.argv[1:] if not a.startswith('--')] or ['example:27', 'gearlike:27', 'gearlike:30', 'blobby:27', 'blobby:30', 'weave:24', 'weave:27', 'knurling:24']
 for job in jobs:
     name, k = job.split(':')
     f = fixtures.build('ex_' + name, ns)
     X, Y, Z, _ = core.grid_axes(core._estimate_bounds(f), None, 2 ** int(k))
-    for on in (1, 0):
+    for on in ((1,) if on_only else (1, 0)):
         eng.set_prune(on); eng.set_cull(on)
         best = None
         for _ in range(3):
