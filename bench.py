@@ -12,7 +12,8 @@ soup in HBM (and, for N>1, the RCCL all-gather of the rank soups).  The axes are
 reported separately as `value_incl_d2h`).  float64 sampling = the reference's NumPy precision.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (k_mesh),
-`cpu_baseline` = the CPU oracle (a C port of the reference path) timed on one host core.
+`cpu_baseline` = the reference's own CPU path (NumPy thread pool + skimage; live where the reference is
+installed, else the committed build-container run, see `kind`), `cpu_port` = the C oracle timed live on one host core.
 """
 import argparse
 import json
@@ -25,9 +26,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# bounds the reference's _estimate_bounds returns for the example (tests/golden/bounds.npz)
-EXAMPLE_BOUNDS = ((-0.8454303741455078, -0.8454303741455078, -0.8454303741455078),
-                  (0.8454312324523926, 0.8454312324523926, 0.8454312324523926))
+# bounds the reference's _estimate_bounds returns for the example (tests/golden/bounds.npz['ex_example'])
+EXAMPLE_BOUNDS = ((-0.8454300600008358, -0.8454300600008358, -0.8454300600008358),
+                  (0.8454307895539046, 0.8454307895539046, 0.8454307895539046))
+# sha256 of the float64 soup the UNMODIFIED reference produces on that grid at samples=2**27
+# (tools/make_golden_full.py -> tests/golden/full_c2_example_s27.npz; 2 945 152 triangles)
+EXAMPLE_S27_SHA256 = '51db77f1a24d68538de3fdfb99fdc379fad9917d3076090ed7086060bb89b88a'
+REFERENCE_DIR = '/root/reference'
+REFERENCE_PYTHON = '/opt/conda/bin/python3.9'
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6
@@ -44,6 +50,35 @@ def build_model(name):
     import fixtures
     ns = {k: getattr(s, k) for k in dir(s) if not k.startswith('_')}
     return fixtures.build('ex_' + name, ns), None
+
+
+def reference_cpu_baseline(samples_log2):
+    """the `cpu_baseline` object from the reference's own generate(): live (subprocess of the reference's
+    interpreter, tools/time_reference.py) or, where the reference is not installed, the committed numbers"""
+    import subprocess
+    script = os.path.join(ROOT, 'tools', 'time_reference.py')
+    rec, kind = None, None
+    if os.path.isdir(REFERENCE_DIR) and os.path.exists(REFERENCE_PYTHON) and not os.environ.get('SDF_BENCH_NO_LIVE_REFERENCE'):
+        try:
+            env = {k: v for k, v in os.environ.items() if k != 'PYTHONPATH'}
+            out = subprocess.run([REFERENCE_PYTHON, '-W', 'ignore', script, '--samples-log2', str(samples_log2)],
+                                 env=env, capture_output=True, text=True, timeout=600, check=True).stdout
+            rec, kind = json.loads(out.strip().splitlines()[-1]), 'reference'
+        except Exception as e:           # fall back to the committed run
+            sys.stderr.write('live reference timing failed: %r\n' % (e,))
+    if rec is None:
+        path = os.path.join(ROOT, 'profiles', 'reference_cpu.json')
+        if not os.path.exists(path):
+            return None
+        rec = json.load(open(path))
+        kind = 'reference (measured in the build container, %d vCPU; %s absent on this box)' % (rec['host_cores'], REFERENCE_DIR)
+    best = max(rec['runs'], key=lambda r: r['voxels_per_sec'])
+    return {'value': best['voxels_per_sec'], 'unit': 'voxels/s', 'cores': best['workers'], 'kind': kind,
+            'sample': '%s; %s; whole workload, %.1f s with workers=%d; all runs: %s'
+                      % (rec['path'], rec['workload'], best['seconds'], best['workers'],
+                         ', '.join('workers=%d %.1f s' % (r['workers'], r['seconds']) for r in rec['runs'])),
+            'triangles_per_sec': best['triangles_per_sec'], 'host_cores': rec['host_cores'],
+            'soup_sha256': best.get('soup_sha256')}
 
 
 def main():
@@ -110,6 +145,8 @@ def main():
             big = torch.empty(max(t + t // 8, 1) * 9, dtype=torch.float64, device=dev)
             mesh.emit_device(big.data_ptr())
             state['bufs'][state['bufs'].index(buf)] = big
+            buf = big
+        state['last_buf'] = buf
         st = mesh.stats()
         state['stats'] = st
         state['tris'] = t
@@ -188,11 +225,18 @@ def main():
             mesh.close()
         incl = grid_voxels * n_incl / (time.perf_counter() - t1)
 
-    # parity spot check inside the bench run: identical soup from two passes + reference counts
+    # parity check inside the bench run: the sha256 of the soup the LAST TIMED STEP left in its device buffer
+    # (copied out after the timed region) against the hash of the reference's own soup on this grid
     check = None
-    if world == 1 and not args.no_check and args.model == 'example' and args.samples_log2 == 27:
-        check = bool((st['batches'], st['skipped'], st['empty'], st['nonempty'], tris) ==
-                     (4096, 2352, 120, 1624, 2945152))
+    soup_sha = None
+    if world == 1 and not args.no_check:
+        import hashlib
+        last = state.get('last_buf')          # the buffer the last collected (= last timed) step wrote
+        if last is not None and tris * 9 <= last.numel():
+            soup_sha = hashlib.sha256(last[:tris * 9].cpu().numpy().tobytes()).hexdigest()
+        if args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64':
+            check = bool(soup_sha == EXAMPLE_S27_SHA256 and
+                         (st['batches'], st['skipped'], st['empty'], st['nonempty'], tris) == (4096, 2352, 120, 1624, 2945152))
 
     if rank != 0:
         if td is not None:
@@ -238,7 +282,14 @@ def main():
                  'peak_tflops': FP64_VECTOR_PEAK_TFLOPS if args.precision == 'f64' else 157.3},
     }
 
-    # ---- CPU baseline: the C oracle (port of the reference path), one core, same workload ----
+    # ---- CPU baseline 1: the reference's own path (reference sdf/core.py:84-150, NumPy thread pool + skimage) ----
+    # timed live when the reference and its interpreter exist on this box (the build container); the GPU boxes
+    # have neither, there the committed numbers of the build-container run are reported with that provenance
+    cpu_ref = None
+    if not args.no_cpu_baseline and args.model == 'example' and args.samples_log2 == 27:
+        cpu_ref = reference_cpu_baseline(args.samples_log2)
+
+    # ---- CPU baseline 2: the C oracle (a port of the reference path), one core, same workload, always live ----
     cpu = None
     if not args.no_cpu_baseline:
         import oracle
@@ -272,8 +323,12 @@ def main():
         'latency_ms_per_call': round(latency_ms, 4) if latency_ms else None,
         'device_ms': {'prepass': round(st['ms_prepass'], 4), 'mesh': round(k_ms, 4), 'emit': round(st.get('ms_emit', 0.0), 4)},
         'parity_check': check,
+        'parity': {'soup_sha256': soup_sha, 'reference_sha256': EXAMPLE_S27_SHA256 if check is not None else None,
+                   'what': 'sha256 of the float64 soup of the last timed step (copied from its device buffer after the '
+                           'timed region) vs the unmodified reference on the same grid (tests/golden/full_c2_example_s27.npz)'},
         'roofline': roofline,
-        'cpu_baseline': cpu,
+        'cpu_baseline': cpu_ref if cpu_ref is not None else cpu,
+        'cpu_port': cpu,
     }
     print(json.dumps(out))
     if td is not None:

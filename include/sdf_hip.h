@@ -95,6 +95,28 @@ int sdf_eval_points_host(sdf_tape *tape, const double *h_points, int64_t n, int 
 int sdf_eval_grid_host(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z,
                        int nz, double *h_out, int precision);
 
+/* Models with user-written closures (the reference's documented extension point: a function decorated with
+ * @sdf3 / @op3 returns `f(p)`, NumPy code -- reference README.md:258-295, sdf/d3.py:48-63).  The closure runs on
+ * the host, in the user's interpreter; the tape reads its values through L_EXTERN leaves.  f(P) then takes two
+ * device passes with the closures in between:
+ *   sdf_eval_extern_points_host   h_ext_points[k][i][3] = the point leaf k sees for sample i (n_extern x n x 3)
+ *   sdf_eval_points_extern_host   f(P) given h_ext_values[k][i] = closure k at that point      (n_extern x n)
+ * The plain entry points refuse such a tape. */
+int sdf_tape_extern_count(sdf_tape *tape);
+int sdf_eval_extern_points_host(sdf_tape *tape, const double *h_points, int64_t n, int dim, double *h_ext_points,
+                                int precision);
+int sdf_eval_points_extern_host(sdf_tape *tape, const double *h_points, int64_t n, int dim, const double *h_ext_values,
+                                double *h_out, int precision);
+/* The batch loop of `generate` (reference sdf/core.py:114-141) around a field evaluated by a HOST callback:
+ * `field(user, points (n x 3 float64, host), n, values (n float64, host))` returns 0, or non-zero to abort.  The
+ * library builds the points of the skip test (`_skip`, core.py:28-43) and of every surviving batch
+ * (`_cartesian_product`, core.py:20-26), calls the field, and meshes the values on the device (float32 cast,
+ * marching cubes, `points * scale + offset`); the result is an ordinary sdf_mesh. */
+typedef int (*sdf_field_fn)(void *user, const double *points, int64_t n, double *values);
+int sdf_generate_field(sdf_ctx *ctx, sdf_field_fn field, void *user, const double *X, int nx, const double *Y, int ny,
+                       const double *Z, int nz, int batch_size, int sparse, int64_t shard_index, int64_t shard_count,
+                       sdf_mesh **out);
+
 /* Marching cubes of a C-order float32 volume (n0,n1,n2) at level 0: replaces `_marching_cubes`
  * (reference sdf/core.py:16-18 -> skimage.measure.marching_cubes(volume, 0)).  Writes up to
  * cap_tris triangles (9 float32 each: 3 vertices in volume index coordinates, reference soup
@@ -139,6 +161,13 @@ int64_t sdf_mesh_triangles(sdf_mesh *mesh);
  * reference sdf/core.py:58-60) into caller-owned device / host memory of 9*T doubles */
 int sdf_mesh_emit_device(sdf_mesh *mesh, void *d_out);
 int sdf_mesh_emit_host(sdf_mesh *mesh, double *h_out);
+/* triangles [first_tri, first_tri + n_tris) of the soup only (9 doubles each) */
+int sdf_mesh_emit_host_range(sdf_mesh *mesh, int64_t first_tri, int64_t n_tris, double *h_out);
+/* n_batches + 1 entries: h_out[b] = index (within this shard's soup) of the first triangle of batch b in
+ * reference batch order, h_out[n_batches] = sdf_mesh_triangles(); batches that were skipped, are empty
+ * or belong to another shard have h_out[b] == h_out[b + 1].  This is the bookkeeping the reference keeps
+ * implicitly by extending its point list batch after batch (reference sdf/core.py:137-141). */
+int sdf_mesh_batch_offsets(sdf_mesh *mesh, int64_t *h_out);
 /* T binary-STL records of 50 bytes (f32 normal, 3 x f32 vertex, u16 0), i.e. the body that
  * `write_binary_stl` writes after the 84-byte header (reference sdf/stl.py:4-24) */
 int sdf_mesh_emit_stl_host(sdf_mesh *mesh, void *h_out);

@@ -459,6 +459,44 @@ static double eval_node(const tree_t *t, int id, const double *p) {
         double qd = len2(np_max(qx, 0), np_max(qy, 0)) + np_min(np_max(qx, qy), 0);
         int outside = (fi < 0) || (fi >= (double)(tw - 1)) || (fj < 0) || (fj >= (double)(th - 1));
         return outside ? qd : d; }
+    case NODE_grid3d: { /* mesh.py:96-105 `f`: np.where(e > background, e, interpolator(p)) with e = box(a=a, b=b)
+                         * (d3.py:122-134) and scipy 1.7.1 RegularGridInterpolator(method='linear', bounds_error=False,
+                         * fill_value=background): _find_indices (searchsorted - 1 clipped to [0, n-2], out of bounds =
+                         * x < grid[0] or x > grid[-1]) and _evaluate_linear (values = 0.; for the 8 corners in
+                         * itertools.product order: weight = ((1. * wx) * wy) * wz; values += float32 voxel * weight).
+                         * c: nx ny nz background box-centre(3) box-half-size(3) X[nx] Y[ny] Z[nz] A[nx][ny][nz] */
+        long n3[3] = {(long)c[0], (long)c[1], (long)c[2]};
+        double bg = c[3];
+        const double *g[3] = {c + 10, c + 10 + n3[0], c + 10 + n3[0] + n3[1]};
+        const double *vox = c + 10 + n3[0] + n3[1] + n3[2];
+        double qx = fabs(x - c[4]) - c[7], qy = fabs(y - c[5]) - c[8], qz = fabs(z - c[6]) - c[9];
+        double e = len3(np_max(qx, 0), np_max(qy, 0), np_max(qz, 0)) + np_min(np_max(np_max(qx, qy), qz), 0);
+        double pp[3] = {x, y, z}, w[3];
+        long idx[3];
+        int oob = 0;
+        for (int a = 0; a < 3; a++) {
+            long lo = 0, hi = n3[a];
+            while (lo < hi) { /* np.searchsorted side='left'; NaN sorts last */
+                long mid = (lo + hi) >> 1;
+                double gm = g[a][mid];
+                if (gm < pp[a] || (pp[a] != pp[a] && gm == gm)) lo = mid + 1; else hi = mid;
+            }
+            long i = lo - 1; if (i < 0) i = 0; if (i > n3[a] - 2) i = n3[a] - 2;
+            idx[a] = i;
+            w[a] = (pp[a] - g[a][i]) / (g[a][i + 1] - g[a][i]);
+            oob = oob || pp[a] < g[a][0] || pp[a] > g[a][n3[a] - 1];
+        }
+        double values = 0.0;
+        for (int k = 0; k < 8; k++) {
+            int o0 = k >> 2, o1 = (k >> 1) & 1, o2 = k & 1;
+            double weight = 1.0;
+            weight *= o0 ? w[0] : 1 - w[0];
+            weight *= o1 ? w[1] : 1 - w[1];
+            weight *= o2 ? w[2] : 1 - w[2];
+            values += vox[((idx[0] + o0) * n3[1] + (idx[1] + o1)) * n3[2] + (idx[2] + o2)] * weight;
+        }
+        double d = oob ? bg : values;
+        return e > bg ? e : d; }
     case NODE_translate2: q[0] = x - c[0]; q[1] = y - c[1]; q[2] = z; return child(t, n, 0, q);
     case NODE_scale2: q[0] = x / c[0]; q[1] = y / c[1]; q[2] = z; return child(t, n, 0, q) * c[2];
     case NODE_rotate2: /* d2.py:229-240: np.dot(p, matrix), matrix row-major c[0..3] */

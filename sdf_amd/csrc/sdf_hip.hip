@@ -59,6 +59,19 @@ __global__ __launch_bounds__(256) void k_eval_grid(const uint32_t *__restrict__ 
     out[i] = (double)run_tape1<T, FULL>(code, consts, (T)X[ix], (T)Y[iy], (T)Z[iz]);
 }
 
+// f(P) for tapes with user closures (L_EXTERN leaves): `dump` writes every leaf's current point for the host
+// to call the closure on, the second pass reads the closures' values (sdf_interp.h ExtIO)
+template <typename T, bool FULL>
+__global__ __launch_bounds__(256) void k_eval_points_ext(const uint32_t *__restrict__ code, const T *__restrict__ consts,
+                                                         const double *__restrict__ pts, long long n, int dim,
+                                                         double *__restrict__ ext, int dump, double *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T x = (T)pts[i * dim], y = (T)pts[i * dim + 1], z = dim > 2 ? (T)pts[i * dim + 2] : T(0);
+    const T v = run_tape1_ext<T, FULL>(code, consts, x, y, z, ExtIO{ext, n, i, dump != 0});
+    if (!dump) out[i] = (double)v;
+}
+
 // reference sdf/core.py:28-43.  16 lanes per batch: lane 0 = centre, lanes 1..8 = corners in
 // itertools.product((x0,x1),(y0,y1),(z0,z1)) order.  kinds[b] = 0 (skipped) or 255 (pending).
 // Workgroups >= pa.first_block run the interval pass of the same batches instead (sdf_prune.h).
@@ -280,6 +293,93 @@ __global__ __launch_bounds__(256) void k_mc_emit(const McTables *__restrict__ mc
     }
 }
 
+// ---- marching cubes of MANY caller-supplied tiles in one submission (sdf_generate_field: the volumes of a
+// chunk of batches sampled by a host callback).  A tile has at most 32 x 32 rows of cells; row slot
+// tile * 1024 + t carries the row's triangle count (0 beyond the tile's rows), so one scan over the slots
+// numbers the triangles of the whole chunk in reference order. ----
+struct FieldTile {
+    long long vol_off;      // first sample of the tile in the chunk's value buffer
+    int n0, n1, n2, pad_;
+    double of[3], sc[3];    // points * scale + offset (reference sdf/core.py:58-60)
+};
+
+__global__ __launch_bounds__(256) void k_cast_f32(const double *__restrict__ in, float *__restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];     // volume.astype(float32) inside skimage
+}
+
+__device__ __forceinline__ unsigned mc_row_count(const McTables *__restrict__ mc, const float *__restrict__ row, int s0, int s1, int c2) {
+    unsigned prev = plane_bits(row, s0, s1);
+    unsigned cnt = 0;
+    for (int i2 = 0; i2 < c2; i2++) {
+        const unsigned next = plane_bits(row + i2 + 1, s0, s1);
+        const unsigned cfg = spread4(prev) | (spread4(next) << 1);
+        if (mc->amb[cfg]) {
+            double lv[8];
+            int off;
+            mc33_load_cell(row + i2, s0, s1, lv);
+            cnt += (unsigned)mc33_cell(lv, mc->mc33, &off);
+        } else {
+            cnt += mc->ntri[cfg];
+        }
+        prev = next;
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void k_field_rows(const McTables *__restrict__ mc, const float *__restrict__ vol,
+                                                    const FieldTile *__restrict__ tiles, unsigned int *__restrict__ row_count) {
+    const FieldTile tl = tiles[blockIdx.y];
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);        // row slot 0..1023
+    const int c0 = tl.n0 - 1, c1 = tl.n1 - 1, c2 = tl.n2 - 1;
+    unsigned cnt = 0;
+    if (c0 > 0 && c1 > 0 && c2 > 0 && t < c0 * c1) {
+        const int i0 = t / c1, i1 = t - i0 * c1;
+        const int s0 = tl.n1 * tl.n2, s1 = tl.n2;
+        cnt = mc_row_count(mc, vol + tl.vol_off + (long long)i0 * s0 + (long long)i1 * s1, s0, s1, c2);
+    }
+    row_count[(size_t)blockIdx.y * 1024 + t] = cnt;
+}
+
+__global__ __launch_bounds__(256) void k_field_emit(const McTables *__restrict__ mc, const float *__restrict__ vol,
+                                                    const FieldTile *__restrict__ tiles, const unsigned long long *__restrict__ row_off,
+                                                    double *__restrict__ out, unsigned long long base, unsigned long long cap) {
+    const FieldTile tl = tiles[blockIdx.y];
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int c0 = tl.n0 - 1, c1 = tl.n1 - 1, c2 = tl.n2 - 1;
+    if (c0 <= 0 || c1 <= 0 || c2 <= 0 || t >= c0 * c1) return;
+    const int i0 = t / c1, i1 = t - i0 * c1;
+    const int s0 = tl.n1 * tl.n2, s1 = tl.n2;
+    const float *row = vol + tl.vol_off + (long long)i0 * s0 + (long long)i1 * s1;
+    unsigned long long k = base + row_off[(size_t)blockIdx.y * 1024 + t];
+    unsigned prev = plane_bits(row, s0, s1);
+    for (int i2 = 0; i2 < c2; i2++) {
+        const unsigned next = plane_bits(row + i2 + 1, s0, s1);
+        const unsigned cfg = spread4(prev) | (spread4(next) << 1);
+        prev = next;
+        int nt = mc->ntri[cfg];
+        const bool amb = mc->amb[cfg] != 0;
+        if (amb) {
+            double lv[8];
+            int off;
+            mc33_load_cell(row + i2, s0, s1, lv);
+            nt = mc33_cell(lv, mc->mc33, &off);
+        }
+        for (int j = 0; j < nt; j++, k++) {
+            if (k >= cap) return;
+            float o[9];
+            if (amb) mc33_triangle(row + i2, s0, s1, i0, i1, i2, mc->mc33, j, o);
+            else for (int q = 0; q < 3; q++) mc_vertex(row + i2, s0, s1, i0, i1, i2, mc->tri[cfg][3 * j + q], o + q * 3);
+            double *d = out + k * 9ull;
+            for (int q = 0; q < 9; q += 3) {
+                d[q] = (double)o[q] * tl.sc[0] + tl.of[0];
+                d[q + 1] = (double)o[q + 1] * tl.sc[1] + tl.of[1];
+                d[q + 2] = (double)o[q + 2] * tl.sc[2] + tl.of[2];
+            }
+        }
+    }
+}
+
 // ---- STL records (reference sdf/stl.py:4-24): float32 vertices, normal = normalised cross ----
 __global__ __launch_bounds__(256) void k_stl(const double *__restrict__ pts, long long ntri, unsigned short *__restrict__ out) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -393,6 +493,7 @@ struct CallSlot {
     hipEvent_t e0 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr;   // start, prepass end, k_mesh start (re-runs), k_mesh end
     hipEvent_t done = nullptr;                                            // behind the counters' copy to the host
     bool busy = false;
+    struct sdf_mesh *owner = nullptr;                                     // the in-flight mesh whose counters / events the slot holds
 };
 #define SDF_PARK_TRIS 8192   // triangles per workgroup staging slot of k_mesh (36 bytes each); larger batches wait instead
 
@@ -403,6 +504,8 @@ struct sdf_ctx {
     int n_cu = 256;
     size_t lds_max = 0;
     DevBuf scratch_in, scratch_out, rows, rows_off, mc;
+    DevBuf ext;                       // closure points / values of sdf_eval_*extern* (L_EXTERN leaves)
+    DevBuf field_vals, field_vol, field_tiles;   // sdf_generate_field: a chunk's sampled values (f64), volumes (f32), tile table
     int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int prune = 1;                    // SDF_PRUNE=0 switches the interval prepass off (diagnostics)
@@ -430,6 +533,7 @@ struct sdf_tape {
     uint16_t *d_rstart = nullptr, *d_lstart = nullptr;   // operand ranges of the prunable combines (or NULL)
     bool ia_complete = false;                            // every op has an interval form (sdf_interval.h ia_has_form)
     bool ia_rare = false;                                // ... one of them a leaf of ia_leaf_rare (the k_cull variant that knows them)
+    uint32_t n_extern = 0;                               // user closures the tape reads through L_EXTERN leaves (sdf_eval_points_extern_*)
     unsigned long long hint_key = 0, hint_total_tris = 0;   // arena sizing: last call of this tape
 };
 
@@ -505,6 +609,8 @@ static int validate_tape(const uint32_t *code, uint32_t n_words, uint32_t n_cons
     return 0;
 }
 
+static int ctx_init(sdf_ctx *c);
+
 extern "C" {
 
 int sdf_abi_version(void) { return SDF_ABI_VERSION; }
@@ -531,6 +637,17 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
     c->lds_max = prop.sharedMemPerBlock;
+    if (ctx_init(c)) {          // (whatever was created so far goes back)
+        const std::string keep = g_err;
+        sdf_ctx_destroy(c);
+        g_err = keep;
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+static int ctx_init(sdf_ctx *c) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
@@ -554,7 +671,6 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
     if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(128)) return 1; }
-    *out = c;
     return 0;
 }
 
@@ -562,7 +678,8 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof, &c->park})
+    for (DevBuf *b : {&c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof, &c->park, &c->ext, &c->field_vals,
+                      &c->field_vol, &c->field_tiles})
         b->release();
     for (auto &b : c->arena_pool) b.release();
     for (auto &b : c->counter_pool) b.release();
@@ -606,12 +723,19 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     if (validate_tape(code, n_words, n_consts, n_p, n_d)) return 1;
     HIPCHK(hipSetDevice(c->device));
     sdf_tape *t = new sdf_tape();
+    struct Guard { sdf_tape *t; ~Guard() { if (t) { const std::string keep = g_err; sdf_tape_destroy(t); g_err = keep; } } } guard{t};
     t->ctx = c; t->n_words = n_words; t->n_consts = n_consts;
     t->full = tape_needs_full(code, n_words, consts);
     t->ia_complete = true;
     for (uint32_t i = 0; i < n_words; i += 2) {
         t->ia_complete = t->ia_complete && ia_has_form(code[i] & 255u);
         t->ia_rare = t->ia_rare || ia_is_rare_leaf(code[i] & 255u);
+        if ((code[i] & 255u) == OP_L_EXTERN) {
+            if ((code[i + 1] & 0xFFFFFFu) + 1 >= n_consts) return fail("tape: closure index out of the constant pool");
+            const double k = consts[(code[i + 1] & 0xFFFFFFu) + 1];
+            if (!(k >= 0.0 && k < 65536.0 && k == (double)(uint32_t)k)) return fail("tape: bad closure index");
+            t->n_extern = std::max(t->n_extern, (uint32_t)k + 1u);
+        }
     }
     t->n_p = n_p; t->n_d = n_d;
     // two more constants behind the tape's own: a K slot and +0.0, the operand of the `acc + (+0.0)` that a
@@ -629,6 +753,7 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     HIPCHK(hipMemcpy(t->d_code, pcode.data(), pcode.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t->d_c64, c64.data(), c64.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t->d_c32, c32.data(), c32.size() * sizeof(float), hipMemcpyHostToDevice));
+    guard.t = nullptr;
     *out = t;
     return 0;
 }
@@ -681,6 +806,7 @@ int sdf_eval_points(sdf_tape *t, const void *d_pts, int64_t n, int dim, void *d_
     if (!t || !d_pts || !d_out) return fail("sdf_eval_points: NULL argument");
     if (dim != 2 && dim != 3) return fail("sdf_eval_points: dim must be 2 or 3");
     if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_points: bad precision");
+    if (t->n_extern) return fail("sdf_eval_points: the tape reads user closures (L_EXTERN): use sdf_eval_extern_points_host / sdf_eval_points_extern_host");
     if (n <= 0) return 0;
     HIPCHK(hipSetDevice(t->ctx->device));
     const unsigned grid = (unsigned)((n + 255) / 256);
@@ -691,6 +817,8 @@ int sdf_eval_points(sdf_tape *t, const void *d_pts, int64_t n, int dim, void *d_
 
 int sdf_eval_points_host(sdf_tape *t, const double *h_pts, int64_t n, int dim, double *h_out, int precision) {
     if (!t || !h_pts || !h_out) return fail("sdf_eval_points_host: NULL argument");
+    if (dim != 2 && dim != 3) return fail("sdf_eval_points_host: dim must be 2 or 3");
+    if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_points_host: bad precision");
     if (n <= 0) return 0;
     sdf_ctx *c = t->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -706,6 +834,7 @@ int sdf_eval_grid_host(sdf_tape *t, const double *X, int nx, const double *Y, in
                        double *h_out, int precision) {
     if (!t || !X || !Y || !Z || !h_out) return fail("sdf_eval_grid_host: NULL argument");
     if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_grid_host: bad precision");
+    if (t->n_extern) return fail("sdf_eval_grid_host: the tape reads user closures (L_EXTERN): evaluate it with the *_extern_* entry points");
     if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
     sdf_ctx *c = t->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -720,6 +849,52 @@ int sdf_eval_grid_host(sdf_tape *t, const double *X, int nx, const double *Y, in
                 nx, ny, nz, (double *)c->scratch_out.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sdf_tape_extern_count(sdf_tape *t) { return t ? (int)t->n_extern : 0; }
+
+// phase 1 of f(P) for a tape with user closures: the point every L_EXTERN leaf sees, per sample
+int sdf_eval_extern_points_host(sdf_tape *t, const double *h_pts, int64_t n, int dim, double *h_ext_pts, int precision) {
+    if (!t || !h_pts || !h_ext_pts) return fail("sdf_eval_extern_points_host: NULL argument");
+    if (dim != 2 && dim != 3) return fail("sdf_eval_extern_points_host: dim must be 2 or 3");
+    if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_extern_points_host: bad precision");
+    if (!t->n_extern) return fail("sdf_eval_extern_points_host: the tape has no user closures");
+    if (n <= 0) return 0;
+    sdf_ctx *c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t ext_bytes = (size_t)t->n_extern * (size_t)n * 24;
+    if (c->scratch_in.ensure((size_t)n * dim * 8) || c->ext.ensure(ext_bytes)) return 1;
+    HIPCHK(hipMemcpyAsync(c->scratch_in.p, h_pts, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    LAUNCH_TAPE(k_eval_points_ext, dim3(grid), dim3(256), 0, t, precision, (const double *)c->scratch_in.p, (long long)n, dim,
+                (double *)c->ext.p, 1, (double *)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_ext_pts, c->ext.p, ext_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// phase 2: f(P) with the closures' values (n_extern x n float64, leaf-major) supplied by the host
+int sdf_eval_points_extern_host(sdf_tape *t, const double *h_pts, int64_t n, int dim, const double *h_ext_vals, double *h_out,
+                                int precision) {
+    if (!t || !h_pts || !h_ext_vals || !h_out) return fail("sdf_eval_points_extern_host: NULL argument");
+    if (dim != 2 && dim != 3) return fail("sdf_eval_points_extern_host: dim must be 2 or 3");
+    if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_points_extern_host: bad precision");
+    if (!t->n_extern) return fail("sdf_eval_points_extern_host: the tape has no user closures");
+    if (n <= 0) return 0;
+    sdf_ctx *c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t ext_bytes = (size_t)t->n_extern * (size_t)n * 8;
+    if (c->scratch_in.ensure((size_t)n * dim * 8) || c->scratch_out.ensure((size_t)n * 8) || c->ext.ensure(ext_bytes)) return 1;
+    HIPCHK(hipMemcpyAsync(c->scratch_in.p, h_pts, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ext.p, h_ext_vals, ext_bytes, hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    LAUNCH_TAPE(k_eval_points_ext, dim3(grid), dim3(256), 0, t, precision, (const double *)c->scratch_in.p, (long long)n, dim,
+                (double *)c->ext.p, 0, (double *)c->scratch_out.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -804,8 +979,10 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
 }
 
 // the per-call statistics from the counters the meshing pass left (end of sdf_generate / sdf_mesh_wait)
-static int finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb, bool pruning, uint32_t n_instr, unsigned long long key,
-                        const CallSlot &cs) {
+extern "C" int sdf_mesh_wait(sdf_mesh *m, int *emitted);
+
+static void finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb, bool pruning, uint32_t n_instr, unsigned long long key,
+                         float ms_prepass, float ms_total) {
     m->work_begin = h.work_begin; m->work_end = h.work_end;
     m->st.n_skipped = nb - h.nwork;
     m->st.n_work_begin = m->work_begin; m->st.n_work_end = m->work_end;
@@ -817,21 +994,29 @@ static int finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb,
     m->pruned = pruning;
     m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, cs.e0, cs.e2));
-    m->st.ms_prepass = ms;
-    HIPCHK(hipEventElapsedTime(&ms, cs.e0, cs.e4));
-    m->st.ms_total = ms;
-    return 0;
+    m->st.ms_prepass = ms_prepass;
+    m->st.ms_total = ms_total;
 }
 
 static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
                          int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out,
                          bool async_mode = false) {
     sdf_ctx *c = t->ctx;
-    const int slot = (int)(c->slot_seq++ % SDF_CALL_SLOTS);
+    // a free call slot; when all are held by calls in flight, the oldest of them is COLLECTED first (its counters
+    // and event times live in the slot's pinned staging and events: reusing the slot before sdf_mesh_wait has
+    // read them would hand that mesh this call's numbers)
+    int slot = -1;
+    for (int k = 0; k < SDF_CALL_SLOTS && slot < 0; k++)
+        if (!c->slots[(c->slot_seq + (unsigned)k) % SDF_CALL_SLOTS].busy) slot = (int)((c->slot_seq + (unsigned)k) % SDF_CALL_SLOTS);
+    if (slot < 0) {
+        slot = (int)(c->slot_seq % SDF_CALL_SLOTS);
+        CallSlot &held = c->slots[slot];
+        if (held.owner && held.owner->pend.active) { if (sdf_mesh_wait(held.owner, nullptr)) return 1; }
+        else { HIPCHK(hipEventSynchronize(held.done)); }
+        held.busy = false; held.owner = nullptr;
+    }
+    c->slot_seq = (unsigned)slot + 1u;
     CallSlot &cs = c->slots[slot];
-    if (cs.busy) { HIPCHK(hipEventSynchronize(cs.done)); cs.busy = false; }     // (the call that held the slot is over)
     char *stage = (char *)c->h_stage + (size_t)slot * SDF_STAGE_BYTES;
     GridDesc &g = m->g;
     g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
@@ -960,6 +1145,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             HIPCHK(hipStreamSynchronize(c->stream));
             const unsigned long long nshard0 = (unsigned long long)std::max(h.work_end - h.work_begin, 1);
             cap = std::max<unsigned long long>(4096ull * nshard0, 1ull << 16);
+            // a guess, not a need (the overflow re-run finds the exact size): never more than half the free memory
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                cap = std::min<unsigned long long>(cap, std::max<unsigned long long>(free_b / 2 / 72, 1ull << 16));
         }
     }
     float ms = 0;
@@ -970,7 +1159,15 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         } else {
             if (!m->out.p && !c->arena_pool.empty()) { m->out = c->arena_pool.back(); c->arena_pool.pop_back(); }
             if (m->out.bytes < (size_t)cap * 72) quiet = false;     // (an allocation: the stream idles meanwhile)
-            if (m->out.ensure((size_t)cap * 72)) return 1;
+            if (m->out.ensure((size_t)cap * 72)) {
+                // a first-call guess that does not fit: shrink it and let the overflow re-run size the soup exactly
+                bool ok = false;
+                for (int k = 0; k < 6 && !ok && attempt == 0 && cap > (1ull << 16); k++) {
+                    cap = std::max<unsigned long long>(cap / 4, 1ull << 16);
+                    ok = m->out.ensure((size_t)cap * 72) == 0;
+                }
+                if (!ok) return 1;
+            }
             a.out = (double *)m->out.p; a.out_cap = m->out.bytes / 72;
         }
         if (attempt) {   // (the first pass finds both cleared by k_compact)
@@ -998,7 +1195,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         if (async_mode && attempt == 0) {   // the caller collects the result with sdf_mesh_wait
             HIPCHK(hipEventRecord(cs.done, c->stream));
-            cs.busy = true;
+            cs.busy = true; cs.owner = m;
             sdf_mesh::Pending &pd = m->pend;
             pd.active = true; pd.tape = t; pd.slot = slot; pd.nb = nb; pd.bs = bs; pd.sparse = sparse; pd.precision = precision;
             pd.pruning = pruning; pd.own_start = own_start; pd.n_instr = n_instr; pd.key = key;
@@ -1029,7 +1226,11 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         m->emitted_to = to_caller ? d_out : nullptr;
         break;
     }
-    return finish_stats(t, m, h, nb, pruning, n_instr, key, cs);
+    float ms_pre = 0, ms_tot = 0;
+    HIPCHK(hipEventElapsedTime(&ms_pre, cs.e0, cs.e2));
+    HIPCHK(hipEventElapsedTime(&ms_tot, cs.e0, cs.e4));
+    finish_stats(t, m, h, nb, pruning, n_instr, key, ms_pre, ms_tot);
+    return 0;
 }
 
 extern "C" {
@@ -1041,6 +1242,7 @@ static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y,
                           sdf_mesh **out, bool async_mode = false) {
     if (!t || !X || !Y || !Z || !out) return fail("sdf_generate: NULL argument");
     *out = nullptr;
+    if (t->n_extern) return fail("sdf_generate: the tape reads user closures (L_EXTERN): mesh it with sdf_generate_field");
     if (bs < 1 || bs > 32) return fail("sdf_generate: batch_size must be in 1..32 (the (batch_size+1)^3 float32 tile lives in LDS)");
     if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sdf_generate: bad shard");
     if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_generate: bad precision");
@@ -1081,6 +1283,160 @@ int sdf_generate_to_device_async(sdf_tape *t, const double *X, int nx, const dou
     return generate_entry(t, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_tris, out, true);
 }
 
+// The batch loop of `generate` (reference sdf/core.py:114-141) around a field that lives on the HOST: a user-written
+// closure (reference README.md:258-295, sdf/d3.py:48-63), possibly calling device-resident sub-models itself.  The
+// library does what the reference's `_skip` / `_worker` do around `sdf(P)`: it builds the points of the skip test and
+// of every surviving batch (`_cartesian_product`, first axis slowest), hands them to the callback, and meshes the
+// returned values on the device -- a chunk of batches per submission: float32 cast, marching cubes of all tiles,
+// one scan for the order, `points * scale + offset` into the ordered float64 soup.
+int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double *X, int nx, const double *Y, int ny,
+                       const double *Z, int nz, int bs, int sparse, int64_t shard_index, int64_t shard_count, sdf_mesh **out) {
+    if (!c || !field || !X || !Y || !Z || !out) return fail("sdf_generate_field: NULL argument");
+    *out = nullptr;
+    if (bs < 1 || bs > 32) return fail("sdf_generate_field: batch_size must be in 1..32");
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sdf_generate_field: bad shard");
+    if (nx < 0 || ny < 0 || nz < 0) return fail("sdf_generate_field: negative axis length");
+    HIPCHK(hipSetDevice(c->device));
+    sdf_mesh *m = new sdf_mesh();
+    m->ctx = c;
+    void *h_pts = nullptr, *h_vals = nullptr;
+    struct Guard {
+        sdf_mesh *&m; void *&a; void *&b;
+        ~Guard() { const std::string keep = g_err; if (a) sdf_host_free(a); if (b) sdf_host_free(b); if (m) sdf_mesh_destroy(m); g_err = keep; }
+    } guard{m, h_pts, h_vals};
+    GridDesc &g = m->g;
+    g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
+    g.nbx = (nx + bs - 1) / bs; g.nby = (ny + bs - 1) / bs; g.nbz = (nz + bs - 1) / bs;
+    const long long nb64 = (long long)g.nbx * g.nby * g.nbz;
+    if (nb64 > 0x7fffffffLL) return fail("sdf_generate_field: too many batches");
+    const int nb = (int)nb64;
+    m->st.n_batches = nb;
+    m->st.n_grid_voxels = (int64_t)nx * ny * nz;
+    if (nb == 0) { *out = m; m = nullptr; return 0; }
+    auto origin = [&](int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {   // (batch_origin, sdf_device.h)
+        const int ibz = b % g.nbz, iby = (b / g.nbz) % g.nby, ibx = b / (g.nbz * g.nby);
+        ox = ibx * bs; oy = iby * bs; oz = ibz * bs;
+        lx = std::min(bs + 1, nx - ox); ly = std::min(bs + 1, ny - oy); lz = std::min(bs + 1, nz - oz);
+    };
+    const size_t tile_max = (size_t)(bs + 1) * (bs + 1) * (bs + 1);
+    const int CH = 32;                                    // batches per submission
+    const size_t pts_cap = std::max<size_t>((size_t)CH * tile_max, (size_t)9 << 12);   // points per callback
+    if (sdf_host_alloc(pts_cap * 24, &h_pts) || sdf_host_alloc(pts_cap * 8, &h_vals)) return 1;
+    double *pts = (double *)h_pts, *vals = (double *)h_vals;
+    std::vector<uint8_t> kinds((size_t)nb, 255);
+
+    // ---- `_skip` (reference sdf/core.py:28-43): centre + the 8 corners of every batch through the field ----
+    if (sparse) {
+        const int per = (int)(pts_cap / 9);
+        for (int b0 = 0; b0 < nb; b0 += per) {
+            const int n = std::min(per, nb - b0);
+            for (int j = 0; j < n; j++) {
+                int ox, oy, oz, lx, ly, lz;
+                origin(b0 + j, ox, oy, oz, lx, ly, lz);
+                const double x0 = X[ox], x1 = X[ox + lx - 1], y0 = Y[oy], y1 = Y[oy + ly - 1], z0 = Z[oz], z1 = Z[oz + lz - 1];
+                double *p = pts + (size_t)j * 27;
+                p[0] = (x0 + x1) / 2; p[1] = (y0 + y1) / 2; p[2] = (z0 + z1) / 2;
+                for (int k = 0; k < 8; k++) {             // itertools.product((x0, x1), (y0, y1), (z0, z1))
+                    p[3 + 3 * k] = (k & 4) ? x1 : x0; p[4 + 3 * k] = (k & 2) ? y1 : y0; p[5 + 3 * k] = (k & 1) ? z1 : z0;
+                }
+            }
+            if (field(user, pts, (int64_t)n * 9, vals)) return fail("sdf_generate_field: the field callback failed");
+            for (int j = 0; j < n; j++) {
+                int ox, oy, oz, lx, ly, lz;
+                origin(b0 + j, ox, oy, oz, lx, ly, lz);
+                const double x0 = X[ox], y0 = Y[oy], z0 = Z[oz];
+                const double *p = pts + (size_t)j * 27, *v = vals + (size_t)j * 9;
+                const double r = fabs(v[0]);
+                const double d = sqrt(((p[0] - x0) * (p[0] - x0) + (p[1] - y0) * (p[1] - y0)) + (p[2] - z0) * (p[2] - z0));
+                bool same = true;
+                const bool pos = v[1] > 0.0;
+                for (int k = 1; k <= 8; k++) same = same && (pos ? v[k] > 0.0 : v[k] < 0.0);
+                kinds[(size_t)(b0 + j)] = (!(r <= d) && same) ? 0 : 255;
+            }
+        }
+    }
+    std::vector<int> work;
+    for (int b = 0; b < nb; b++) if (kinds[(size_t)b]) work.push_back(b);
+    const long long nwork = (long long)work.size();
+    const int w_begin = (int)((nwork * shard_index) / shard_count), w_end = (int)((nwork * (shard_index + 1)) / shard_count);
+    m->work_begin = w_begin; m->work_end = w_end;
+    m->st.n_skipped = nb - (int64_t)nwork;
+    m->st.n_work_begin = w_begin; m->st.n_work_end = w_end;
+
+    // ---- `_worker` for the shard's batches, CH at a time ----
+    std::vector<FieldTile> tiles((size_t)CH);
+    std::vector<unsigned long long> offs((size_t)CH * 1024 + 1);
+    unsigned long long total = 0;
+    for (int w0 = w_begin; w0 < w_end; w0 += CH) {
+        const int nt = std::min(CH, w_end - w0);
+        size_t npts = 0;
+        for (int j = 0; j < nt; j++) {
+            int ox, oy, oz, lx, ly, lz;
+            origin(work[(size_t)(w0 + j)], ox, oy, oz, lx, ly, lz);
+            FieldTile &tl = tiles[(size_t)j];
+            tl.vol_off = (long long)npts; tl.n0 = lx; tl.n1 = ly; tl.n2 = lz; tl.pad_ = 0;
+            // scale = the batch's first axis step (reference sdf/core.py:58-59: `X[1] - X[0]` of the batch's slices);
+            // a one-sample axis has none and the tile has no cells, so its value is never used
+            tl.of[0] = X[ox]; tl.of[1] = Y[oy]; tl.of[2] = Z[oz];
+            tl.sc[0] = lx > 1 ? X[ox + 1] - X[ox] : 0.0; tl.sc[1] = ly > 1 ? Y[oy + 1] - Y[oy] : 0.0; tl.sc[2] = lz > 1 ? Z[oz + 1] - Z[oz] : 0.0;
+            double *p = pts + npts * 3;
+            for (int ix = 0; ix < lx; ix++)
+                for (int iy = 0; iy < ly; iy++)
+                    for (int iz = 0; iz < lz; iz++, p += 3) { p[0] = X[ox + ix]; p[1] = Y[oy + iy]; p[2] = Z[oz + iz]; }
+            npts += (size_t)lx * ly * lz;
+            m->st.n_eval_voxels += (int64_t)lx * ly * lz;
+        }
+        if (field(user, pts, (int64_t)npts, vals)) return fail("sdf_generate_field: the field callback failed");
+        const size_t nslots = (size_t)nt * 1024;
+        if (c->field_vals.ensure(npts * 8) || c->field_vol.ensure(npts * 4) || c->field_tiles.ensure(sizeof(FieldTile) * CH) ||
+            c->rows.ensure(nslots * 4) || c->rows_off.ensure((nslots + 1) * 8))
+            return 1;
+        HIPCHK(hipMemcpyAsync(c->field_vals.p, vals, npts * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->field_tiles.p, tiles.data(), sizeof(FieldTile) * (size_t)nt, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_cast_f32, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->field_vals.p,
+                           (float *)c->field_vol.p, (long long)npts);
+        hipLaunchKernelGGL(k_field_rows, dim3(4, (unsigned)nt), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
+                           (const FieldTile *)c->field_tiles.p, (unsigned *)c->rows.p);
+        unsigned long long *d_total = (unsigned long long *)c->rows_off.p + nslots;
+        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)c->rows.p, (long long)nslots,
+                           (unsigned long long *)c->rows_off.p, d_total);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(offs.data(), c->rows_off.p, (nslots + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const unsigned long long chunk_total = offs[nslots];
+        for (int j = 0; j < nt; j++) {
+            const unsigned long long cnt = offs[(size_t)(j + 1) * 1024] - offs[(size_t)j * 1024];
+            kinds[(size_t)work[(size_t)(w0 + j)]] = cnt ? 2 : 1;
+            if (cnt) m->st.n_nonempty++; else m->st.n_empty++;
+        }
+        if (chunk_total) {
+            if ((total + chunk_total) * 72 > m->out.bytes) {       // grow the soup (geometric), keeping what is there
+                DevBuf bigger;
+                if (bigger.ensure(std::max<size_t>((size_t)(total + chunk_total) * 72 * 2, (size_t)1 << 22))) return 1;
+                if (total) HIPCHK(hipMemcpyAsync(bigger.p, m->out.p, (size_t)total * 72, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                m->out.release();
+                m->out = bigger;
+            }
+            hipLaunchKernelGGL(k_field_emit, dim3(4, (unsigned)nt), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
+                               (const FieldTile *)c->field_tiles.p, (const unsigned long long *)c->rows_off.p, (double *)m->out.p, total,
+                               (unsigned long long)(m->out.bytes / 72));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));   // (the chunk's buffers are refilled next)
+            total += chunk_total;
+        }
+    }
+    m->st.n_triangles = (int64_t)total;
+    m->st.n_sampled_voxels = m->st.n_eval_voxels;
+    if (m->kinds.ensure((size_t)nb)) return 1;
+    // (work items of other shards stay 255 = "other shard", like sdf_generate)
+    HIPCHK(hipMemcpyAsync(m->kinds.p, kinds.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = m;
+    m = nullptr;
+    return 0;
+}
+
 int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
     if (!m) return fail("sdf_mesh_wait: NULL argument");
     sdf_mesh::Pending &pd = m->pend;
@@ -1089,11 +1445,14 @@ int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
         HIPCHK(hipSetDevice(c->device));
         CallSlot &cs = c->slots[pd.slot];
         HIPCHK(hipEventSynchronize(cs.done));
-        cs.busy = false; pd.active = false;
+        pd.active = false;
         const MeshCounters h = *(const MeshCounters *)((char *)c->h_stage + (size_t)pd.slot * SDF_STAGE_BYTES + SDF_STAGE_BYTES - 256);
-        float ms = 0;
+        float ms = 0, ms_pre = 0, ms_tot = 0;
         HIPCHK(hipEventElapsedTime(&ms, pd.own_start ? cs.e3 : cs.e2, cs.e4));
+        HIPCHK(hipEventElapsedTime(&ms_pre, cs.e0, cs.e2));
+        HIPCHK(hipEventElapsedTime(&ms_tot, cs.e0, cs.e4));
         m->st.ms_mesh = ms;
+        cs.busy = false; cs.owner = nullptr;      // (everything the slot held for this mesh has been read)
         if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
         if (h.overflow) {
             // the soup did not fit the caller's buffer: the call is repeated synchronously into library memory
@@ -1107,7 +1466,7 @@ int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
         } else {
             m->emitted_to = pd.d_out;
             m->st.n_retries = 0;
-            if (finish_stats(pd.tape, m, h, pd.nb, pd.pruning, pd.n_instr, pd.key, cs)) return 1;
+            finish_stats(pd.tape, m, h, pd.nb, pd.pruning, pd.n_instr, pd.key, ms_pre, ms_tot);
         }
         pd.axes.clear(); pd.axes.shrink_to_fit();
     }
@@ -1157,6 +1516,46 @@ int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) {
     HIPCHK(hipSetDevice(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, mesh_soup(m), (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToHost, m->ctx->stream));
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
+int sdf_mesh_emit_host_range(sdf_mesh *m, int64_t first_tri, int64_t n_tris, double *h_out) {
+    if (!m || !h_out) return fail("sdf_mesh_emit_host_range: NULL argument");
+    MESH_READY(m);
+    if (first_tri < 0 || n_tris < 0 || first_tri + n_tris > m->st.n_triangles) return fail("sdf_mesh_emit_host_range: range outside the soup");
+    if (n_tris == 0) return 0;
+    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(hipMemcpyAsync(h_out, (const char *)mesh_soup(m) + (size_t)first_tri * 72, (size_t)n_tris * 72, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
+// Where each batch's triangles sit in this shard's soup: after k_mesh every work item's look-back word holds
+// the inclusive prefix of the triangle counts up to and including it (ordered_base / publish_count).
+int sdf_mesh_batch_offsets(sdf_mesh *m, int64_t *h_out) {
+    if (!m || !h_out) return fail("sdf_mesh_batch_offsets: NULL argument");
+    MESH_READY(m);
+    const int64_t nb = m->st.n_batches;
+    for (int64_t b = 0; b <= nb; b++) h_out[b] = 0;
+    const int nw = m->work_end - m->work_begin;
+    if (nb == 0 || nw <= 0) return 0;
+    if (!m->status.p || !m->worklist.p) return fail("sdf_mesh_batch_offsets: this mesh was not produced by sdf_generate");
+    HIPCHK(hipSetDevice(m->ctx->device));
+    std::vector<int> wl((size_t)nw);
+    std::vector<unsigned long long> stw((size_t)nw);
+    HIPCHK(hipMemcpyAsync(wl.data(), (const int *)m->worklist.p + m->work_begin, (size_t)nw * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipMemcpyAsync(stw.data(), (const unsigned long long *)m->status.p + m->work_begin, (size_t)nw * 8, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    // h_out[b + 1] = triangles of batch b for now; the running sum follows
+    unsigned long long prev = 0;
+    for (int i = 0; i < nw; i++) {
+        if ((stw[(size_t)i] >> 62) != 2ull) return fail("sdf_mesh_batch_offsets: a work item has no prefix (the meshing pass did not complete)");
+        const unsigned long long incl = stw[(size_t)i] & MESH_VAL_MASK;
+        if (incl < prev || wl[(size_t)i] < 0 || wl[(size_t)i] >= nb) return fail("sdf_mesh_batch_offsets: inconsistent look-back words");
+        h_out[wl[(size_t)i] + 1] = (int64_t)(incl - prev);
+        prev = incl;
+    }
+    for (int64_t b = 0; b < nb; b++) h_out[b + 1] += h_out[b];
     return 0;
 }
 
@@ -1299,7 +1698,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
     sdf_ctx *c = m->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (m->pend.active) { c->slots[m->pend.slot].busy = false; m->pend.active = false; }   // (abandoned; the stream is idle now)
+    if (m->pend.active) { c->slots[m->pend.slot].busy = false; c->slots[m->pend.slot].owner = nullptr; m->pend.active = false; }   // (abandoned; the stream is idle now)
     if (m->out.p) {   // keep one soup buffer around for the next call
         if (c->arena_pool.empty()) c->arena_pool.push_back(m->out);
         else if (c->arena_pool.back().bytes < m->out.bytes) { c->arena_pool.back().release(); c->arena_pool.back() = m->out; }

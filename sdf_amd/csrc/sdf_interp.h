@@ -278,12 +278,25 @@ template <typename V> SDF_DEV V box_like(const V &qx, const V &qy, const V &qz) 
 #define SDF_JT_ROW(NAME) "s_branch %l[L_" #NAME "]\n\t"
 #define SDF_JT_LABEL(NAME) L_##NAME,
 
+// User closures (L_EXTERN leaves, reference README.md:258-295): the values of a closure at the leaf's points
+// are computed on the host by the user's own code.  A kernel that supports them passes an ExtIO: in `dump`
+// mode the leaf stores its current point (the host then calls the closure on those points), in read mode it
+// takes the closure's value from the buffer.  Every other kernel passes NoExt and the leaf yields NaN (the
+// host never launches those kernels with a tape that has such leaves).
+struct NoExt { static constexpr bool enabled = false; };
+struct ExtIO {
+    static constexpr bool enabled = true;
+    double *buf;          // dump: [leaf][sample][3] points; read: [leaf][sample] values
+    long long n, i;       // samples in the launch, this lane's sample
+    bool dump;
+};
+
 // Run the whole tape for NS samples per lane.  FULL=false builds leave out the ops that need
 // sin/cos/atan2/hypot/fmod/pow (their ocml bodies cost registers); NP / ND are the register-file
 // sizes; the host picks the variant from the opcodes and slot counts of the tape.
-template <typename T, bool FULL, int NP, int ND, int NS>
+template <typename T, bool FULL, int NP, int ND, int NS, typename EXT = NoExt>
 __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code, const T *__restrict__ consts,
-                                               Vec<T, NS> x, Vec<T, NS> y, Vec<T, NS> z) {
+                                               Vec<T, NS> x, Vec<T, NS> y, Vec<T, NS> z, EXT ext = EXT()) {
     typedef Vec<T, NS> V;
     V acc(T(0));
     RegFile<V, NP> PSx, PSy, PSz;
@@ -536,6 +549,62 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const V q = len2(np_max(qx, T(0)), np_max(qy, T(0))) + np_min(np_max(qx, qy), T(0));
             const Mask<NS> outside = (ti < T(0)) | (ti >= (T)(tw - 1)) | (tj < T(0)) | (tj >= (T)(th - 1));
             v = vsel(outside, q, d); goto fold; }
+        L_L_GRID3D: {  // mesh.py:96-105: np.where(e > background, e, interpolator(p)), scipy RegularGridInterpolator
+            // (linear, bounds_error=False, fill_value=background) over float32 voxels, e = box(a, b)
+            // c: nx ny nz | background | box centre (3) | box half size (3) | X[nx] Y[ny] Z[nz] | A[nx][ny][nz]
+            const int n0 = (int)c[0], n1 = (int)c[1], n2 = (int)c[2];
+            const T bg = c[3];
+            const T *gx = c + 10, *gy = gx + n0, *gz = gy + n1, *vox = gz + n2;
+            const V e = box_like(m_fabs(x - c[4]) - c[7], m_fabs(y - c[5]) - c[8], m_fabs(z - c[6]) - c[9]);   // d3.py:122-134
+            V d;
+            SDF_UNROLL
+            for (int k = 0; k < NS; k++) {
+                const T p[3] = {x.v[k], y.v[k], z.v[k]};
+                const T *g[3] = {gx, gy, gz};
+                const int n[3] = {n0, n1, n2};
+                int idx[3];
+                T w[3];
+                bool oob = false;
+                SDF_UNROLL
+                for (int a = 0; a < 3; a++) {   // _find_indices: np.searchsorted(grid, x) - 1, clipped to [0, n - 2]
+                    int lo = 0, hi = n[a];
+                    while (lo < hi) {           // (side='left'; NaN sorts behind everything, like NumPy)
+                        const int mid = (lo + hi) >> 1;
+                        const T gm = g[a][mid];
+                        if (gm < p[a] || (p[a] != p[a] && gm == gm)) lo = mid + 1; else hi = mid;
+                    }
+                    const int i = min(max(lo - 1, 0), n[a] - 2);
+                    idx[a] = i;
+                    w[a] = (p[a] - g[a][i]) / (g[a][i + 1] - g[a][i]);
+                    oob = oob || p[a] < g[a][0] || p[a] > g[a][n[a] - 1];
+                }
+                T acc8 = T(0);                  // _evaluate_linear: edges in itertools.product order, weight = ((1 * wx) * wy) * wz
+                SDF_UNROLL
+                for (int q = 0; q < 8; q++) {
+                    const int o0 = q >> 2, o1 = (q >> 1) & 1, o2 = q & 1;
+                    T wt = o0 ? w[0] : T(1) - w[0];
+                    wt = wt * (o1 ? w[1] : T(1) - w[1]);
+                    wt = wt * (o2 ? w[2] : T(1) - w[2]);
+                    acc8 = acc8 + vox[((size_t)(idx[0] + o0) * n1 + (idx[1] + o1)) * n2 + (idx[2] + o2)] * wt;
+                }
+                d.v[k] = oob ? bg : acc8;
+            }
+            v = vsel(e > bg, e, d); goto fold; }
+        L_L_EXTERN: {  // a user closure: its value at this leaf's point comes from the host (ExtIO)
+            if constexpr (EXT::enabled) {
+                static_assert(NS == 1, "extern leaves: one sample per lane");
+                const long long k = (long long)c[0];
+                if (ext.dump) {
+                    double *o = ext.buf + (k * ext.n + ext.i) * 3;
+                    o[0] = (double)x.v[0]; o[1] = (double)y.v[0]; o[2] = (double)z.v[0];
+                    v = V(T(0));
+                } else {
+                    v = V((T)ext.buf[k * ext.n + ext.i]);
+                }
+            } else {
+                v = V(T(__builtin_nan("")));
+            }
+            goto fold; }
         // ---------------- fold a parked distance ----------------
         L_COMB: { V d1; DGET(d1, sa); acc = post_combine(post, d1, acc, c[-1]); goto next; }
         // ---------------- point ops ----------------
@@ -679,6 +748,11 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
 template <typename T, bool FULL>
 __device__ __forceinline__ T run_tape1(const uint32_t *__restrict__ code, const T *__restrict__ consts, T x, T y, T z) {
     return run_tape<T, FULL, SDF_NP_SLOTS, SDF_ND_SLOTS, 1>(code, consts, Vec<T, 1>(x), Vec<T, 1>(y), Vec<T, 1>(z)).v[0];
+}
+// the same with user closures (L_EXTERN leaves) served from / dumped to a buffer
+template <typename T, bool FULL>
+__device__ __forceinline__ T run_tape1_ext(const uint32_t *__restrict__ code, const T *__restrict__ consts, T x, T y, T z, ExtIO io) {
+    return run_tape<T, FULL, SDF_NP_SLOTS, SDF_ND_SLOTS, 1, ExtIO>(code, consts, Vec<T, 1>(x), Vec<T, 1>(y), Vec<T, 1>(z), io).v[0];
 }
 
 }  // namespace sdfk

@@ -289,6 +289,7 @@ __host__ __device__ inline bool ia_has_form(uint32_t op) {
     case OP_L_WIREFRAME_BOX: case OP_L_CAPPED_CYLINDER: case OP_L_ROUNDED_CONE: case OP_L_ELLIPSOID: case OP_L_TETRAHEDRON:
     case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: case OP_L_ROUNDED_RECTANGLE: case OP_L_EQUILATERAL_TRIANGLE: case OP_L_HEXAGON:
     case OP_L_ROUNDED_X: case OP_L_VESICA: case OP_L_CAPPED_CONE: case OP_L_PYRAMID: case OP_L_POLYGON: case OP_L_TEXTURE2D:
+    case OP_L_GRID3D:
     case OP_COMB: case OP_TRANSLATE: case OP_SCALE: case OP_ROTATE: case OP_ELONGATE: case OP_TRANSLATE2: case OP_SCALE2:
     case OP_ROTATE2: case OP_ELONGATE2: case OP_REVOLVE: case OP_SETZ0: case OP_SAVE_P: case OP_LOAD_P: case OP_PUSH_D: case OP_NOP:
     case OP_NEG: case OP_ADDC: case OP_SUBC: case OP_MULC: case OP_SHELL: case OP_ADD_DS: case OP_EXT_PRE: case OP_EXT_POST:
@@ -348,6 +349,7 @@ SDF_IA bool ia_is_rare_leaf(uint32_t op) {
     case OP_L_WIREFRAME_BOX: case OP_L_CAPPED_CYLINDER: case OP_L_ROUNDED_CONE: case OP_L_ELLIPSOID: case OP_L_TETRAHEDRON:
     case OP_L_DODECAHEDRON: case OP_L_ICOSAHEDRON: case OP_L_ROUNDED_RECTANGLE: case OP_L_EQUILATERAL_TRIANGLE: case OP_L_HEXAGON:
     case OP_L_ROUNDED_X: case OP_L_VESICA: case OP_L_CAPPED_CONE: case OP_L_PYRAMID: case OP_L_POLYGON: case OP_L_TEXTURE2D:
+    case OP_L_GRID3D:
         return true;
     default: return false;
     }
@@ -528,6 +530,46 @@ __host__ __device__ __attribute__((noinline)) inline Ival ia_leaf_rare(uint32_t 
         const Ival d = pad(Ival{lo, hi}, 1e-12, 1e-300);
         const bool all_inside = ti.lo >= 0.0 && ti.hi < wi && tj.lo >= 0.0 && tj.hi < hj;
         return all_inside ? d : hull(d, q);
+    }
+    case OP_L_GRID3D: {        // mesh.py:96-105: the box estimator beyond `background`, else the trilinear look-up
+        // c: nx ny nz | background | box centre (3) | box half size (3) | X[nx] Y[ny] Z[nz] | A[nx][ny][nz]
+        const int n[3] = {(int)c[0], (int)c[1], (int)c[2]};
+        const double bg = c[3];
+        if (n[0] < 2 || n[1] < 2 || n[2] < 2 || bad(x) || bad(y) || bad(z) || !(bg == bg)) return top();
+        const Ival e = ia_box_like(subc(abs_(subc(x, c[4])), c[7]), subc(abs_(subc(y, c[5])), c[8]), subc(abs_(subc(z, c[6])), c[9]));
+        if (bad(e)) return top();
+        if (e.lo > bg) return e;                              // the estimator wins at every point of the box
+        // the voxels a point of the box can interpolate between: per axis, cells searchsorted(lo) - 1 .. searchsorted(hi) - 1
+        const double *g[3] = {c + 10, c + 10 + n[0], c + 10 + n[0] + n[1]};
+        const double *vox = c + 10 + n[0] + n[1] + n[2];
+        const Ival *pv[3] = {&x, &y, &z};
+        int i0[3], i1[3];
+        bool oob = false;
+        for (int a = 0; a < 3; a++) {
+            const double plo = pv[a]->lo, phi = pv[a]->hi;
+            int lo = 0, hi = n[a];
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (g[a][mid] < plo) lo = mid + 1; else hi = mid; }
+            i0[a] = lo - 1 < 0 ? 0 : (lo - 1 > n[a] - 2 ? n[a] - 2 : lo - 1);
+            lo = 0; hi = n[a];
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (g[a][mid] < phi) lo = mid + 1; else hi = mid; }
+            i1[a] = (lo - 1 < 0 ? 0 : (lo - 1 > n[a] - 2 ? n[a] - 2 : lo - 1)) + 1;
+            oob = oob || plo < g[a][0] || phi > g[a][n[a] - 1];
+        }
+        if ((long long)(i1[0] - i0[0] + 1) * (long long)(i1[1] - i0[1] + 1) * (long long)(i1[2] - i0[2] + 1) > 4096) return top();
+        double lo = __builtin_inf(), hi = -__builtin_inf();
+        for (int i = i0[0]; i <= i1[0]; i++)
+            for (int j = i0[1]; j <= i1[1]; j++)
+                for (int k = i0[2]; k <= i1[2]; k++) {
+                    const double p = vox[((size_t)i * n[1] + j) * n[2] + k];
+                    if (p != p) return top();
+                    lo = fmin(lo, p); hi = fmax(hi, p);
+                }
+        if (!(lo <= hi)) return top();
+        // inside the grid the eight weights lie in [0, 1] and add up to 1 (to a few roundings): a convex combination
+        // of the reachable voxels; outside it the fill value
+        Ival d = pad(Ival{lo, hi}, 1e-12, 1e-300);
+        if (oob) d = hull(d, pt(bg));
+        return e.hi <= bg ? d : hull(e, d);
     }
     case OP_L_POLYGON: {       // d2.py:175-196
         const int np_ = (int)c[0];

@@ -42,7 +42,7 @@ class SdfStats(ctypes.Structure):
     ]
 
 
-# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+# name -> (restype, argtypes); this table is also what tests/test_host.py checks against the header
 ABI = {
     'sdf_abi_version': (ctypes.c_int, []),
     'sdf_last_error': (ctypes.c_char_p, []),
@@ -62,6 +62,11 @@ ABI = {
     'sdf_eval_points_host': (ctypes.c_int, [_vp, _f64p, _c_i64, ctypes.c_int, _f64p, ctypes.c_int]),
     'sdf_eval_grid_host': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p,
                                           ctypes.c_int, _f64p, ctypes.c_int]),
+    'sdf_tape_extern_count': (ctypes.c_int, [_vp]),
+    'sdf_eval_extern_points_host': (ctypes.c_int, [_vp, _f64p, _c_i64, ctypes.c_int, _f64p, ctypes.c_int]),
+    'sdf_eval_points_extern_host': (ctypes.c_int, [_vp, _f64p, _c_i64, ctypes.c_int, _f64p, _f64p, ctypes.c_int]),
+    'sdf_generate_field': (ctypes.c_int, [_vp, _vp, _vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.POINTER(_vp)]),
     'sdf_marching_cubes': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp,
                                           _c_i64, ctypes.POINTER(_c_i64)]),
     'sdf_marching_cubes_host': (ctypes.c_int, [_vp, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -80,6 +85,8 @@ ABI = {
     'sdf_mesh_triangles': (_c_i64, [_vp]),
     'sdf_mesh_emit_device': (ctypes.c_int, [_vp, _vp]),
     'sdf_mesh_emit_host': (ctypes.c_int, [_vp, _f64p]),
+    'sdf_mesh_emit_host_range': (ctypes.c_int, [_vp, _c_i64, _c_i64, _f64p]),
+    'sdf_mesh_batch_offsets': (ctypes.c_int, [_vp, ctypes.POINTER(_c_i64)]),
     'sdf_mesh_emit_stl_host': (ctypes.c_int, [_vp, _vp]),
     'sdf_mesh_weld': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     'sdf_mesh_weld_fetch': (ctypes.c_int, [_vp, _f64p, ctypes.POINTER(ctypes.c_int64)]),
@@ -97,6 +104,19 @@ _lib_lock = threading.Lock()
 
 class SdfHipError(RuntimeError):
     pass
+
+
+# `sdf_field_fn` of include/sdf_hip.h
+FIELD_FN = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _f64p, _c_i64, _f64p)
+
+
+def call_closure(fn, P):
+    """a user closure on (N, d) points -> (N,) float64: the contract of a function decorated with the
+    reference's @sdf3 / @op3 (reference README.md:258-295: returns (N,) or (N, 1))"""
+    v = np.asarray(fn(P), dtype=np.float64).reshape(-1)
+    if v.shape[0] != len(P):
+        raise ValueError('a user SDF returned %d values for %d points' % (v.shape[0], len(P)))
+    return v
 
 
 def load_library(path=None):
@@ -232,6 +252,22 @@ class Mesh:
             _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_host(self.handle, _dp(out, _f64p)))
         return out
 
+    def points_range(self, first_tri, n_tris):
+        """rows of triangles [first_tri, first_tri + n_tris) of the soup: (3 * n_tris, 3) float64"""
+        out = pinned_empty(self.engine.lib, (3 * int(n_tris), 3), np.float64)
+        if n_tris:
+            _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_host_range(self.handle, int(first_tri), int(n_tris),
+                                                                             _dp(out, _f64p)))
+        return out
+
+    def batch_offsets(self):
+        """(n_batches + 1,) int64: where each batch's triangles start in this shard's soup (reference
+        batch order; equal neighbours = the batch contributed nothing)"""
+        n = self.stats()['n_batches']
+        out = np.zeros(n + 1, np.int64)
+        _check(self.engine.lib, self.engine.lib.sdf_mesh_batch_offsets(self.handle, _dp(out, ctypes.POINTER(_c_i64))))
+        return out
+
     def emit_device(self, device_ptr):
         """write the (3T,3) float64 soup into caller-owned device memory (e.g. a torch tensor)"""
         _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_device(self.handle, _vp(device_ptr)))
@@ -298,7 +334,7 @@ class Engine:
         if isinstance(sdf, DeviceTape):
             return sdf
         t = sdf if isinstance(sdf, _tape.Tape) else _tape.lower(sdf)
-        key = (t.code.tobytes(), t.consts.tobytes())
+        key = (t.code.tobytes(), t.consts.tobytes(), tuple(id(fn) for fn, _ in t.externs))
         dt = self._tapes.get(key)
         if dt is None:
             dt = DeviceTape(self, t)
@@ -311,15 +347,41 @@ class Engine:
         pts = np.ascontiguousarray(pts, dtype=np.float64)
         if pts.ndim != 2 or pts.shape[1] not in (2, 3):
             raise ValueError('points must be (N,2) or (N,3)')
+        if dt.tape.externs:
+            return self._eval_points_hybrid(dt, pts)
         out = np.empty(len(pts), np.float64)
         if len(pts):
             _check(self.lib, self.lib.sdf_eval_points_host(dt.handle, _dp(pts, _f64p), len(pts), pts.shape[1],
                                                            _dp(out, _f64p), self.precision))
         return out
 
+    def _eval_points_hybrid(self, dt, pts):
+        """f(P) of a model that contains user closures (`extern` leaves): the device runs the tape twice --
+        first to find the point every closure is asked at (its argument after the transforms above it), then,
+        with the closures' values (computed here, by the user's own NumPy code), for the result"""
+        ext = dt.tape.externs
+        n, dim = pts.shape
+        if n == 0:
+            return np.empty(0, np.float64)
+        if dt.tape.n_instr == 2:          # the model IS one closure: nothing for the device to do
+            return call_closure(ext[0][0], pts.copy())
+        epts = np.empty((len(ext), n, 3), np.float64)
+        _check(self.lib, self.lib.sdf_eval_extern_points_host(dt.handle, _dp(pts, _f64p), n, dim, _dp(epts, _f64p),
+                                                              self.precision))
+        vals = np.empty((len(ext), n), np.float64)
+        for k, (fn, d) in enumerate(ext):
+            vals[k] = call_closure(fn, np.ascontiguousarray(epts[k, :, :d]))
+        out = np.empty(n, np.float64)
+        _check(self.lib, self.lib.sdf_eval_points_extern_host(dt.handle, _dp(pts, _f64p), n, dim, _dp(vals, _f64p),
+                                                              _dp(out, _f64p), self.precision))
+        return out
+
     def eval_grid(self, sdf, X, Y, Z):
         dt = self.tape_for(sdf)
         X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
+        if dt.tape.externs:
+            G = np.stack(np.meshgrid(X, Y, Z, indexing='ij'), axis=-1).reshape(-1, 3)
+            return self._eval_points_hybrid(dt, np.ascontiguousarray(G)).reshape(len(X), len(Y), len(Z))
         out = np.empty((len(X), len(Y), len(Z)), np.float64)
         if out.size:
             _check(self.lib, self.lib.sdf_eval_grid_host(dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y),
@@ -355,6 +417,11 @@ class Engine:
         X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
         h = _vp()
         emitted = ctypes.c_int(0)
+        if dt.tape.externs:
+            if out_ptr or not wait:
+                raise ValueError('a model with user closures is meshed through the host callback path: no output '
+                                 'buffer, no asynchronous submission')
+            return self._generate_field(dt, X, Y, Z, batch_size, sparse, shard)
         if not wait:
             if not out_ptr:
                 raise ValueError('generate(wait=False) needs an output buffer (out_ptr / out_cap)')
@@ -378,6 +445,34 @@ class Engine:
         m = Mesh(self, h)
         m._tape = dt          # keep the device tape alive as long as the mesh
         m.emitted = bool(emitted.value)
+        return m
+
+
+    def _generate_field(self, dt, X, Y, Z, batch_size, sparse, shard):
+        """`generate` for a model with user closures: the library drives the reference's batch loop and asks
+        this callback for f(P) of the skip test and of every surviving batch (sdf_generate_field)"""
+        failure = []
+
+        def field(_user, p_pts, n, p_out):
+            try:
+                P = np.ctypeslib.as_array(p_pts, shape=(n, 3))
+                np.ctypeslib.as_array(p_out, shape=(n,))[:] = self._eval_points_hybrid(dt, P)
+                return 0
+            except BaseException as e:      # (an exception cannot cross the C frames: it is re-raised below)
+                failure.append(e)
+                return 1
+
+        cb = FIELD_FN(field)
+        h = _vp()
+        rc = self.lib.sdf_generate_field(self.ctx, ctypes.cast(cb, _vp), None, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y),
+                                         _dp(Z, _f64p), len(Z), int(batch_size), 1 if sparse else 0, int(shard[0]),
+                                         int(shard[1]), ctypes.byref(h))
+        if failure:
+            raise failure[0]
+        _check(self.lib, rc)
+        m = Mesh(self, h)
+        m._tape = dt
+        m.emitted = False
         return m
 
 

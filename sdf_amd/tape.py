@@ -37,7 +37,7 @@ _LEAVES = [
     'capped_cylinder', 'rounded_cylinder', 'capped_cone', 'rounded_cone', 'ellipsoid',
     'pyramid', 'tetrahedron', 'octahedron', 'dodecahedron', 'icosahedron',
     'circle', 'line', 'rectangle', 'rounded_rectangle', 'equilateral_triangle', 'hexagon',
-    'rounded_x', 'polygon', 'vesica', 'texture2d',
+    'rounded_x', 'polygon', 'vesica', 'texture2d', 'grid3d', 'extern',
 ]
 _MACHINE = (
     ['END'] + ['L_' + n.upper() for n in _LEAVES] + [
@@ -74,6 +74,8 @@ RL_FLAG, RL_SHIFT = 1 << 11, 12
 SV_FLAG, SV_SHIFT = 1 << 15, 16
 PD_FLAG, PD_SHIFT = 1 << 19, 20
 PREFIX_MASK = 0x00FFF800
+
+PRUNE_MAX_INSTR = 256     # csrc/sdf_hip.hip generate_impl: `pruning` needs n_instr <= 256
 
 # hard limits of the default kernel build (csrc/sdf_interp.h NP_SLOTS / ND_SLOTS)
 MAX_P_SLOTS = 8
@@ -116,6 +118,9 @@ class Tape:
         self.n_dslots = n_dslots
         self.dim = dim
         self.rstart = self.lstart = None
+        # user closures the tape reads through its L_EXTERN leaves: [(callable, dimension of its points)],
+        # leaf k of the tape = entry k
+        self.externs = []
 
     @property
     def n_instr(self):
@@ -171,6 +176,7 @@ class _Lowering:
         # instructions to skip (csrc/sdf_prune.h)
         self.meta = []
         self.chain = []               # stack: index of the first instruction of the enclosing chain
+        self.externs = []             # user closures, in leaf order
 
     # -- emission helpers --
     def emit(self, op, post='SET', a=0, b=0, consts=(), K=0.0, blob=None):
@@ -179,7 +185,10 @@ class _Lowering:
         self.consts.extend(float(c) for c in consts)
         if blob is not None:          # bulk constants (a sampled field) behind the parameters
             self.consts.frombytes(np.ascontiguousarray(blob, dtype=np.float64).tobytes())
-        assert 0 <= a < 256 and 0 <= b < 256 and off <= COFF_MASK
+        assert 0 <= a < 256 and 0 <= b < 256
+        if len(self.consts) > COFF_MASK:
+            raise ValueError('model needs more than %d float64 constants (sampled fields included): the tape '
+                             'addresses its constant pool with 24 bits' % COFF_MASK)
         self.code.append(OP[op] | (POST[post] << 8) | (a << A_SHIFT))
         self.code.append(off | (b << B_SHIFT))
         self.meta.append(None)
@@ -264,6 +273,11 @@ class _Lowering:
         if n.dim and n.dim != dim:
             raise TypeError('%s is a %d-D node used on %d-D points' % (op, n.dim, dim))
         leaf = 'L_' + op.upper()
+        if op == 'extern':            # a user closure: the device reads its value at this leaf's point from a buffer
+            self.emit(leaf, post, consts=[len(self.externs)], K=K)
+            self.externs.append((n.meta['fn'], dim))
+            self.note_combine(post, _rs)
+            return False
         if leaf in OP:
             self.emit(leaf, post, consts=n.params, K=K, blob=(n.meta or {}).get('blob'))
             self.note_combine(post, _rs)
@@ -559,6 +573,9 @@ def lower(obj, dim=None):
     t = Tape(np.array(code, dtype=np.uint32), np.frombuffer(lw.consts, dtype=np.float64).copy(), n_p, n_d, dim)
     # per instruction: first instruction of the right operand / of the left chain (0xFFFF: not a
     # prunable combine) -- input of the interval prepass
-    t.rstart = np.array([0xFFFF if m is None else m[0] for m in meta], dtype=np.uint16)
-    t.lstart = np.array([0xFFFF if m is None else m[1] for m in meta], dtype=np.uint16)
+    # (the prepass handles tapes of up to PRUNE_MAX_INSTR instructions; longer ones carry no ranges and run unpruned)
+    t.externs = list(lw.externs)
+    if t.n_instr <= PRUNE_MAX_INSTR and not t.externs:
+        t.rstart = np.array([0xFFFF if m is None else m[0] for m in meta], dtype=np.uint16)
+        t.lstart = np.array([0xFFFF if m is None else m[1] for m in meta], dtype=np.uint16)
     return t

@@ -179,8 +179,74 @@ for _e in EASINGS:
         "f = capsule(-Z * 2, Z * 2, 0.25).bend_linear(-Z, Z, X, ease.%s)" % _e)
 
 
+# ---- user-written SDFs: the reference's documented extension point (reference README.md:258-295,
+# sdf/d3.py:48-63).  The same user code runs against the reference (tools/make_golden_custom.py) and
+# against the implementation under test; the first two closures are the README's own examples. ----
+_CUSTOM_PRELUDE = """
+@sdf3
+def my_sphere(radius=1, center=ORIGIN):
+    def f(p):
+        return np.linalg.norm(p - center, axis=1) - radius
+    return f
+
+@op3
+def my_translate(other, offset):
+    def f(p):
+        return other(p - offset)
+    return f
+
+@sdf3
+def my_gyroid(scale, thickness):
+    def f(p):
+        q = p * scale
+        g = np.sin(q[:, 0]) * np.cos(q[:, 1]) + np.sin(q[:, 1]) * np.cos(q[:, 2]) + np.sin(q[:, 2]) * np.cos(q[:, 0])
+        return (np.abs(g) - thickness).reshape((-1, 1)) / scale
+    return f
+
+@sdf2
+def my_circle(radius):
+    def f(p):
+        return np.sqrt(p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) - radius
+    return f
+
+@op3
+def my_mirror_x(other):
+    def f(p):
+        q = p.copy()
+        q[:, 0] = np.abs(q[:, 0])
+        return other(q)
+    return f
+"""
+
+CUSTOM_FIXTURES = {
+    # the README's two examples, alone: the whole model is user code
+    'custom_readme': "f = my_sphere(1).my_translate((0.25, -0.5, 0.125))",
+    # a user leaf under library operators (the canonical example with the README's sphere)
+    'custom_leaf_in_example': """
+f = my_sphere(1) & box(1.5)
+c = cylinder(0.5)
+f -= c.orient(X) | c.orient(Y) | c.orient(Z)
+""",
+    # a user operator around a library model, library operators around that
+    'custom_op_over_library': EXAMPLE + "f = f.my_translate((0.1, 0.2, -0.15)).rotate(pi / 5, X) | sphere(0.3).translate((0, 0, 0.9)).k(0.1)\n",
+    # user leaves under transforms, smooth booleans and repeat; two closures, one of them used twice
+    'custom_under_transforms': """
+s = my_sphere(0.4)
+f = s.translate((0.5, 0, 0)) | s.translate((-0.5, 0, 0)).scale(1.25).k(0.2)
+f = f.rotate(0.3, Z) & my_gyroid(9.0, 0.35).translate((0.1, 0.1, 0.1))
+""",
+    # a user 2-D leaf through extrude, a user operator over a user leaf over a library leaf
+    'custom_2d_and_nested': """
+f = my_circle(0.6).extrude(0.5) - capsule(-Z, Z, 0.25)
+f = f | box((0.5, 0.3, 0.3)).translate((0.8, 0, 0)).my_mirror_x().k(0.05)
+""",
+}
+for _k in CUSTOM_FIXTURES:
+    CUSTOM_FIXTURES[_k] = _CUSTOM_PRELUDE + CUSTOM_FIXTURES[_k]
+
+
 def build(name, namespace):
     """exec the fixture program in a copy of `namespace` and return its ``f``."""
     ns = dict(namespace)
-    exec(FIXTURES[name], ns)
+    exec(FIXTURES[name] if name in FIXTURES else CUSTOM_FIXTURES[name], ns)
     return ns['f']

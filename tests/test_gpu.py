@@ -689,6 +689,43 @@ def test_async_generate_matches_sync(ns, eng):
     assert np.array_equal(m.points(), want[0][0]); m.close()
 
 
+def test_async_calls_beyond_the_slot_count_keep_their_own_results(ns, eng):
+    """seven calls in flight on the context's four call slots, every one a DIFFERENT job (three models on
+    seven grids), collected out of order, with synchronous calls in between: a call that needs the slot of
+    an uncollected one collects that mesh first, so every mesh reports its own counters"""
+    import torch
+    models = [fixtures.build(n, ns) for n in ('ex_example', 'ex_blobby', 'torus')]
+    jobs = []
+    for i in range(7):
+        model = models[i % 3]
+        half = (1.2, 4.4, 1.4)[i % 3]
+        ax = np.arange(-half, half, 2 * half / (96 + 16 * i))
+        jobs.append((model, ax))
+    want = []
+    for model, ax in jobs:
+        m = eng.generate(model, ax, ax, ax, 32, True)
+        want.append((m.points(), m.kinds(), m.stats())); m.close()
+    assert len({w[2]['triangles'] for w in want}) == 7          # pairwise different results
+    bufs = [torch.empty(9 * (1 << 20), dtype=torch.float64, device='cuda:0') for _ in range(7)]
+    meshes = []
+    for i, (model, ax) in enumerate(jobs):
+        meshes.append(eng.generate(model, ax, ax, ax, 32, True, out_ptr=bufs[i].data_ptr(), out_cap=bufs[i].numel() // 9, wait=False))
+        if i == 4:      # a synchronous call while five are in flight: it must not take a held slot's staging
+            m = eng.generate(jobs[0][0], jobs[0][1], jobs[0][1], jobs[0][1], 32, True)
+            assert m.n_triangles == want[0][2]['triangles']; m.close()
+    for i in (3, 0, 6, 1, 5, 2, 4):
+        m = meshes[i]
+        assert m.wait() is True
+        p0, k0, s0 = want[i]
+        st = m.stats()
+        assert m.n_triangles == s0['triangles'] and st['triangles'] == s0['triangles']
+        assert (st['batches'], st['skipped'], st['empty'], st['nonempty']) == (s0['batches'], s0['skipped'], s0['empty'], s0['nonempty'])
+        assert st['n_eval_voxels'] == s0['n_eval_voxels'] and st['ms_mesh'] > 0 and st['ms_total'] >= st['ms_mesh']
+        assert np.array_equal(m.kinds(), k0)
+        assert np.array_equal(bufs[i][:9 * s0['triangles']].cpu().numpy().reshape(-1, 3), p0)
+        m.close()
+
+
 def test_results_land_in_recycled_pinned_memory(ns, eng):
     """large results come back in the library's pinned host blocks (sdf_host_alloc); a block returns to the
     free list when the last view of the array is gone and is handed out again"""
@@ -795,4 +832,108 @@ def test_interval_passes_on_texture_leaf_are_bit_identical(name, ns, oracle_lib,
     assert np.array_equal(k1, k0) and p1.shape == p0.shape and np.array_equal(p1, p0)
     assert s1['n_sampled_voxels'] < s1['n_eval_voxels']
     o = oracle_lib.generate(g, X, Y, Z, 32, True)
+    assert np.array_equal(k1, o.kinds) and np.array_equal(p1, o.points)
+
+
+# ---- user-written SDFs (reference README.md:258-295, sdf/d3.py:48-63): closures run on the host, everything
+# around them on the device; goldens from the unmodified reference running the SAME user code ----
+
+CUSTOM = np.load(os.path.join(GOLDEN, 'custom.npz'))
+CUSTOM_LIBM = {'custom_under_transforms'}          # the closure calls np.sin / np.cos (NumPy's SIMD libm differs by version)
+
+
+@pytest.mark.parametrize('name', sorted(fixtures.CUSTOM_FIXTURES))
+def test_user_closures_match_reference(name, ns, eng):
+    f = fixtures.build(name, ns)
+    P = CUSTOM['P']
+    v = f(P.copy())
+    assert v.shape == (len(P), 1) and v.dtype == np.float64
+    v, ref = v.reshape(-1), CUSTOM['v_' + name]
+    assert np.array_equal(np.isnan(v), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    if name in CUSTOM_LIBM:
+        assert np.all(np.abs(v[ok] - ref[ok]) <= value_tolerance(ref[ok], P[ok]))
+    else:
+        assert np.array_equal(v[ok], ref[ok])
+    bounds = core._estimate_bounds(f)
+    rb = CUSTOM['bounds_' + name]
+    assert np.array_equal(np.array(bounds), rb) if name not in CUSTOM_LIBM else np.allclose(np.array(bounds), rb, rtol=0, atol=1e-9)
+    rbt = tuple(map(tuple, rb))
+    pts = f.generate(samples=2 ** 17, bounds=rbt, verbose=False)
+    want = CUSTOM['pts_' + name]
+    assert isinstance(pts, np.ndarray) and pts.shape == want.shape
+    if name in CUSTOM_LIBM:
+        assert np.abs(pts - want).max() <= 1e-5 * np.ptp(rb, axis=0).max() and (pts == want).mean() > 0.999
+    else:
+        assert np.array_equal(pts, want)
+        assert hashlib.sha256(pts.tobytes()).digest() == CUSTOM['sha_' + name].tobytes()
+    st = core.generate.last_stats
+    assert st['triangles'] == int(CUSTOM['ntri_' + name]) and st['skipped'] + st['empty'] + st['nonempty'] == st['batches']
+    # shards of the surviving work list concatenate to the whole; the dense pass gives the same soup
+    X, Y, Z, _ = core.grid_axes(rbt, samples=2 ** 17)
+    parts = []
+    for r in range(3):
+        m = eng.generate(f, X, Y, Z, 32, True, shard=(r, 3))
+        parts.append(m.points()); m.close()
+    assert np.array_equal(np.concatenate(parts), pts)
+    m = eng.generate(f, X, Y, Z, 32, False)
+    assert np.array_equal(m.points(), pts) and m.stats()['skipped'] == 0
+    m.close()
+
+
+def test_user_closure_save_and_errors(ns, eng, tmp_path):
+    f = fixtures.build('custom_leaf_in_example', ns)
+    g = fixtures.build('ex_example', ns)                        # the same model from library leaves only
+    p1, p2 = str(tmp_path / 'a.stl'), str(tmp_path / 'b.stl')
+    f.save(p1, samples=2 ** 16, verbose=False)
+    g.save(p2, samples=2 ** 16, verbose=False)
+    assert open(p1, 'rb').read() == open(p2, 'rb').read()       # README's sphere IS the library's sphere
+    a, _, _ = core.sample_slice(f, w=32, h=24, z=0.1, bounds=((-1, -1, -1), (1, 1, 1)))
+    b, _, _ = core.sample_slice(g, w=32, h=24, z=0.1, bounds=((-1, -1, -1), (1, 1, 1)))
+    assert np.array_equal(a, b)
+
+    @ns['sdf3']
+    def broken(kind):
+        def f(p):
+            if kind == 'raise':
+                raise KeyError('user bug')
+            return np.zeros(len(p) + 1)
+        return f
+    with pytest.raises(KeyError):
+        (broken('raise') & ns['box'](1)).generate(samples=2 ** 12, bounds=((-1, -1, -1), (1, 1, 1)), verbose=False)
+    with pytest.raises(ValueError):
+        (broken('shape') & ns['box'](1)).generate(samples=2 ** 12, bounds=((-1, -1, -1), (1, 1, 1)), verbose=False)
+    with pytest.raises(KeyError):
+        broken('raise').generate(samples=2 ** 12, bounds=((-1, -1, -1), (1, 1, 1)), verbose=False)
+    # the engine is still usable afterwards
+    assert len(g.generate(samples=2 ** 12, verbose=False)) > 0
+
+
+# ---- the voxel-grid leaf of Mesh.sdf (reference sdf/mesh.py:96-105) ----
+
+GRID3D = np.load(os.path.join(GOLDEN, 'grid3d.npz'))
+
+
+@pytest.mark.parametrize('name', ['torus', 'two_spheres', 'noise'])
+def test_grid_leaf_on_device(name, ns, oracle_lib, eng):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), '..', 'tools'))
+    import make_golden_custom as mgc
+    from sdf_amd import mesh
+    X, Y, Z, A, bg, bb = mgc.grids()[name]
+    f = mesh.grid_sdf((X, Y, Z), A, bg, bb)
+    P = GRID3D['p_' + name]
+    v = eng.eval_points(f, P)
+    assert np.array_equal(v, GRID3D['v_' + name]) and np.array_equal(v, oracle_lib.evaluate(f, P))
+    g = f.translate((0.05, -0.03, 0.02)) | ns['sphere'](0.2).translate((0, 0, 0.5))
+    assert np.array_equal(eng.eval_points(g, P), GRID3D['vc_' + name])
+    bounds = core._estimate_bounds(g)
+    assert np.array_equal(np.array(bounds), GRID3D['bounds_' + name])
+    Xa, Ya, Za, _ = core.grid_axes(bounds, samples=2 ** 17)
+    (p1, k1, s1), (p0, k0, s0) = _both_ways(eng, g, Xa, Ya, Za)
+    assert np.array_equal(p1, p0) and np.array_equal(k1, k0)
+    assert s1['n_sampled_voxels'] < s1['n_eval_voxels']          # the leaf has an interval form: groups are culled
+    assert np.array_equal(p1, GRID3D['pts_' + name])
+    assert hashlib.sha256(p1.tobytes()).digest() == GRID3D['sha_' + name].tobytes()
+    o = oracle_lib.generate(g, Xa, Ya, Za, 32, True)
     assert np.array_equal(k1, o.kinds) and np.array_equal(p1, o.points)

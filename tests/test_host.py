@@ -69,7 +69,9 @@ def test_every_fixture_lowers(name, ns):
     assert t.n_pslots <= tape.MAX_P_SLOTS and t.n_dslots <= tape.MAX_D_SLOTS
 
 
-def test_opaque_closure_is_rejected(ns):
+def test_user_closures_lower_to_extern_leaves(ns):
+    """a function decorated with @sdf3 / @op3 that returns NumPy code (reference README.md:258-295) becomes an
+    `extern` leaf: the tape remembers the callable, the device reads its values from a buffer"""
     from sdf_amd import tape, ir
 
     @ns['sdf3']
@@ -77,8 +79,39 @@ def test_opaque_closure_is_rejected(ns):
         def f(p):
             return np.linalg.norm(p, axis=1) - 1
         return f
+    c = custom()
+    t = tape.lower(c | ns['sphere'](1))
+    assert 'L_EXTERN' in t.disassemble() and len(t.externs) == 1 and t.externs[0][1] == 3
+    assert t.rstart is None                                   # no interval prepass around host code
+    t2 = tape.lower(c.translate((1, 0, 0)) | c)               # one closure, two leaves
+    assert len(t2.externs) == 2 and t2.externs[0][0] is t2.externs[1][0]
     with pytest.raises(ir.OpaqueSDFError):
-        tape.lower(custom() | ns['sphere'](1))
+        tape.lower(ns['SDF3'](42) | ns['sphere'](1))          # neither a node nor a callable
+    for name in fixtures.CUSTOM_FIXTURES:
+        t = tape.lower(fixtures.build(name, ns))
+        assert len(t.externs) >= 1 and (t.code[-2] & 255) == tape.OP['END']
+
+
+def test_grid_leaf_matches_the_reference_closure_on_the_oracle(ns, oracle_lib):
+    """reference sdf/mesh.py:96-105 (scipy RegularGridInterpolator + box estimator) restated in the oracle:
+    bit-identical to values produced by the reference's own ingredients (tools/make_golden_custom.py)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import make_golden_custom as mgc
+    from sdf_amd import mesh, tape
+    g = np.load(os.path.join(GOLDEN, 'grid3d.npz'))
+    for name, (X, Y, Z, A, bg, bb) in mgc.grids().items():
+        f = mesh.grid_sdf((X, Y, Z), A, bg, bb)
+        assert np.array_equal(oracle_lib.evaluate(f, g['p_' + name]), g['v_' + name]), name
+        h = f.translate((0.05, -0.03, 0.02)) | ns['sphere'](0.2).translate((0, 0, 0.5))
+        assert np.array_equal(oracle_lib.evaluate(h, g['p_' + name]), g['vc_' + name]), name
+        assert 'L_GRID3D' in tape.lower(h).disassemble()
+    with pytest.raises(ValueError):
+        mesh.grid_sdf((np.arange(3.0), np.arange(3.0), np.array([0.0, 2.0, 1.0])), np.zeros((3, 3, 3)), 1.0, ((0, 0, 0), (1, 1, 1)))
+    m = mesh.Mesh(np.array([[0.0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3]]), np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]]))
+    assert m.size == (1.0, 2.0, 3.0) and m.centered().bounding_box == ((-0.5, -1.0, -1.5), (0.5, 1.0, 1.5))
+    assert m.scaled(2).translated((1, 1, 1)).bounding_box == ((1.0, 1.0, 1.0), (3.0, 5.0, 7.0))
+    with pytest.raises(ImportError):                          # the voxeliser is OpenVDB's, exactly like the reference
+        m.sdf(0.1)
 
 
 def test_generated_headers_are_in_sync():
