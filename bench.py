@@ -144,7 +144,7 @@ def main():
         if not mesh.emitted:               # (the soup did not fit: it was meshed again into library memory)
             big = torch.empty(max(t + t // 8, 1) * 9, dtype=torch.float64, device=dev)
             mesh.emit_device(big.data_ptr())
-            state['bufs'][state['bufs'].index(buf)] = big
+            state['bufs'] = [big if b is buf else b for b in state['bufs']]      # (identity, not tensor ==)
             buf = big
         state['last_buf'] = buf
         st = mesh.stats()
@@ -169,7 +169,8 @@ def main():
             state['buf'] = soup
             state['stats'] = st
             state['tris'] = st['triangles']
-            mesh_ms.append(st['ms_mesh'])
+            mesh_ms.append(st['ms_mesh'])            # this rank: prepass + k_mesh of its shard, into the slab
+            exch_ms.append((st['ms_exchange'], st['ms_expand']))
 
     def sync():
         while inflight:
@@ -180,21 +181,28 @@ def main():
             td.barrier()
             torch.cuda.synchronize()
 
-    mesh_ms = []
+    mesh_ms, exch_ms = [], []
     for _ in range(args.warmup):
         one_step()
     sync()
-    del mesh_ms[:]
+    del mesh_ms[:], exch_ms[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     sync()                                 # every one of the K steps is complete (collected) here
     dt = time.perf_counter() - t0
     assert len(mesh_ms) == args.steps
+    per_rank = None
     if td is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
+        # per-rank device times of the three stages of a step (means over the timed steps)
+        mine = torch.tensor([float(np.mean(mesh_ms)), float(np.mean([e[0] for e in exch_ms])), float(np.mean([e[1] for e in exch_ms]))],
+                            dtype=torch.float64, device=comm_dev)
+        allr = torch.empty(3 * world, dtype=torch.float64, device=comm_dev)
+        td.all_gather_into_tensor(allr, mine)
+        per_rank = allr.cpu().numpy().reshape(world, 3)
 
     st = state['stats']
     tris = int(state['tris'])
@@ -229,9 +237,9 @@ def main():
     # (copied out after the timed region) against the hash of the reference's own soup on this grid
     check = None
     soup_sha = None
-    if world == 1 and not args.no_check:
+    if not args.no_check and rank == 0:
         import hashlib
-        last = state.get('last_buf')          # the buffer the last collected (= last timed) step wrote
+        last = state.get('last_buf') if world == 1 else state.get('buf')   # the soup the last timed step left on the device
         if last is not None and tris * 9 <= last.numel():
             soup_sha = hashlib.sha256(last[:tris * 9].cpu().numpy().tobytes()).hexdigest()
         if args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64':
@@ -276,7 +284,7 @@ def main():
         'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': round(k_ms, 4),
         'note': 'path is VALU/latency bound by construction (SURVEY 8d): see valu',
         'valu': {'eval_voxels_per_launch': eval_vox, 'interpreted_voxels_per_launch': sampled_vox,
-                 'pruned_instr_fraction': round(st.get('n_pruned_instrs', 0) / max(st.get('n_batch_instrs', 0), 1), 4),
+                 'pruned_instr_fraction': round(st.get('n_pruned_instrs', 0) / st['n_batch_instrs'], 4) if st.get('n_batch_instrs') else None,
                  'flops_per_voxel_est': plain + special,
                  'achieved_tflops_est': round((plain + special) * sampled_vox / (k_ms * 1e-3) / 1e12, 3) if k_ms > 0 else 0,
                  'peak_tflops': FP64_VECTOR_PEAK_TFLOPS if args.precision == 'f64' else 157.3},
@@ -321,7 +329,13 @@ def main():
         'value_incl_d2h': round(incl, 1) if incl else None,
         'steps_in_flight': DEPTH if world == 1 else 1,
         'latency_ms_per_call': round(latency_ms, 4) if latency_ms else None,
-        'device_ms': {'prepass': round(st['ms_prepass'], 4), 'mesh': round(k_ms, 4), 'emit': round(st.get('ms_emit', 0.0), 4)},
+        'device_ms': ({'prepass': round(st['ms_prepass'], 4), 'mesh': round(k_ms, 4), 'emit': round(st.get('ms_emit', 0.0), 4)} if world == 1 else
+                      {'per_rank_mesh': [round(float(v), 4) for v in per_rank[:, 0]],          # prepass + k_mesh of the rank's shard
+                       'per_rank_exchange': [round(float(v), 4) for v in per_rank[:, 1]],      # the all-gather of the slabs
+                       'per_rank_expand': [round(float(v), 4) for v in per_rank[:, 2]]}),      # slabs -> float64 soup
+        'exchange_ms': None if world == 1 else round(float(per_rank[:, 1].max()), 4),
+        'exchange': None if world == 1 else {'payload': st.get('payload'), 'slab_bytes': st.get('slab_bytes'), 'chunks': st.get('chunks'),
+                                             'collectives_per_step': st.get('chunks'), 'host_syncs_per_step': 1},
         'parity_check': check,
         'parity': {'soup_sha256': soup_sha, 'reference_sha256': EXAMPLE_S27_SHA256 if check is not None else None,
                    'what': 'sha256 of the float64 soup of the last timed step (copied from its device buffer after the '

@@ -155,6 +155,21 @@ int sdf_generate_to_device_async(sdf_tape *tape, const double *X, int nx, const 
                                  int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,
                                  void *d_out, int64_t cap_tris, sdf_mesh **out);
 int sdf_mesh_wait(sdf_mesh *mesh, int *emitted);
+/* Multi-GPU exchange (north_star: "batches shard naturally over the 8 GPUs of one node with an RCCL all-gather of
+ * triangle buffers"; the reference itself has no distributed path).  A rank meshes its shard of the surviving-batch
+ * work list into a SLAB of fixed capacity in caller-owned device memory -- header (counts, statistics, overflow
+ * flag), per-work-item triangle prefix and transform, and the triangles in marching cubes' local float32 form
+ * (36 bytes each instead of the 72 of the float64 soup) -- the caller all-gathers the equal-sized slabs of all
+ * ranks in ONE collective, and sdf_expand_slabs writes the ordered float64 soup from the gathered slabs (given in
+ * final order) on every rank.  Everything is only ENQUEUED on the context's stream; the caller reads the 128-byte
+ * headers (int64[16]: n_tris, n_items, overflow, n_empty, n_nonempty, n_eval, n_ambiguous, n_sampled, n_pruned,
+ * n_work_total, ...) once at the end; overflow != 0 anywhere: repeat with larger capacities. */
+size_t sdf_slab_bytes(int64_t cap_items, int64_t cap_tris);
+int sdf_generate_compact_async(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
+                               int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,
+                               void *d_slab, int64_t cap_items, int64_t cap_tris, sdf_mesh **out);
+int sdf_expand_slabs(sdf_ctx *ctx, const void *const *d_slabs, int n_slabs, int64_t cap_items, int64_t cap_tris,
+                     void *d_out, int64_t cap_out_tris);
 int sdf_mesh_stats(sdf_mesh *mesh, sdf_stats *out);
 int64_t sdf_mesh_triangles(sdf_mesh *mesh);
 /* write the (3T,3) float64 world-space soup (reference order; `points * scale + offset`,

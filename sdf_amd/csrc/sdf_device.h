@@ -78,6 +78,12 @@ struct MeshArgs {
     int park_cap;
     unsigned park_spins;           // polls of the predecessors' counts before a batch is parked
     const unsigned char *cull;     // NULL, or k_cull's records: per work item, the sampling tasks to evaluate (cull_tasks)
+    // compact output (multi-GPU exchange, sdf_generate_compact_async): `out` then holds 9 FLOAT32 per triangle in the
+    // batch's local voxel coordinates (what marching cubes itself produces, 36 bytes instead of 72) and xf[] the
+    // per-work-item transform (offset[3], scale[3], indexed by w - work_begin) that k_expand applies after the gather
+    int compact;
+    double *xf;
+    int xf_cap;
 };
 
 // dynamic LDS layout of k_mesh
@@ -474,6 +480,14 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 const int n9 = pend_total * 9;
                 const double sc[3] = {psc0, psc1, psc2}, of[3] = {pof0, pof1, pof2};
                 constexpr int U = 8;
+                if (a.compact) {   // (uniform) the soup keeps the local float32 form: a plain copy
+                    float *dstf = reinterpret_cast<float *>(a.out) + pbase * 9ull;
+                    for (int e0 = tid; e0 < n9; e0 += BLOCK * U) {
+                        float f[U];
+                        SDF_UNROLL for (int k = 0; k < U; k++) f[k] = src[min(e0 + k * BLOCK, n9 - 1)];
+                        SDF_UNROLL for (int k = 0; k < U; k++) if (e0 + k * BLOCK < n9) dstf[e0 + k * BLOCK] = f[k];
+                    }
+                } else
                 for (int e0 = tid; e0 < n9; e0 += BLOCK * U) {
                     float f[U];
                     SDF_UNROLL for (int k = 0; k < U; k++) f[k] = src[min(e0 + k * BLOCK, n9 - 1)];
@@ -749,6 +763,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         }
         // ---- the batch's count is public from here on; bookkeeping that needs no position ----
         if (tid < 64) publish_count(a.status, w, work_begin, (unsigned long long)total);
+        if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
+            double *xf = a.xf + (size_t)(w - work_begin) * 6;
+            xf[0] = axes[0]; xf[1] = axes[33]; xf[2] = axes[66];
+            xf[3] = axes[1] - axes[0]; xf[4] = axes[34] - axes[33]; xf[5] = axes[67] - axes[66];
+        }
         if (tid == 0) {
             atomicAdd(total ? &a.ctr->n_nonempty : &a.ctr->n_empty, 1u);
             atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
@@ -837,9 +856,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     mc_vertex(corner, lyz, lz, i0, i1, i2, tt[1], o + 3);
                     mc_vertex(corner, lyz, lz, i0, i1, i2, tt[2], o + 6);
                 }
-                if (parking) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
+                if (parking || a.compact) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
                     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                    float *dst = park0 + (size_t)t * 9;
+                    float *dst = parking ? park0 + (size_t)t * 9
+                                         : reinterpret_cast<float *>(a.out) + (base + (unsigned long long)lo + (unsigned long long)t) * 9ull;
                     *reinterpret_cast<f4u *>(dst) = f4u{o[0], o[1], o[2], o[3]};
                     *reinterpret_cast<f4u *>(dst + 4) = f4u{o[4], o[5], o[6], o[7]};
                     dst[8] = o[8];
@@ -866,8 +886,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
 }
 
 // host-side launcher of one (T, FULL) family, defined in sdf_mesh_inst.hip (one translation
-// unit per family so the variants compile in parallel).  slots: 0 = (2,2), 1 = (4,4), 2 = (8,8)
-// register files; shape: 0 = 1024 threads x 1 sample per lane, 1 = 512 x 2, anything else = 1024 x 2.
+// unit per family so the variants compile in parallel).  slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (4,4), 4 = (8,8)
+// register files; shape: 0 = 1024 threads x 1 sample per lane, 1 = 512 x 2, anything else = 1024 x 2 (where instantiated).
 #define SDF_DECLARE_MESH_LAUNCH(NAME, T) \
     int NAME(int slots, int shape, int grid, size_t lds, hipStream_t stream, const uint32_t *code, const T *consts, const MeshArgs &a)
 SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f64, double);

@@ -380,6 +380,79 @@ __global__ __launch_bounds__(256) void k_field_emit(const McTables *__restrict__
     }
 }
 
+// ---- the multi-GPU exchange unit ("slab"): what one rank contributes to the all-gather (sdf_amd/dist.py) ----
+// [header 128 B | prefix[cap_items] u64 | xf[cap_items][6] f64 | tris[cap_tris][9] f32], a fixed capacity per call so
+// that ONE all-gather of equal-sized slabs moves everything: the counts travel in the header, the triangles in
+// marching cubes' own local float32 form (36 B instead of the 72 B of the float64 soup), the per-batch transforms
+// next to them.  k_expand turns the gathered slabs into the ordered float64 soup on every rank.
+struct SlabHeader {
+    long long n_tris, n_items, overflow, n_empty, n_nonempty, n_eval, n_ambiguous, n_sampled, n_pruned, n_work_total;
+    long long pad_[6];
+};
+static_assert(sizeof(SlabHeader) == 128, "slab header");
+struct SlabLayout {
+    size_t prefix_off, xf_off, tris_off, bytes;
+    __host__ __device__ SlabLayout(long long cap_items, long long cap_tris) {
+        prefix_off = 128;
+        xf_off = prefix_off + (size_t)cap_items * 8;
+        tris_off = (xf_off + (size_t)cap_items * 48 + 15) & ~(size_t)15;
+        bytes = (tris_off + (size_t)cap_tris * 36 + 255) & ~(size_t)255;
+    }
+};
+
+// header + the shard's look-back words (inclusive triangle prefix per work item) into the slab, behind k_mesh
+__global__ __launch_bounds__(256) void k_pack_slab(const MeshCounters *__restrict__ ctr, const unsigned long long *__restrict__ status,
+                                                   unsigned char *__restrict__ slab, long long cap_items, long long cap_tris) {
+    const SlabLayout L(cap_items, cap_tris);
+    const long long n_items = (long long)ctr->work_end - ctr->work_begin;
+    unsigned long long *prefix = reinterpret_cast<unsigned long long *>(slab + L.prefix_off);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_items && i < cap_items; i += (long long)gridDim.x * blockDim.x)
+        prefix[i] = status[ctr->work_begin + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        SlabHeader h = {};
+        h.n_tris = (long long)ctr->total; h.n_items = n_items;
+        h.overflow = (long long)ctr->overflow | (n_items > cap_items ? 4 : 0) | ((long long)ctr->total > cap_tris ? 1 : 0);
+        h.n_empty = ctr->n_empty; h.n_nonempty = ctr->n_nonempty; h.n_eval = (long long)ctr->n_eval;
+        h.n_ambiguous = (long long)ctr->n_ambiguous; h.n_sampled = (long long)ctr->n_sampled; h.n_pruned = (long long)ctr->n_pruned;
+        h.n_work_total = ctr->nwork;
+        *reinterpret_cast<SlabHeader *>(slab) = h;
+    }
+}
+
+// gathered slabs (in final order) -> the ordered float64 soup: `points * scale + offset` (reference sdf/core.py:58-60)
+// per work item; a workgroup per (slab, work item), consecutive lanes = consecutive coordinates
+struct SlabPtrs { const unsigned char *p[64]; };
+__global__ __launch_bounds__(256) void k_expand(SlabPtrs slabs, int n_slabs, long long cap_items, long long cap_tris,
+                                                double *__restrict__ out, unsigned long long cap_out) {
+    const SlabLayout L(cap_items, cap_tris);
+    const int sidx = blockIdx.y;
+    unsigned long long base = 0;
+    for (int q = 0; q < sidx; q++) {
+        const long long n = reinterpret_cast<const SlabHeader *>(slabs.p[q])->n_tris;
+        base += (unsigned long long)(n < 0 ? 0 : (n > cap_tris ? cap_tris : n));
+    }
+    const unsigned char *slab = slabs.p[sidx];
+    const SlabHeader *h = reinterpret_cast<const SlabHeader *>(slab);
+    const long long n_items = h->n_items < cap_items ? h->n_items : cap_items;
+    const unsigned long long *prefix = reinterpret_cast<const unsigned long long *>(slab + L.prefix_off);
+    const double *xf = reinterpret_cast<const double *>(slab + L.xf_off);
+    const float *tris = reinterpret_cast<const float *>(slab + L.tris_off);
+    for (long long i = blockIdx.x; i < n_items; i += gridDim.x) {
+        const unsigned long long w1 = prefix[i], w0 = i ? prefix[i - 1] : MESH_FLAG_PFX;
+        if ((w1 >> 62) != 2ull || (w0 >> 62) != 2ull) continue;             // (an incomplete pass: flagged in the header)
+        unsigned long long t0 = w0 & MESH_VAL_MASK, t1 = w1 & MESH_VAL_MASK;
+        if (t1 > (unsigned long long)cap_tris) t1 = (unsigned long long)cap_tris;
+        if (t0 >= t1) continue;
+        const double of[3] = {xf[i * 6], xf[i * 6 + 1], xf[i * 6 + 2]}, sc[3] = {xf[i * 6 + 3], xf[i * 6 + 4], xf[i * 6 + 5]};
+        const unsigned long long e1 = t1 * 9ull;
+        for (unsigned long long e = t0 * 9ull + threadIdx.x; e < e1; e += 256) {
+            const int ax = (int)(e % 3ull);
+            const unsigned long long o = base * 9ull + e;
+            if (o < cap_out * 9ull) out[o] = (double)tris[e] * (ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2])) + (ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]));
+        }
+    }
+}
+
 // ---- STL records (reference sdf/stl.py:4-24): float32 vertices, normal = normalised cross ----
 __global__ __launch_bounds__(256) void k_stl(const double *__restrict__ pts, long long ntri, unsigned short *__restrict__ out) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,7 +624,7 @@ struct sdf_mesh {
         bool active = false;
         sdf_tape *tape = nullptr;
         int slot = 0, nb = 0, bs = 0, sparse = 0, precision = 0;
-        bool pruning = false, own_start = false;
+        bool pruning = false, own_start = false, compact = false;
         uint32_t n_instr = 0;
         unsigned long long key = 0;
         void *d_out = nullptr;
@@ -960,12 +1033,13 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     const size_t list_cap = std::min<size_t>((c->lds_max - list_off) / 4, 16384);
     a.list_off = (int)list_off; a.list_cap = (int)list_cap;
     const size_t lds = list_off + list_cap * 4;
-    const uint32_t need = std::max(t->n_p, t->n_d);
-    int slots = need <= 2 ? 0 : (need <= 4 ? 1 : 2);
-    if (c->mesh_slots >= 0) slots = std::max(slots, std::min(c->mesh_slots, 2));
-    // measured on the 512^3 example: 4 waves per SIMD beat 2, and two samples per lane
-    // beat one whenever the variant still fits 128 VGPRs
-    int shape = slots <= 1 ? 3 : 0;   // (2,2) and (4,4) register files: 1024 x 2; (8,8): 1024 x 1 (x 2 would spill)
+    // the smallest register-file variant that holds the tape's slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (4,4), 4 = (8,8)
+    const uint32_t np = std::max(t->n_p, 1u), nd = std::max(t->n_d, 1u);
+    int slots = (np <= 1 && nd <= 1) ? 0 : (np <= 2 && nd <= 2) ? 1 : (np <= 4 && nd <= 2) ? 2 : (np <= 4 && nd <= 4) ? 3 : 4;
+    if (c->mesh_slots >= 0) slots = std::max(slots, std::min(c->mesh_slots, 4));     // (tuning: force a larger file)
+    // measured (profiles/r02b_shapes.txt): 4 waves per SIMD beat 2, and two samples per lane beat one
+    // wherever that shape exists; the 8-slot file runs 1024 x 1
+    int shape = slots <= 3 ? 3 : 0;
     if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
     int rc;
     if (precision == SDF_PRECISION_F64)
@@ -1000,8 +1074,10 @@ static void finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb
 
 static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
                          int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out,
-                         bool async_mode = false) {
+                         bool async_mode = false, int64_t slab_items = -1) {
+    // slab_items >= 0: compact mode (sdf_generate_compact_async) -- d_out is a SLAB of capacity (slab_items, cap_out)
     sdf_ctx *c = t->ctx;
+    const bool compact = slab_items >= 0;
     // a free call slot; when all are held by calls in flight, the oldest of them is COLLECTED first (its counters
     // and event times live in the slot's pinned staging and events: reusing the slot before sdf_mesh_wait has
     // read them would hand that mesh this call's numbers)
@@ -1026,7 +1102,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     const int nb = (int)nb64;
     m->st.n_batches = nb;
     m->st.n_grid_voxels = (int64_t)nx * ny * nz;
-    if (nb == 0) return 0;
+    if (nb == 0) {
+        if (compact) HIPCHK(hipMemsetAsync(d_out, 0, sizeof(SlabHeader), c->stream));   // an empty grid: an empty slab
+        return 0;
+    }
 
     if (m->axes.ensure((size_t)(nx + ny + nz) * 8) || m->kinds.ensure((size_t)nb) || m->worklist.ensure((size_t)nb * 4) ||
         m->status.ensure((size_t)nb * 8))
@@ -1134,7 +1213,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                                    ((unsigned long long)bs << 36) ^ (sparse ? 1ull << 63 : 0ull);
     unsigned long long cap = 0;
     MeshCounters h;
-    bool to_caller = d_out && cap_out > 0;
+    bool to_caller = compact || (d_out && cap_out > 0);
     bool quiet = true;     // nothing but k_mesh follows ev[2] on the stream, and the host did not stall in between
     if (!to_caller) {
         if (t->hint_key == key && t->hint_total_tris) {
@@ -1154,7 +1233,13 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     float ms = 0;
     for (int attempt = 0;; attempt++) {
         MeshArgs a;
-        if (to_caller) {
+        a.compact = 0; a.xf = nullptr; a.xf_cap = 0;
+        if (compact) {
+            const SlabLayout L(slab_items, cap_out);
+            a.out = reinterpret_cast<double *>((unsigned char *)d_out + L.tris_off); a.out_cap = (unsigned long long)cap_out;
+            a.compact = 1; a.xf = reinterpret_cast<double *>((unsigned char *)d_out + L.xf_off);
+            a.xf_cap = (int)std::min<int64_t>(slab_items, 0x7fffffff);
+        } else if (to_caller) {
             a.out = (double *)d_out; a.out_cap = (unsigned long long)cap_out;
         } else {
             if (!m->out.p && !c->arena_pool.empty()) { m->out = c->arena_pool.back(); c->arena_pool.pop_back(); }
@@ -1191,6 +1276,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (own_start) HIPCHK(hipEventRecord(cs.e3, c->stream));
         if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs)) return 1;
         HIPCHK(hipEventRecord(cs.e4, c->stream));
+        if (compact) {
+            const unsigned pack_blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((slab_items + 255) / 256, 1), 1024);
+            hipLaunchKernelGGL(k_pack_slab, dim3(pack_blocks), dim3(256), 0, c->stream, (const MeshCounters *)m->counters.p,
+                               (const unsigned long long *)m->status.p, (unsigned char *)d_out, (long long)slab_items, (long long)cap_out);
+            HIPCHK(hipGetLastError());
+        }
         MeshCounters *hp = (MeshCounters *)(stage + SDF_STAGE_BYTES - 256);   // pinned
         HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         if (async_mode && attempt == 0) {   // the caller collects the result with sdf_mesh_wait
@@ -1198,7 +1289,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             cs.busy = true; cs.owner = m;
             sdf_mesh::Pending &pd = m->pend;
             pd.active = true; pd.tape = t; pd.slot = slot; pd.nb = nb; pd.bs = bs; pd.sparse = sparse; pd.precision = precision;
-            pd.pruning = pruning; pd.own_start = own_start; pd.n_instr = n_instr; pd.key = key;
+            pd.pruning = pruning; pd.own_start = own_start; pd.n_instr = n_instr; pd.key = key; pd.compact = compact;
             pd.d_out = d_out; pd.cap_out = cap_out; pd.shard_index = shard_index; pd.shard_count = shard_count;
             pd.nx = nx; pd.ny = ny; pd.nz = nz;
             pd.axes.assign(X, X + nx); pd.axes.insert(pd.axes.end(), Y, Y + ny); pd.axes.insert(pd.axes.end(), Z, Z + nz);
@@ -1239,7 +1330,7 @@ int sdf_mesh_destroy(sdf_mesh *m);
 
 static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
                           int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out,
-                          sdf_mesh **out, bool async_mode = false) {
+                          sdf_mesh **out, bool async_mode = false, int64_t slab_items = -1) {
     if (!t || !X || !Y || !Z || !out) return fail("sdf_generate: NULL argument");
     *out = nullptr;
     if (t->n_extern) return fail("sdf_generate: the tape reads user closures (L_EXTERN): mesh it with sdf_generate_field");
@@ -1251,7 +1342,7 @@ static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y,
     HIPCHK(hipSetDevice(c->device));
     sdf_mesh *m = new sdf_mesh();
     m->ctx = c;
-    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out, async_mode)) {
+    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out, async_mode, slab_items)) {
         const std::string keep = g_err;
         sdf_mesh_destroy(m);
         g_err = keep;
@@ -1437,6 +1528,33 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
     return 0;
 }
 
+size_t sdf_slab_bytes(int64_t cap_items, int64_t cap_tris) {
+    if (cap_items < 0 || cap_tris < 0) return 0;
+    return SlabLayout(cap_items, cap_tris).bytes;
+}
+
+int sdf_generate_compact_async(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
+                               int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_slab,
+                               int64_t cap_items, int64_t cap_tris, sdf_mesh **out) {
+    if (!d_slab || cap_items < 0 || cap_tris < 0) return fail("sdf_generate_compact_async: slab is NULL or its capacities are negative");
+    return generate_entry(t, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_slab, cap_tris, out, true, cap_items);
+}
+
+int sdf_expand_slabs(sdf_ctx *c, const void *const *d_slabs, int n_slabs, int64_t cap_items, int64_t cap_tris, void *d_out, int64_t cap_out) {
+    if (!c || !d_slabs || (!d_out && cap_out > 0)) return fail("sdf_expand_slabs: NULL argument");
+    if (n_slabs < 1 || n_slabs > 64) return fail("sdf_expand_slabs: 1..64 slabs");
+    if (cap_items < 0 || cap_tris < 0 || cap_out < 0) return fail("sdf_expand_slabs: negative capacity");
+    if (cap_items == 0 || cap_out == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    SlabPtrs ptrs = {};
+    for (int i = 0; i < n_slabs; i++) { if (!d_slabs[i]) return fail("sdf_expand_slabs: NULL slab"); ptrs.p[i] = (const unsigned char *)d_slabs[i]; }
+    const unsigned gx = (unsigned)std::min<int64_t>(cap_items, 8192);
+    hipLaunchKernelGGL(k_expand, dim3(gx, (unsigned)n_slabs), dim3(256), 0, c->stream, ptrs, n_slabs, (long long)cap_items, (long long)cap_tris,
+                       (double *)d_out, (unsigned long long)cap_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
     if (!m) return fail("sdf_mesh_wait: NULL argument");
     sdf_mesh::Pending &pd = m->pend;
@@ -1454,7 +1572,11 @@ int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
         m->st.ms_mesh = ms;
         cs.busy = false; cs.owner = nullptr;      // (everything the slot held for this mesh has been read)
         if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
-        if (h.overflow) {
+        if (h.overflow && pd.compact) {
+            // a slab that was too small: the exchange protocol retries with larger slabs on EVERY rank (sdf_amd/dist.py)
+            finish_stats(pd.tape, m, h, pd.nb, pd.pruning, pd.n_instr, pd.key, ms_pre, ms_tot);
+            m->emitted_to = nullptr;
+        } else if (h.overflow) {
             // the soup did not fit the caller's buffer: the call is repeated synchronously into library memory
             // (sized from the count just learned)
             pd.tape->hint_key = pd.key; pd.tape->hint_total_tris = std::max<unsigned long long>(h.total, 1);
@@ -1464,7 +1586,7 @@ int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
                 return 1;
             m->st.n_retries += 1;
         } else {
-            m->emitted_to = pd.d_out;
+            m->emitted_to = pd.compact ? nullptr : pd.d_out;
             m->st.n_retries = 0;
             finish_stats(pd.tape, m, h, pd.nb, pd.pruning, pd.n_instr, pd.key, ms_pre, ms_tot);
         }

@@ -278,6 +278,49 @@ template <typename V> SDF_DEV V box_like(const V &qx, const V &qy, const V &qz) 
 #define SDF_JT_ROW(NAME) "s_branch %l[L_" #NAME "]\n\t"
 #define SDF_JT_LABEL(NAME) L_##NAME,
 
+// The voxel look-up of the grid leaf (reference sdf/mesh.py:88-103): scipy 1.7.1 RegularGridInterpolator(method='linear',
+// bounds_error=False, fill_value=background) over float32 voxels.  `_find_indices`: i = searchsorted(grid, x) - 1
+// clipped to [0, n - 2], w = (x - grid[i]) / (grid[i + 1] - grid[i]), out of bounds = x < grid[0] or x > grid[-1];
+// `_evaluate_linear`: values = 0.; for the 8 corners in itertools.product order: weight = ((1. * wx) * wy) * wz,
+// values += voxel * weight.  Outlined like the libm bodies: its index arithmetic would otherwise cost every
+// kernel variant registers at its tightest point.
+// c: nx ny nz | background | box centre (3) | box half size (3) | X[nx] Y[ny] Z[nz] | A[nx][ny][nz]
+template <typename T>
+static __device__ __attribute__((noinline)) T grid3d_lookup(const T *__restrict__ c, T px, T py, T pz) {
+    const int n0 = (int)c[0], n1 = (int)c[1], n2 = (int)c[2];
+    const T *g = c + 10;
+    const T *vox = g + n0 + n1 + n2;
+    const T p[3] = {px, py, pz};
+    const int n[3] = {n0, n1, n2};
+    int idx[3];
+    T w[3];
+    bool oob = false;
+    SDF_UNROLL
+    for (int a = 0; a < 3; a++) {
+        int lo = 0, hi = n[a];
+        while (lo < hi) {           // np.searchsorted side='left'; NaN sorts behind everything, like NumPy
+            const int mid = (lo + hi) >> 1;
+            const T gm = g[mid];
+            if (gm < p[a] || (p[a] != p[a] && gm == gm)) lo = mid + 1; else hi = mid;
+        }
+        const int i = min(max(lo - 1, 0), n[a] - 2);
+        idx[a] = i;
+        w[a] = (p[a] - g[i]) / (g[i + 1] - g[i]);
+        oob = oob || p[a] < g[0] || p[a] > g[n[a] - 1];
+        g += n[a];
+    }
+    T acc8 = T(0);
+    SDF_UNROLL
+    for (int q = 0; q < 8; q++) {
+        const int o0 = q >> 2, o1 = (q >> 1) & 1, o2 = q & 1;
+        T wt = o0 ? w[0] : T(1) - w[0];
+        wt = wt * (o1 ? w[1] : T(1) - w[1]);
+        wt = wt * (o2 ? w[2] : T(1) - w[2]);
+        acc8 = acc8 + vox[((size_t)(idx[0] + o0) * n1 + (idx[1] + o1)) * n2 + (idx[2] + o2)] * wt;
+    }
+    return oob ? c[3] : acc8;
+}
+
 // User closures (L_EXTERN leaves, reference README.md:258-295): the values of a closure at the leaf's points
 // are computed on the host by the user's own code.  A kernel that supports them passes an ExtIO: in `dump`
 // mode the leaf stores its current point (the host then calls the closure on those points), in read mode it
@@ -549,47 +592,11 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             const V q = len2(np_max(qx, T(0)), np_max(qy, T(0))) + np_min(np_max(qx, qy), T(0));
             const Mask<NS> outside = (ti < T(0)) | (ti >= (T)(tw - 1)) | (tj < T(0)) | (tj >= (T)(th - 1));
             v = vsel(outside, q, d); goto fold; }
-        L_L_GRID3D: {  // mesh.py:96-105: np.where(e > background, e, interpolator(p)), scipy RegularGridInterpolator
-            // (linear, bounds_error=False, fill_value=background) over float32 voxels, e = box(a, b)
-            // c: nx ny nz | background | box centre (3) | box half size (3) | X[nx] Y[ny] Z[nz] | A[nx][ny][nz]
-            const int n0 = (int)c[0], n1 = (int)c[1], n2 = (int)c[2];
-            const T bg = c[3];
-            const T *gx = c + 10, *gy = gx + n0, *gz = gy + n1, *vox = gz + n2;
-            const V e = box_like(m_fabs(x - c[4]) - c[7], m_fabs(y - c[5]) - c[8], m_fabs(z - c[6]) - c[9]);   // d3.py:122-134
+        L_L_GRID3D: {  // mesh.py:96-105: np.where(e > background, e, interpolator(p)); e = box(a, b) (d3.py:122-134)
+            const V e = box_like(m_fabs(x - c[4]) - c[7], m_fabs(y - c[5]) - c[8], m_fabs(z - c[6]) - c[9]);
             V d;
-            SDF_UNROLL
-            for (int k = 0; k < NS; k++) {
-                const T p[3] = {x.v[k], y.v[k], z.v[k]};
-                const T *g[3] = {gx, gy, gz};
-                const int n[3] = {n0, n1, n2};
-                int idx[3];
-                T w[3];
-                bool oob = false;
-                SDF_UNROLL
-                for (int a = 0; a < 3; a++) {   // _find_indices: np.searchsorted(grid, x) - 1, clipped to [0, n - 2]
-                    int lo = 0, hi = n[a];
-                    while (lo < hi) {           // (side='left'; NaN sorts behind everything, like NumPy)
-                        const int mid = (lo + hi) >> 1;
-                        const T gm = g[a][mid];
-                        if (gm < p[a] || (p[a] != p[a] && gm == gm)) lo = mid + 1; else hi = mid;
-                    }
-                    const int i = min(max(lo - 1, 0), n[a] - 2);
-                    idx[a] = i;
-                    w[a] = (p[a] - g[a][i]) / (g[a][i + 1] - g[a][i]);
-                    oob = oob || p[a] < g[a][0] || p[a] > g[a][n[a] - 1];
-                }
-                T acc8 = T(0);                  // _evaluate_linear: edges in itertools.product order, weight = ((1 * wx) * wy) * wz
-                SDF_UNROLL
-                for (int q = 0; q < 8; q++) {
-                    const int o0 = q >> 2, o1 = (q >> 1) & 1, o2 = q & 1;
-                    T wt = o0 ? w[0] : T(1) - w[0];
-                    wt = wt * (o1 ? w[1] : T(1) - w[1]);
-                    wt = wt * (o2 ? w[2] : T(1) - w[2]);
-                    acc8 = acc8 + vox[((size_t)(idx[0] + o0) * n1 + (idx[1] + o1)) * n2 + (idx[2] + o2)] * wt;
-                }
-                d.v[k] = oob ? bg : acc8;
-            }
-            v = vsel(e > bg, e, d); goto fold; }
+            SDF_UNROLL for (int k = 0; k < NS; k++) d.v[k] = grid3d_lookup<T>(c, x.v[k], y.v[k], z.v[k]);
+            v = vsel(e > c[3], e, d); goto fold; }
         L_L_EXTERN: {  // a user closure: its value at this leaf's point comes from the host (ExtIO)
             if constexpr (EXT::enabled) {
                 static_assert(NS == 1, "extern leaves: one sample per lane");

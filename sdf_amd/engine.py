@@ -81,6 +81,11 @@ ABI = {
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                     ctypes.c_int, _vp, ctypes.c_int64, ctypes.POINTER(_vp)]),
     'sdf_mesh_wait': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
+    'sdf_slab_bytes': (ctypes.c_size_t, [_c_i64, _c_i64]),
+    'sdf_generate_compact_async': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _vp, _c_i64,
+                                                  _c_i64, ctypes.POINTER(_vp)]),
+    'sdf_expand_slabs': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int, _c_i64, _c_i64, _vp, _c_i64]),
     'sdf_mesh_stats': (ctypes.c_int, [_vp, ctypes.POINTER(SdfStats)]),
     'sdf_mesh_triangles': (_c_i64, [_vp]),
     'sdf_mesh_emit_device': (ctypes.c_int, [_vp, _vp]),
@@ -447,6 +452,34 @@ class Engine:
         m.emitted = bool(emitted.value)
         return m
 
+
+    # -- the multi-GPU exchange unit (sdf_amd/dist.py) --
+    SLAB_HEADER = ('n_tris', 'n_items', 'overflow', 'n_empty', 'n_nonempty', 'n_eval_voxels', 'n_ambiguous_cells',
+                   'n_sampled_voxels', 'n_pruned_instrs', 'n_work_total')      # int64[16] at the head of a slab
+
+    def slab_bytes(self, cap_items, cap_tris):
+        return int(self.lib.sdf_slab_bytes(int(cap_items), int(cap_tris)))
+
+    def generate_compact(self, sdf, X, Y, Z, batch_size, sparse, shard, slab_ptr, cap_items, cap_tris):
+        """mesh this rank's shard into a slab in caller-owned device memory (enqueue only; the returned mesh
+        keeps the call's device buffers alive until it is closed)"""
+        dt = self.tape_for(sdf)
+        X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
+        h = _vp()
+        _check(self.lib, self.lib.sdf_generate_compact_async(
+            dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y), _dp(Z, _f64p), len(Z), int(batch_size),
+            1 if sparse else 0, int(shard[0]), int(shard[1]), self.precision, _vp(slab_ptr), int(cap_items), int(cap_tris),
+            ctypes.byref(h)))
+        m = Mesh(self, h)
+        m._tape = dt
+        m.emitted = None
+        return m
+
+    def expand_slabs(self, slab_ptrs, cap_items, cap_tris, out_ptr, out_cap):
+        """gathered slabs (device pointers, final order) -> ordered float64 soup at out_ptr (enqueue only)"""
+        arr = (_vp * len(slab_ptrs))(*[_vp(int(p)) for p in slab_ptrs])
+        _check(self.lib, self.lib.sdf_expand_slabs(self.ctx, arr, len(slab_ptrs), int(cap_items), int(cap_tris),
+                                                   _vp(out_ptr), int(out_cap)))
 
     def _generate_field(self, dt, X, Y, Z, batch_size, sparse, shard):
         """`generate` for a model with user closures: the library drives the reference's batch loop and asks

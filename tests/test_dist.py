@@ -1,6 +1,8 @@
-"""The N>1 path on CPU: world_size-2 gloo processes run sdf_amd.dist.generate_sharded with an
-engine whose compute is the CPU oracle (test infrastructure), and must reproduce the
-single-process soup, order included."""
+"""The N>1 path on CPU: world_size-2 / -3 gloo processes run the exchange protocol of sdf_amd.dist (fixed-capacity
+slabs whose headers carry the counts, ONE all-gather per shard, capacity hints, overflow -> every rank retries,
+optional chunking for overlap) with an engine whose compute is the CPU oracle (test infrastructure), and must
+reproduce the single-process soup, order included.  The device side of the protocol (compact float32 slabs,
+k_expand) is covered on one GPU by tests/test_gpu.py::test_slab_exchange_emulated_ranks."""
 import os
 import sys
 
@@ -60,7 +62,7 @@ class OracleEngine:
         return OracleMesh(part, lo, hi, len(work))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, chunks=1):
     import torch.distributed as td
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -75,24 +77,50 @@ def _worker(rank, world, port, q):
         d = np.load(os.path.join(GOLDEN, 'gen_example_s22.npz'))
         X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
         assert dist.world_size() == world and dist.rank() == rank
-        pts, st = dist.generate_sharded(OracleEngine(), f, X, Y, Z, 32, True)
         import hashlib
-        q.put((rank, hashlib.sha256(pts.tobytes()).hexdigest(), len(pts) // 3,
+        eng = OracleEngine()
+        soup, st = dist.generate_sharded_device(eng, f, X, Y, Z, 32, True, chunks=chunks)      # first call: upper-bound capacities
+        pts = soup.numpy().reshape(-1, 3)
+        sha = hashlib.sha256(pts.tobytes()).hexdigest()
+        assert st['chunks'] == chunks and st['n_retries'] == 0
+        soup2, st2 = dist.generate_sharded_device(eng, f, X, Y, Z, 32, True, chunks=chunks)    # second: capacities from the first
+        assert st2['n_retries'] == 0 and st2['slab_bytes'] < st['slab_bytes']
+        assert hashlib.sha256(soup2.numpy().tobytes()).hexdigest() == sha
+        hints = dist._hints_for(f)
+        for k in list(hints):                                                                   # slabs far too small: flagged, repeated
+            hints[k] = (1, 7, 3)
+        soup3, st3 = dist.generate_sharded_device(eng, f, X, Y, Z, 32, True, chunks=chunks)
+        assert st3['n_retries'] >= 1 and st3['triangles'] == st['triangles']
+        assert hashlib.sha256(soup3.numpy().tobytes()).hexdigest() == sha
+        pts4, st4 = dist.generate_sharded(eng, f, X, Y, Z, 32, True)                            # the ndarray front
+        assert hashlib.sha256(pts4.tobytes()).hexdigest() == sha
+        q.put((rank, sha, len(pts) // 3,
                st['skipped'], st['empty'], st['nonempty'], st['per_rank_triangles']))
+    except BaseException:
+        import traceback
+        q.put((rank, 'ERROR', traceback.format_exc()))
+        raise
     finally:
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_generate_over_gloo(world):
+@pytest.mark.parametrize('world,chunks', [(2, 1), (3, 1), (2, 2)])
+def test_sharded_generate_over_gloo(world, chunks):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + world + 7 * chunks
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=300) for _ in procs]
+    errors = [o for o in out if o[1] == 'ERROR']
+    if errors:
+        for p in procs:
+            p.join(10)
+            if p.is_alive():
+                p.terminate()
+        pytest.fail('rank %d failed:\n%s' % (errors[0][0], errors[0][2]))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

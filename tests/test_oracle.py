@@ -25,12 +25,16 @@ def test_values_match_reference(name, ns, golden_values, oracle_lib):
 
 
 def test_values_bit_exact_where_numpy_is_deterministic(ns, golden_values, oracle_lib):
-    """fixtures that use only correctly-rounded elementwise NumPy ops must agree bit for bit"""
+    """fixtures that use only correctly-rounded elementwise NumPy ops must agree bit for bit.  (`rotate` by a
+    general angle is NOT among them: the reference's np.dot goes through BLAS, whose kernel choice -- FMA or not --
+    depends on the host CPU; goldens regenerated on another machine differ from these by <= 4 ulp there, and
+    the tolerance test above covers it.  `orient` and the rotations inside ex_example are by axis-aligned
+    matrices of 0 / +-1, exact under either kernel.)"""
     P = golden_values['P']
     for name in ('ex_example', 'ex_blobby', 'ex_pawn', 'sphere', 'box2', 'rounded_box', 'wireframe_box',
                  'torus', 'capsule', 'capped_cylinder', 'rounded_cylinder', 'capped_cone', 'ellipsoid',
                  'pyramid', 'tetrahedron', 'smooth_union', 'smooth_difference', 'smooth_intersection',
-                 'blend_k', 'elongate', 'rotate', 'orient', 'scale', 'slab_k', 'rectangle',
+                 'blend_k', 'elongate', 'orient', 'scale', 'slab_k', 'rectangle',
                  'rounded_rectangle', 'equilateral_triangle', 'rounded_x', 'vesica', 'slice', 'extrude_to',
                  'ease_in_out_quad', 'ease_out_bounce', 'ease_in_out_back', 'ease_in_out_circ'):
         v = oracle_lib.evaluate(fixtures.build(name, ns), P)

@@ -7,6 +7,9 @@ has scikit-image 0.18.3):
     env -u PYTHONPATH /opt/conda/bin/python3.9 -W ignore tools/make_golden.py
 
 Nothing here is imported by the product or by the tests; the tests read the .npz files.
+Machine dependence: every value comes from correctly rounded NumPy operations EXCEPT the fixtures that go
+through BLAS (`np.dot` in rotate / rotate_to / plane / line / cones / polyhedra) or libm -- regenerating on a
+different CPU changes those by a few ulp (the tests hold them to `value_tolerance`, not to bit equality).
 What is recorded:
 
   values.npz     reference SDF values  f(P) for every fixture in tests/fixtures.py on one
