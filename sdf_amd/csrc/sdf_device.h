@@ -504,6 +504,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             __syncthreads();   // (bcast is reused)
         }
     };
+    // (Taking the NEXT work item early -- thread 0 issuing the atomic and the work-list load behind the sampling phase, so
+    // that their two dependent round trips hide behind counting and emit -- was built and measured in r02: the time
+    // at the top of the loop did not move (it is the barrier and the record / axis loads, not the atomic), and the two
+    // values carried across the phases cost the 2- and 4-slot variants 6 - 9 more spilled registers: k_mesh
+    // 0.288 -> 0.300 ms.  Rejected.)
     for (;;) {
         SDF_FRESH();
         if (tid == 0) bcast[0] = work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
