@@ -567,6 +567,8 @@ struct CallSlot {
     hipEvent_t done = nullptr;                                            // behind the counters' copy to the host
     bool busy = false;
     struct sdf_mesh *owner = nullptr;                                     // the in-flight mesh whose counters / events the slot holds
+    hipStream_t stream = nullptr;                                         // the lane asynchronous calls of this slot run on
+    DevBuf park;                                                          // ... and its k_mesh staging slots
 };
 #define SDF_PARK_TRIS 8192   // triangles per workgroup staging slot of k_mesh (36 bytes each); larger batches wait instead
 
@@ -593,6 +595,7 @@ struct sdf_ctx {
     void *h_stage = nullptr;          // pinned host staging, SDF_CALL_SLOTS x SDF_STAGE_BYTES
     CallSlot slots[SDF_CALL_SLOTS];
     unsigned slot_seq = 0;
+    int slot_streams = 1;             // SDF_SLOT_STREAMS=0: asynchronous calls stay on the context's stream (diagnostics)
 };
 
 struct sdf_tape {
@@ -616,6 +619,7 @@ struct sdf_mesh {
     GridDesc g = {};
     DevBuf axes, kinds, worklist, status, out, prune, tapes, cull;
     bool pruned = false;
+    hipStream_t stream = nullptr;  // the stream the generating call ran on (the context's, or a call slot's lane)
     DevBuf counters;               // this call's MeshCounters block (pooled in the context)
     int work_begin = 0, work_end = 0;
     void *emitted_to = nullptr;    // caller buffer the soup was gathered into by sdf_generate_to_device
@@ -728,7 +732,9 @@ static int ctx_init(sdf_ctx *c) {
     for (auto &cs : c->slots) {
         HIPCHK(hipEventCreate(&cs.e0)); HIPCHK(hipEventCreate(&cs.e2)); HIPCHK(hipEventCreate(&cs.e3)); HIPCHK(hipEventCreate(&cs.e4));
         HIPCHK(hipEventCreateWithFlags(&cs.done, hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithFlags(&cs.stream, hipStreamNonBlocking));
     }
+    if (const char *e = getenv("SDF_SLOT_STREAMS")) c->slot_streams = atoi(e);
     McTables t;
     memcpy(t.ntri, MC_NTRI, 256);
     memcpy(t.amb, MC_AMBIGUOUS, 256);
@@ -751,6 +757,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (auto &cs : c->slots) { if (cs.stream) (void)hipStreamSynchronize(cs.stream); cs.park.release(); }
     for (DevBuf *b : {&c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof, &c->park, &c->ext, &c->field_vals,
                       &c->field_vol, &c->field_tiles})
         b->release();
@@ -759,6 +766,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     g_pool.drop_device(c->device);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto &cs : c->slots) for (hipEvent_t e : {cs.e0, cs.e2, cs.e3, cs.e4, cs.done}) if (e) (void)hipEventDestroy(e);
+    for (auto &cs : c->slots) if (cs.stream) (void)hipStreamDestroy(cs.stream);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -787,6 +795,7 @@ int sdf_ctx_synchronize(sdf_ctx *c) {
     if (!c) return fail("sdf_ctx_synchronize: ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &cs : c->slots) if (cs.stream) HIPCHK(hipStreamSynchronize(cs.stream));
     return 0;
 }
 
@@ -870,6 +879,17 @@ int sdf_tape_destroy(sdf_tape *t) {
         } else {                                                                                                \
             if ((t)->full) hipLaunchKernelGGL((KERNEL<float, true>), grid, block, shmem, (t)->ctx->stream, (t)->d_code, (t)->d_c32, __VA_ARGS__); \
             else hipLaunchKernelGGL((KERNEL<float, false>), grid, block, shmem, (t)->ctx->stream, (t)->d_code, (t)->d_c32, __VA_ARGS__); \
+        }                                                                                                       \
+    } while (0)
+
+#define LAUNCH_TAPE_ON(STREAM, KERNEL, grid, block, shmem, t, precision, ...)                                   \
+    do {                                                                                                        \
+        if ((precision) == SDF_PRECISION_F64) {                                                                 \
+            if ((t)->full) hipLaunchKernelGGL((KERNEL<double, true>), grid, block, shmem, STREAM, (t)->d_code, (t)->d_c64, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<double, false>), grid, block, shmem, STREAM, (t)->d_code, (t)->d_c64, __VA_ARGS__); \
+        } else {                                                                                                \
+            if ((t)->full) hipLaunchKernelGGL((KERNEL<float, true>), grid, block, shmem, STREAM, (t)->d_code, (t)->d_c32, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<float, false>), grid, block, shmem, STREAM, (t)->d_code, (t)->d_c32, __VA_ARGS__); \
         }                                                                                                       \
     } while (0)
 
@@ -1022,7 +1042,7 @@ int sdf_marching_cubes_host(sdf_ctx *c, const float *h_vol, int n0, int n1, int 
 
 // k_mesh launch: the register-file variant is the smallest that holds the tape's slots, the
 // shape (threads x samples per lane) a per-precision default found by measurement
-static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a, int grid, int bs) {
+static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a, int grid, int bs, hipStream_t st) {
     sdf_ctx *c = t->ctx;
     const size_t tile = (size_t)(bs + 1) * (bs + 1) * (bs + 1) * 4;
     const size_t bits_off = (MESH_LDS_VOL + tile + 15) & ~(size_t)15;
@@ -1043,11 +1063,11 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
     int rc;
     if (precision == SDF_PRECISION_F64)
-        rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, grid, lds, c->stream, (const uint32_t *)code, t->d_c64, a)
-                     : sdf_launch_mesh_f64(slots, shape, grid, lds, c->stream, (const uint32_t *)code, t->d_c64, a);
+        rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, grid, lds, st, (const uint32_t *)code, t->d_c64, a)
+                     : sdf_launch_mesh_f64(slots, shape, grid, lds, st, (const uint32_t *)code, t->d_c64, a);
     else
-        rc = t->full ? sdf_launch_mesh_f32_full(slots, shape, grid, lds, c->stream, (const uint32_t *)code, t->d_c32, a)
-                     : sdf_launch_mesh_f32(slots, shape, grid, lds, c->stream, (const uint32_t *)code, t->d_c32, a);
+        rc = t->full ? sdf_launch_mesh_f32_full(slots, shape, grid, lds, st, (const uint32_t *)code, t->d_c32, a)
+                     : sdf_launch_mesh_f32(slots, shape, grid, lds, st, (const uint32_t *)code, t->d_c32, a);
     if (rc) return fail(std::string("k_mesh launch: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
@@ -1093,6 +1113,14 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     }
     c->slot_seq = (unsigned)slot + 1u;
     CallSlot &cs = c->slots[slot];
+    // Calls in flight (sdf_generate_to_device_async) each run on their slot's OWN stream: call i + 1's prepass then
+    // fills the compute units that call i's k_mesh leaves idle in its tail (a persistent workgroup per CU, the last
+    // batches finish at different times: 9 % of that kernel's CU-time) and the dispatch gaps of one call hide behind
+    // the kernels of the other.  Everything a call touches is its own (per-mesh buffers, per-slot staging / events /
+    // park slots), so the streams need no ordering among themselves.  An adopted caller stream is never left.
+    const bool own_lane = async_mode && !compact && c->stream == c->own_stream && c->slot_streams;
+    hipStream_t st = own_lane ? cs.stream : c->stream;
+    m->stream = own_lane ? st : nullptr;
     char *stage = (char *)c->h_stage + (size_t)slot * SDF_STAGE_BYTES;
     GridDesc &g = m->g;
     g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
@@ -1103,7 +1131,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     m->st.n_batches = nb;
     m->st.n_grid_voxels = (int64_t)nx * ny * nz;
     if (nb == 0) {
-        if (compact) HIPCHK(hipMemsetAsync(d_out, 0, sizeof(SlabHeader), c->stream));   // an empty grid: an empty slab
+        if (compact) HIPCHK(hipMemsetAsync(d_out, 0, sizeof(SlabHeader), st));   // an empty grid: an empty slab
         return 0;
     }
 
@@ -1114,17 +1142,17 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     if (m->counters.ensure(sizeof(MeshCounters))) return 1;
     double *dX = (double *)m->axes.p, *dY = dX + nx, *dZ = dY + ny;
     g.X = dX; g.Y = dY; g.Z = dZ;
-    HIPCHK(hipEventRecord(cs.e0, c->stream));
+    HIPCHK(hipEventRecord(cs.e0, st));
     const size_t axis_bytes = (size_t)(nx + ny + nz) * 8;
     if (async_mode && axis_bytes > SDF_STAGE_BYTES - 256) return fail("sdf_generate_to_device_async: axes too long for the staging slot");
     if (axis_bytes <= SDF_STAGE_BYTES - 256) {   // one copy from pinned memory instead of three from pageable
         double *hs = (double *)stage;
         memcpy(hs, X, (size_t)nx * 8); memcpy(hs + nx, Y, (size_t)ny * 8); memcpy(hs + nx + ny, Z, (size_t)nz * 8);
-        HIPCHK(hipMemcpyAsync(dX, hs, axis_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dX, hs, axis_bytes, hipMemcpyHostToDevice, st));
     } else {
-        HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, st));
     }
 
     // ---- prepass: skip test for every batch, then the ordered work list (+ this shard's slice) ----
@@ -1168,11 +1196,11 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
         }
         const size_t skip_lds = prune_blocks ? prune_lds : 0;
-        if (t->ia_rare) LAUNCH_TAPE(k_skip_rare, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
-        else LAUNCH_TAPE(k_skip, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
+        if (t->ia_rare) LAUNCH_TAPE_ON(st, k_skip_rare, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
+        else LAUNCH_TAPE_ON(st, k_skip, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
     }
-    if (!sparse) HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, c->stream));
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, c->stream, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
+    if (!sparse) HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, st));
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
                        (MeshCounters *)m->counters.p, (unsigned long long *)m->status.p, (long long)shard_index,
                        (long long)shard_count);
     HIPCHK(hipGetLastError());
@@ -1180,7 +1208,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         pa.worklist = (const int *)m->worklist.p; pa.ctr = (const MeshCounters *)m->counters.p;
         auto kp = t->full ? (t->ia_rare ? k_prune_list<true, true> : k_prune_list<true, false>) : (t->ia_rare ? k_prune_list<false, true> : k_prune_list<false, false>);
         if (prune_lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
-        hipLaunchKernelGGL(kp, dim3((unsigned)(((long long)nb * 8 + PRUNE_BLOCK - 1) / PRUNE_BLOCK)), dim3(PRUNE_BLOCK), prune_lds, c->stream,
+        hipLaunchKernelGGL(kp, dim3((unsigned)(((long long)nb * 8 + PRUNE_BLOCK - 1) / PRUNE_BLOCK)), dim3(PRUNE_BLOCK), prune_lds, st,
                            (const uint32_t *)t->d_code, g, nb, pa);
         HIPCHK(hipGetLastError());
     }
@@ -1193,13 +1221,13 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         auto kc = t->full ? (t->ia_rare ? k_cull<true, true> : k_cull<true, false>) : (t->ia_rare ? k_cull<false, true> : k_cull_lean);
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kc, dim3(nb), dim3(CULL_BLOCK), lds, c->stream,
+        hipLaunchKernelGGL(kc, dim3(nb), dim3(CULL_BLOCK), lds, st,
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
                            (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
                            ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(cs.e2, c->stream));
+    HIPCHK(hipEventRecord(cs.e2, st));
 
     // ---- meshing.  The whole chain (prepass -> k_mesh) is enqueued without a host round trip: the
     // work-list length stays on the device and k_mesh writes the ordered float64 soup itself.  The
@@ -1220,8 +1248,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             cap = t->hint_total_tris + t->hint_total_tris / 4 + 4096;
         } else {
             quiet = false;
-            HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
             const unsigned long long nshard0 = (unsigned long long)std::max(h.work_end - h.work_begin, 1);
             cap = std::max<unsigned long long>(4096ull * nshard0, 1ull << 16);
             // a guess, not a need (the overflow re-run finds the exact size): never more than half the free memory
@@ -1256,36 +1284,37 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             a.out = (double *)m->out.p; a.out_cap = m->out.bytes / 72;
         }
         if (attempt) {   // (the first pass finds both cleared by k_compact)
-            HIPCHK(hipMemsetAsync(m->counters.p, 0, MESH_COUNTERS_RESET_BYTES, c->stream));
-            HIPCHK(hipMemsetAsync(m->status.p, 0, (size_t)nb * 8, c->stream));
+            HIPCHK(hipMemsetAsync(m->counters.p, 0, MESH_COUNTERS_RESET_BYTES, st));
+            HIPCHK(hipMemsetAsync(m->status.p, 0, (size_t)nb * 8, st));
         }
         a.g = g; a.worklist = (const int *)m->worklist.p;
         a.kinds = (unsigned char *)m->kinds.p; a.status = (unsigned long long *)m->status.p;
         a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
-        if (c->parking && !c->park.p) { quiet = false; if (c->park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
-        a.park = c->parking ? (float *)c->park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
+        DevBuf &park = own_lane ? cs.park : c->park;     // (k_mesh kernels of different lanes may overlap in time)
+        if (c->parking && !park.p) { quiet = false; if (park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
+        a.park = c->parking ? (float *)park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
         a.park_spins = (unsigned)c->park_spins;
         a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
         a.tape_stride = pruning ? tape_stride : 0;
         a.n_instr = (int)n_instr;
-        if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, c->stream));
+        if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, st));
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         const bool own_start = attempt > 0 || a.prof || !quiet;   // (something was enqueued, or the host waited, since ev[2])
-        if (own_start) HIPCHK(hipEventRecord(cs.e3, c->stream));
-        if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs)) return 1;
-        HIPCHK(hipEventRecord(cs.e4, c->stream));
+        if (own_start) HIPCHK(hipEventRecord(cs.e3, st));
+        if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs, st)) return 1;
+        HIPCHK(hipEventRecord(cs.e4, st));
         if (compact) {
             const unsigned pack_blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((slab_items + 255) / 256, 1), 1024);
-            hipLaunchKernelGGL(k_pack_slab, dim3(pack_blocks), dim3(256), 0, c->stream, (const MeshCounters *)m->counters.p,
+            hipLaunchKernelGGL(k_pack_slab, dim3(pack_blocks), dim3(256), 0, st, (const MeshCounters *)m->counters.p,
                                (const unsigned long long *)m->status.p, (unsigned char *)d_out, (long long)slab_items, (long long)cap_out);
             HIPCHK(hipGetLastError());
         }
         MeshCounters *hp = (MeshCounters *)(stage + SDF_STAGE_BYTES - 256);   // pinned
-        HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
         if (async_mode && attempt == 0) {   // the caller collects the result with sdf_mesh_wait
-            HIPCHK(hipEventRecord(cs.done, c->stream));
+            HIPCHK(hipEventRecord(cs.done, st));
             cs.busy = true; cs.owner = m;
             sdf_mesh::Pending &pd = m->pend;
             pd.active = true; pd.tape = t; pd.slot = slot; pd.nb = nb; pd.bs = bs; pd.sparse = sparse; pd.precision = precision;
@@ -1295,7 +1324,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             pd.axes.assign(X, X + nx); pd.axes.insert(pd.axes.end(), Y, Y + ny); pd.axes.insert(pd.axes.end(), Z, Z + nz);
             return 0;
         }
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(st));
         h = *hp;
         HIPCHK(hipEventElapsedTime(&ms, own_start ? cs.e3 : cs.e2, cs.e4));
         m->st.ms_mesh = ms;
@@ -1631,14 +1660,21 @@ int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
     return 0;
 }
 
+// (Cutting a large device-to-host copy into pieces that travel on several streams at once was measured in r02: the
+// 212 MB soup took 7.7 ms as one copy, 8.7 ms as two, 9.8 ms as four -- one copy already runs at the link's rate for
+// pinned memory.  One copy it stays.)
+static int copy_to_host(sdf_ctx *c, void *h_dst, const void *d_src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_emit_host: NULL argument");
     MESH_READY(m);
     if (m->st.n_triangles == 0) return 0;
     HIPCHK(hipSetDevice(m->ctx->device));
-    HIPCHK(hipMemcpyAsync(h_out, mesh_soup(m), (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToHost, m->ctx->stream));
-    HIPCHK(hipStreamSynchronize(m->ctx->stream));
-    return 0;
+    return copy_to_host(m->ctx, h_out, mesh_soup(m), (size_t)m->st.n_triangles * 72);
 }
 
 int sdf_mesh_emit_host_range(sdf_mesh *m, int64_t first_tri, int64_t n_tris, double *h_out) {
@@ -1692,9 +1728,7 @@ int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
     hipLaunchKernelGGL(k_stl, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, (const double *)mesh_soup(m), nt,
                        (unsigned short *)c->scratch_out.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)nt * 50, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return copy_to_host(c, h_out, c->scratch_out.p, (size_t)nt * 50);
 }
 
 int sdf_mesh_weld(sdf_mesh *m, int64_t *n_unique) {
@@ -1820,6 +1854,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
     sdf_ctx *c = m->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);        // (a call slot's lane)
     if (m->pend.active) { c->slots[m->pend.slot].busy = false; c->slots[m->pend.slot].owner = nullptr; m->pend.active = false; }   // (abandoned; the stream is idle now)
     if (m->out.p) {   // keep one soup buffer around for the next call
         if (c->arena_pool.empty()) c->arena_pool.push_back(m->out);
