@@ -217,10 +217,11 @@ def main():
         n_lat = max(1, min(args.steps, 20))
         buf = state['bufs'][0]
         t1 = time.perf_counter()
-        lat_mesh_ms = []
+        lat_mesh_ms, lat_pre_ms = [], []
         for _ in range(n_lat):
             mesh = eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9)
             lat_mesh_ms.append(mesh.stats()['ms_mesh'])
+            lat_pre_ms.append(mesh.stats()['ms_prepass'])
             mesh.close()
         latency_ms = 1e3 * (time.perf_counter() - t1) / n_lat
 
@@ -273,12 +274,15 @@ def main():
     # HBM traffic of k_mesh per launch from the PMC passes of tools/profile.sh (separate rocprofv3
     # --pmc runs of this same command; FETCH_SIZE/WRITE_SIZE corrected as MI355X_MICROARCH.md says,
     # see tools/summarize_prof.py); the newest committed summary is used
-    traffic = None
+    traffic = traffic_src = None
     if args.model == 'example' and args.samples_log2 == 27 and world == 1 and args.precision == 'f64':
         import glob
         for prof in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')), reverse=True):
-            try:
-                traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+            try:                          # (the newest summary of THIS workload: same algorithmic bytes per launch)
+                rec = json.load(open(prof))
+                if abs(float(rec.get('algorithmic_bytes_per_launch') or 0) - alg_bytes) <= 1e-3 * alg_bytes:
+                    traffic = rec.get('hbm_bytes_per_launch')
+                    traffic_src = os.path.basename(prof)
             except Exception:
                 traffic = None
             if traffic:
@@ -287,6 +291,11 @@ def main():
         'kernel': 'k_mesh<%s>' % ('double' if args.precision == 'f64' else 'float'),
         'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
+        'traffic_source': ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured '
+                           'in this run)' % traffic_src) if traffic_src else None,
+        'kernel_ms_source': 'HIP events around k_mesh in calls that ran alone (the latency loop of this run); with several '
+                            'calls in flight the same events read %.4f ms because the kernel then shares the compute units '
+                            'with the neighbouring calls\' prepass' % float(np.mean(mesh_ms)) if world == 1 else 'HIP events',
         'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': round(k_ms, 4),
         'note': 'path is VALU/latency bound by construction (SURVEY 8d): see valu',
         'valu': {'eval_voxels_per_launch': eval_vox, 'interpreted_voxels_per_launch': sampled_vox,
@@ -335,7 +344,7 @@ def main():
         'value_incl_d2h': round(incl, 1) if incl else None,
         'steps_in_flight': DEPTH if world == 1 else 1,
         'latency_ms_per_call': round(latency_ms, 4) if latency_ms else None,
-        'device_ms': ({'prepass': round(st['ms_prepass'], 4), 'mesh': round(k_ms, 4), 'mesh_pipelined': round(float(np.mean(mesh_ms)), 4),
+        'device_ms': ({'prepass': round(float(np.mean(lat_pre_ms)), 4), 'mesh': round(k_ms, 4), 'mesh_pipelined': round(float(np.mean(mesh_ms)), 4),
                        'emit': round(st.get('ms_emit', 0.0), 4)} if world == 1 else
                       {'per_rank_mesh': [round(float(v), 4) for v in per_rank[:, 0]],          # prepass + k_mesh of the rank's shard
                        'per_rank_exchange': [round(float(v), 4) for v in per_rank[:, 1]],      # the all-gather of the slabs
