@@ -154,6 +154,14 @@ def main():
         mesh_ms.append(st['ms_mesh'])
         mesh.close()
 
+    def collect_dist():
+        soup, st = dist.collect_sharded(inflight.pop(0))
+        state['buf'] = soup
+        state['stats'] = st
+        state['tris'] = st['triangles']
+        mesh_ms.append(st['ms_mesh'])            # this rank: prepass + k_mesh of its shard, into the slab
+        exch_ms.append((st['ms_exchange'], st['ms_expand']))
+
     def one_step():
         if world == 1:
             # every step writes its ordered float64 soup into a device buffer of its own (DEPTH of them
@@ -166,16 +174,16 @@ def main():
                 collect()
             inflight.append((eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9, wait=False), buf))
         else:
-            soup, st = dist.generate_sharded_device(eng, tape, X, Y, Z, 32, True, device=comm_dev)
-            state['buf'] = soup
-            state['stats'] = st
-            state['tris'] = st['triangles']
-            mesh_ms.append(st['ms_mesh'])            # this rank: prepass + k_mesh of its shard, into the slab
-            exch_ms.append((st['ms_exchange'], st['ms_expand']))
+            # N > 1: two exchange steps in flight on lanes of their own: step i + 1's meshing runs under step i's
+            # all-gather; a step is complete when its gathered headers are back on the host (collect_dist)
+            while len(inflight) >= (1 if args.sync else 2):
+                collect_dist()
+            state['n'] = state.get('n', 0) + 1
+            inflight.append(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=comm_dev, lane=state['n'] % 2))
 
     def sync():
         while inflight:
-            collect()
+            collect() if world == 1 else collect_dist()
         eng.synchronize()
         torch.cuda.synchronize()
         if td is not None:
@@ -342,7 +350,7 @@ def main():
         'triangles_per_sec': round(tris * args.steps / dt, 1),
         'eval_voxels_per_sec': round(int(st['n_eval_voxels']) * args.steps / dt, 1),
         'value_incl_d2h': round(incl, 1) if incl else None,
-        'steps_in_flight': DEPTH if world == 1 else 1,
+        'steps_in_flight': DEPTH if world == 1 else (1 if args.sync else 2),
         'latency_ms_per_call': round(latency_ms, 4) if latency_ms else None,
         'device_ms': ({'prepass': round(float(np.mean(lat_pre_ms)), 4), 'mesh': round(k_ms, 4), 'mesh_pipelined': round(float(np.mean(mesh_ms)), 4),
                        'emit': round(st.get('ms_emit', 0.0), 4)} if world == 1 else

@@ -1292,7 +1292,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
-        DevBuf &park = own_lane ? cs.park : c->park;     // (k_mesh kernels of different lanes may overlap in time)
+        DevBuf &park = async_mode ? cs.park : c->park;   // (k_mesh kernels of calls in flight may overlap in time, whichever
+                                                         // streams they run on: each call slot has its own staging slots)
         if (c->parking && !park.p) { quiet = false; if (park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
         a.park = c->parking ? (float *)park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
         a.park_spins = (unsigned)c->park_spins;

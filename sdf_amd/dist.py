@@ -40,7 +40,7 @@ H_TRIS, H_ITEMS, H_OVERFLOW, H_EMPTY, H_NONEMPTY, H_EVAL, H_AMBIGUOUS, H_SAMPLED
 
 _HINTS = weakref.WeakKeyDictionary()      # tape object -> {job key: (cap_items, cap_tris, total_tris)}
 _HINTS_BY_ID = {}                         # the same for objects that cannot be weakly referenced
-_STREAMS = {}                             # device index -> the torch stream the exchange steps run on
+_STREAMS = {}                             # device index -> {lane: the torch stream exchange steps of that lane run on}
 
 
 def _dist():
@@ -138,29 +138,46 @@ class DeviceCodec:
         self.eng.expand_slabs([s.data_ptr() for s in slabs], cap_items, cap_tris, out.data_ptr(), out_cap)
 
 
-def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=None, chunks=None):
-    """every rank returns (soup: flat float64 torch tensor of 9*T values on `device`, in
-    reference order; merged stats dict).  On GPUs the soup never leaves the device."""
+class ShardedStep:
+    """one exchange step in flight (submit_sharded): everything is enqueued, nothing has been read back"""
+    __slots__ = ('eng', 'tape', 'args', 'device', 'group', 'world', 'C', 'nb', 'codec', 'key', 'caps', 'out_cap', 'sb',
+                 'slabs', 'keep', 'out', 'meshes', 'events', 'stream', 'outer', 'lane', 'attempt')
+
+
+def _job(eng, tape, X, Y, Z, batch_size, sparse, device, group, chunks):
     import torch
     td = _dist()
     if td is None:
         raise RuntimeError('torch.distributed is not initialised')
-    world, r = td.get_world_size(group), td.get_rank(group)
+    world = td.get_world_size(group)
     if device is None:
         backend = td.get_backend(group)
         device = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-    on_gpu = device.type == 'cuda'
     externs = getattr(getattr(tape, 'tape', None), 'externs', None)
-    codec = DeviceCodec(eng) if (on_gpu and hasattr(eng, 'generate_compact') and not externs) else HostCodec(eng)
+    codec = DeviceCodec(eng) if (device.type == 'cuda' and hasattr(eng, 'generate_compact') and not externs) else HostCodec(eng)
     if chunks is None:
         chunks = int(os.environ.get('SDF_DIST_CHUNKS', '1'))
     C = max(1, min(int(chunks), 64 // max(world, 1)))
-
     s = int(batch_size)
     nb = (-(-len(X) // s)) * (-(-len(Y) // s)) * (-(-len(Z) // s))
-    hints = _hints_for(tape)
     key = (len(X), len(Y), len(Z), s, bool(sparse), world, C, type(codec).__name__)
-    if key in hints:
+    return device, world, C, nb, codec, key
+
+
+def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=None, chunks=None, lane=0, _caps=None, _attempt=0):
+    """enqueue one exchange step -- mesh this rank's shard(s) into slabs, all-gather, expand -- and return without
+    waiting for any of it; `collect_sharded` finishes the step.  Steps submitted on different `lane`s (0 / 1) run on
+    streams of their own, so step i + 1's meshing overlaps step i's collective."""
+    import contextlib
+    import torch
+    td = _dist()
+    device, world, C, nb, codec, key = _job(eng, tape, X, Y, Z, batch_size, sparse, device, group, chunks)
+    r = td.get_rank(group)
+    on_gpu = device.type == 'cuda'
+    hints = _hints_for(tape)
+    if _caps is not None:
+        cap_items, cap_tris, total_hint = _caps
+    elif key in hints:
         cap_items, cap_tris, total_hint = hints[key]
     else:                       # first call: a shard is a contiguous piece of the work list, at most 1/(world*C) of ALL batches
         cap_items = -(-nb // (world * C)) + 1
@@ -169,79 +186,95 @@ def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None,
         cap_tris = max(min(4096 * cap_items, (8 << 30) // (72 * world * C)), 1 << 16)
         total_hint = 0
 
+    st = ShardedStep()
+    st.eng, st.tape, st.args, st.device, st.group = eng, tape, (X, Y, Z, batch_size, sparse, chunks), device, group
+    st.world, st.C, st.nb, st.codec, st.key, st.caps, st.lane, st.attempt = world, C, nb, codec, key, (cap_items, cap_tris, total_hint), lane, _attempt
     # The step runs on a stream of its own that the engine adopts: its kernels, torch's allocations and the collective
     # are then ordered among themselves without a host round trip.  (torch's DEFAULT stream has the null handle, which
     # the engine's sdf_ctx_set_stream reads as "back to your own stream" -- adopting it would silently unorder the
-    # meshing kernels and the all-gather.)  The caller's stream waits for the step's at the end.
+    # meshing kernels and the all-gather.)  The caller's stream waits for the step's when the step is collected.
     adopted = False
-    outer = step_stream = None
+    st.outer = st.stream = None
     if on_gpu:
-        outer = torch.cuda.current_stream(device)
-        step_stream = _STREAMS.get(device.index)
-        if step_stream is None:
-            step_stream = _STREAMS[device.index] = torch.cuda.Stream(device)
-        step_stream.wait_stream(outer)
+        st.outer = torch.cuda.current_stream(device)
+        lanes = _STREAMS.setdefault(device.index, {})
+        st.stream = lanes.get(lane)
+        if st.stream is None:
+            st.stream = lanes[lane] = torch.cuda.Stream(device)
+        st.stream.wait_stream(st.outer)
         if hasattr(eng, 'set_stream'):
-            eng.set_stream(step_stream.cuda_stream)
+            eng.set_stream(st.stream.cuda_stream)
             adopted = True
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if on_gpu else None
-    import contextlib
+    st.events = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if on_gpu else None
+    ev = st.events
     try:
-        with (torch.cuda.stream(step_stream) if on_gpu else contextlib.nullcontext()):
-            for attempt in range(6):
-                sb = codec.slab_bytes(cap_items, cap_tris)
-                if ev:
-                    ev[0].record()
-                gathered, works, meshes = [], [], []
-                for j in range(C):
-                    mine = torch.empty(sb, dtype=torch.uint8, device=device)
-                    meshes.append(codec.pack(tape, X, Y, Z, batch_size, sparse, (r * C + j, world * C), mine, cap_items, cap_tris))
-                    g = torch.empty(world * sb, dtype=torch.uint8, device=device)
-                    if ev and j == C - 1:
-                        ev[1].record()
-                    # one collective per shard; with several shards the gather of shard j overlaps the meshing of shard j + 1
-                    works.append(td.all_gather_into_tensor(g, mine, group=group, async_op=C > 1))
-                    gathered.append((g, mine))
-                for w in works:
-                    if w is not None and C > 1:
-                        w.wait()
-                if ev:
-                    ev[2].record()
-                slabs = [gathered[j][0][rr * sb:(rr + 1) * sb] for rr in range(world) for j in range(C)]      # final order
-                out_cap = max(total_hint + total_hint // 8 + 4096, 1) if total_hint else world * C * cap_tris
-                out = torch.empty(out_cap * 9, dtype=torch.float64, device=device)
-                codec.expand(slabs, None, cap_items, cap_tris, out, out_cap)
-                if ev:
-                    ev[3].record()
-                # the ONE host synchronisation of the step: the gathered headers
-                heads = torch.stack([sl[:8 * HEADER_WORDS] for sl in slabs]).cpu().numpy().view(np.int64).reshape(len(slabs), HEADER_WORDS)
-                for m in meshes:
-                    if m is not None:
-                        m.close()
-                total = int(heads[:, H_TRIS].sum())
-                need_items, need_tris = int(heads[:, H_ITEMS].max()), int(heads[:, H_TRIS].max())
-                if (heads[:, H_OVERFLOW] & 2).any():
-                    raise RuntimeError('sdf_amd.dist: a rank reported a look-back timeout')
-                ok = not heads[:, H_OVERFLOW].any() and need_items <= cap_items and need_tris <= cap_tris and total <= out_cap
-                total_hint = total
-                if ok:
-                    break
-                # every rank sees the same headers, so every rank repeats the step with the same larger capacities
-                cap_items = max(cap_items, need_items + need_items // 8 + 16)
-                cap_tris = max(cap_tris, need_tris + need_tris // 8 + 1024)
-            else:
-                raise RuntimeError('sdf_amd.dist: slab capacities did not converge')
-            # capacities for the next call of this job: what this one needed, with some slack
-            hints[key] = (need_items + need_items // 8 + 16, need_tris + need_tris // 8 + 1024, total)
-            soup = out[:total * 9]
+        with (torch.cuda.stream(st.stream) if on_gpu else contextlib.nullcontext()):
+            sb = st.sb = codec.slab_bytes(cap_items, cap_tris)
+            if ev:
+                ev[0].record()
+            gathered, works, st.meshes = [], [], []
+            for j in range(C):
+                mine = torch.empty(sb, dtype=torch.uint8, device=device)
+                st.meshes.append(codec.pack(tape, X, Y, Z, batch_size, sparse, (r * C + j, world * C), mine, cap_items, cap_tris))
+                g = torch.empty(world * sb, dtype=torch.uint8, device=device)
+                if ev and j == C - 1:
+                    ev[1].record()
+                # one collective per shard; with several shards the gather of shard j overlaps the meshing of shard j + 1
+                works.append(td.all_gather_into_tensor(g, mine, group=group, async_op=C > 1))
+                gathered.append((g, mine))
+            for w in works:
+                if w is not None and C > 1:
+                    w.wait()
+            if ev:
+                ev[2].record()
+            st.slabs = [gathered[j][0][rr * sb:(rr + 1) * sb] for rr in range(world) for j in range(C)]      # final order
+            st.keep = gathered
+            st.out_cap = max(total_hint + total_hint // 8 + 4096, 1) if total_hint else world * C * cap_tris
+            st.out = torch.empty(st.out_cap * 9, dtype=torch.float64, device=device)
+            codec.expand(st.slabs, None, cap_items, cap_tris, st.out, st.out_cap)
+            if ev:
+                ev[3].record()
     finally:
         if adopted:
             eng.set_stream(0)
-        if on_gpu:
-            outer.wait_stream(step_stream)        # whatever the caller enqueues next sees the soup
-    if on_gpu:
-        soup.record_stream(outer)                 # (allocated on the step's stream, used on the caller's)
+    return st
 
+
+def collect_sharded(st):
+    """finish a step: the ONE host synchronisation (the gathered headers), the verdict on the capacities -- every rank
+    sees the same headers, so every rank repeats an undersized step with the same larger slabs -- and the result:
+    (soup: flat float64 torch tensor of 9*T values in reference order, merged stats dict)"""
+    import contextlib
+    import torch
+    on_gpu = st.device.type == 'cuda'
+    cap_items, cap_tris, _ = st.caps
+    with (torch.cuda.stream(st.stream) if on_gpu else contextlib.nullcontext()):
+        heads = torch.stack([sl[:8 * HEADER_WORDS] for sl in st.slabs]).cpu().numpy().view(np.int64).reshape(len(st.slabs), HEADER_WORDS)
+    for m in st.meshes:
+        if m is not None:
+            m.close()
+    st.meshes = []
+    total = int(heads[:, H_TRIS].sum())
+    need_items, need_tris = int(heads[:, H_ITEMS].max()), int(heads[:, H_TRIS].max())
+    if (heads[:, H_OVERFLOW] & 2).any():
+        raise RuntimeError('sdf_amd.dist: a rank reported a look-back timeout')
+    ok = not heads[:, H_OVERFLOW].any() and need_items <= cap_items and need_tris <= cap_tris and total <= st.out_cap
+    if not ok:
+        if st.attempt >= 5:
+            raise RuntimeError('sdf_amd.dist: slab capacities did not converge')
+        X, Y, Z, batch_size, sparse, chunks = st.args
+        caps = (max(cap_items, need_items + need_items // 8 + 16), max(cap_tris, need_tris + need_tris // 8 + 1024), total)
+        if on_gpu:
+            st.outer.wait_stream(st.stream)
+        return collect_sharded(submit_sharded(st.eng, st.tape, X, Y, Z, batch_size, sparse, st.device, st.group, chunks, st.lane,
+                                              _caps=caps, _attempt=st.attempt + 1))
+    # capacities for the next call of this job: what this one needed, with some slack
+    _hints_for(st.tape)[st.key] = (need_items + need_items // 8 + 16, need_tris + need_tris // 8 + 1024, total)
+    soup = st.out[:total * 9]
+    if on_gpu:
+        st.outer.wait_stream(st.stream)           # whatever the caller enqueues next sees the soup
+        soup.record_stream(st.outer)              # (allocated on the step's stream, used on the caller's)
+    world, C, nb = st.world, st.C, st.nb
     per_rank = heads[:, H_TRIS].reshape(world, C).sum(axis=1)
     merged = {
         'batches': nb, 'n_batches': nb,
@@ -250,17 +283,25 @@ def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None,
         'n_eval_voxels': int(heads[:, H_EVAL].sum()), 'n_ambiguous_cells': int(heads[:, H_AMBIGUOUS].sum()),
         'n_sampled_voxels': int(heads[:, H_SAMPLED].sum()), 'n_pruned_instrs': int(heads[:, H_PRUNED].sum()),
         'triangles': total, 'n_triangles': total, 'per_rank_triangles': [int(c) for c in per_rank],
-        'n_grid_voxels': len(X) * len(Y) * len(Z), 'n_retries': attempt, 'chunks': C,
-        'slab_bytes': sb, 'payload': 'f32 local + per-batch transform' if isinstance(codec, DeviceCodec) else 'f64 soup',
+        'n_grid_voxels': len(st.args[0]) * len(st.args[1]) * len(st.args[2]), 'n_retries': st.attempt, 'chunks': C,
+        'slab_bytes': st.sb, 'payload': 'f32 local + per-batch transform' if isinstance(st.codec, DeviceCodec) else 'f64 soup',
     }
     merged['n_empty'], merged['n_nonempty'] = merged['empty'], merged['nonempty']
-    if ev:      # (the headers' copy has synchronised the stream: the events are complete)
+    if st.events:      # (the headers' copy has synchronised the step's stream: the events are complete)
+        ev = st.events
         merged['ms_mesh'] = ev[0].elapsed_time(ev[1])
         merged['ms_exchange'] = ev[1].elapsed_time(ev[2])
         merged['ms_expand'] = ev[2].elapsed_time(ev[3])
     else:
         merged['ms_mesh'] = merged['ms_exchange'] = merged['ms_expand'] = 0.0
+    st.slabs = st.keep = None
     return soup, merged
+
+
+def generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=None, chunks=None):
+    """every rank returns (soup: flat float64 torch tensor of 9*T values on `device`, in
+    reference order; merged stats dict).  On GPUs the soup never leaves the device."""
+    return collect_sharded(submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device, group, chunks))
 
 
 def generate_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=None):

@@ -92,6 +92,12 @@ def _worker(rank, world, port, q, chunks=1):
         soup3, st3 = dist.generate_sharded_device(eng, f, X, Y, Z, 32, True, chunks=chunks)
         assert st3['n_retries'] >= 1 and st3['triangles'] == st['triangles']
         assert hashlib.sha256(soup3.numpy().tobytes()).hexdigest() == sha
+        # two steps in flight on lanes of their own (what bench.py does for N > 1), collected in order
+        a = dist.submit_sharded(eng, f, X, Y, Z, 32, True, chunks=chunks, lane=0)
+        b = dist.submit_sharded(eng, f, X, Y, Z, 32, True, chunks=chunks, lane=1)
+        for step in (a, b):
+            soup5, st5 = dist.collect_sharded(step)
+            assert hashlib.sha256(soup5.numpy().tobytes()).hexdigest() == sha and st5['n_retries'] == 0
         pts4, st4 = dist.generate_sharded(eng, f, X, Y, Z, 32, True)                            # the ndarray front
         assert hashlib.sha256(pts4.tobytes()).hexdigest() == sha
         q.put((rank, sha, len(pts) // 3,

@@ -368,6 +368,18 @@ def test_sharded_generate_over_rccl_single_rank(ns, eng):
             assert np.array_equal(got, want)
             assert st['ms_mesh'] > 0 and st['ms_exchange'] >= 0 and st['ms_expand'] > 0
             assert (st['batches'], st['skipped'] + st['empty'] + st['nonempty']) == (len(ref_kinds), len(ref_kinds))
+        # two steps in flight on lanes of their own (bench.py for N > 1), a different job on each, collected in order
+        g = fixtures.build('ex_blobby', ns)
+        Xb = np.arange(-4.4, 4.4, 8.8 / 130)
+        mb = eng.generate(g, Xb, Xb, Xb)
+        want_b = mb.points(); mb.close()
+        steps = [dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=torch.device('cuda', 0), lane=0),
+                 dist.submit_sharded(eng, eng.tape_for(g), Xb, Xb, Xb, 32, True, device=torch.device('cuda', 0), lane=1),
+                 dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=torch.device('cuda', 0), lane=0)]
+        for step, w in zip(steps, (want, want_b, want)):
+            soup, st = dist.collect_sharded(step)
+            torch.cuda.synchronize()
+            assert np.array_equal(soup.cpu().numpy().reshape(-1, 3), w) and st['triangles'] == len(w) // 3
         pts = f.generate(bounds=tuple(map(tuple, d['bounds'])), step=d['step'].tolist(), verbose=False)
         assert np.array_equal(pts, want)          # core.generate takes the sharded route when dist is up
     finally:
