@@ -476,6 +476,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 // consecutive lanes move consecutive coordinates (4-byte loads, 8-byte stores: whole cache lines per
                 // instruction on both sides); coordinate e belongs to axis e % 3, so the axis of a thread's k-th
                 // coordinate is (its first axis + k * (BLOCK % 3)) % 3.  Eight loads in flight per thread.
+                // (16-byte loads / stores, four coordinates per lane and instruction, with all of a batch's loads in flight
+                // before the first store: measured in r02, placing 16.7 -> 15.4 Mcycles, k_mesh unchanged within noise, and
+                // the 16 floats held per lane cost the headline variant its spill-free register allocation.  Rejected.)
                 static_assert(BLOCK % 3 == 1 || BLOCK % 3 == 2, "axis rotation below");
                 const int n9 = pend_total * 9;
                 const double sc[3] = {psc0, psc1, psc2}, of[3] = {pof0, pof1, pof2};
