@@ -233,13 +233,15 @@ def main():
             mesh.close()
         latency_ms = 1e3 * (time.perf_counter() - t1) / n_lat
 
-    # PCIe-inclusive variant (single GPU): same step + D2H of the soup into pageable host memory
+    # PCIe-inclusive variant (single GPU): same step + D2H of the soup into the ndarray `generate` returns (a recycled pinned block)
     incl = None
     if world == 1:
         sync()
-        t1 = time.perf_counter()
         n_incl = max(1, min(args.steps, 5))
-        for _ in range(n_incl):
+        pts = None
+        for i in range(2 + n_incl):          # (two untimed passes: the result blocks are pinned once, then recycled)
+            if i == 2:
+                t1 = time.perf_counter()
             mesh = eng.generate(tape, X, Y, Z, 32, True)
             pts = mesh.points()
             mesh.close()
