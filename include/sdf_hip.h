@@ -117,6 +117,11 @@ int sdf_generate_field(sdf_ctx *ctx, sdf_field_fn field, void *user, const doubl
                        const double *Z, int nz, int batch_size, int sparse, int64_t shard_index, int64_t shard_count,
                        sdf_mesh **out);
 
+/* `_estimate_bounds` (reference sdf/core.py:62-82: up to 32 rounds of a 16^3 probe grid shrinking from +-1e9) in one
+ * launch: h_out6 = x0, y0, z0, x1, y1, z1.  Fails -- with NumPy's message -- where the reference raises (a round in
+ * which no probe lies within half a cell diagonal of the surface). */
+int sdf_estimate_bounds(sdf_tape *tape, double *h_out6, int precision);
+
 /* Marching cubes of a C-order float32 volume (n0,n1,n2) at level 0: replaces `_marching_cubes`
  * (reference sdf/core.py:16-18 -> skimage.measure.marching_cubes(volume, 0)).  Writes up to
  * cap_tris triangles (9 float32 each: 3 vertices in volume index coordinates, reference soup

@@ -36,11 +36,15 @@ def _cartesian_product(*arrays):
 
 
 def _estimate_bounds(sdf):
-    """iterative 16^3 shrink from +-1e9 (reference sdf/core.py:62-82); the 4096 samples of
-    every round are evaluated on the device in float64"""
+    """iterative 16^3 shrink from +-1e9 (reference sdf/core.py:62-82), on the device"""
     from . import engine
     eng = engine.get_engine()
     tape = eng.tape_for(sdf)
+    if eng.precision == engine.PRECISION_F64:        # the whole loop in one launch (k_estimate_bounds)
+        b = eng.estimate_bounds(tape)
+        if b is not None:
+            return b
+    # (float32 sampling, and models with user closures: the reference's loop, the probes evaluated by eval_grid)
     s = 16
     x0 = y0 = z0 = -1e9
     x1 = y1 = z1 = 1e9

@@ -62,6 +62,7 @@ ABI = {
     'sdf_eval_points_host': (ctypes.c_int, [_vp, _f64p, _c_i64, ctypes.c_int, _f64p, ctypes.c_int]),
     'sdf_eval_grid_host': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p,
                                           ctypes.c_int, _f64p, ctypes.c_int]),
+    'sdf_estimate_bounds': (ctypes.c_int, [_vp, _f64p, ctypes.c_int]),
     'sdf_tape_extern_count': (ctypes.c_int, [_vp]),
     'sdf_eval_extern_points_host': (ctypes.c_int, [_vp, _f64p, _c_i64, ctypes.c_int, _f64p, ctypes.c_int]),
     'sdf_eval_points_extern_host': (ctypes.c_int, [_vp, _f64p, _c_i64, ctypes.c_int, _f64p, _f64p, ctypes.c_int]),
@@ -380,6 +381,21 @@ class Engine:
         _check(self.lib, self.lib.sdf_eval_points_extern_host(dt.handle, _dp(pts, _f64p), n, dim, _dp(vals, _f64p),
                                                               _dp(out, _f64p), self.precision))
         return out
+
+    def estimate_bounds(self, sdf):
+        """((x0, y0, z0), (x1, y1, z1)) of reference sdf/core.py:62-82 in one launch; None for a model with user
+        closures (the caller then runs the reference's loop around eval_grid)"""
+        dt = self.tape_for(sdf)
+        if dt.tape.externs:
+            return None
+        out = np.zeros(6, np.float64)
+        lib = self.lib
+        if lib.sdf_estimate_bounds(dt.handle, _dp(out, _f64p), self.precision) != 0:
+            msg = (lib.sdf_last_error() or b'').decode()
+            if msg.startswith('zero-size array'):
+                raise ValueError(msg)                       # what np.argwhere(...).max(axis=0) raises in the reference
+            raise SdfHipError(msg)
+        return (tuple(out[:3]), tuple(out[3:]))
 
     def eval_grid(self, sdf, X, Y, Z):
         dt = self.tape_for(sdf)

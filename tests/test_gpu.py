@@ -1048,3 +1048,14 @@ def test_slab_exchange_emulated_ranks(name, samples, ns, eng):
     assert (heads[:, 2] != 0).all() and int(heads[:, 0].sum()) == T        # flagged, and the true counts are reported
     for m in meshes:
         m.close()
+
+
+def test_estimate_bounds_failure_is_numpys(ns):
+    """a model no probe of the +-1e9 cube comes near: the reference dies in `where.max(axis=0)` of an empty array
+    (reference sdf/core.py:80); so does the device loop, with the same exception type"""
+    far = ns['sphere'](1).translate((1e12, 0, 0))
+    with pytest.raises(ValueError):
+        core._estimate_bounds(far)
+    # (and a model with a user closure takes the reference's host loop around the hybrid evaluation)
+    f = fixtures.build('custom_leaf_in_example', ns)
+    assert np.array_equal(np.array(core._estimate_bounds(f)), CUSTOM['bounds_custom_leaf_in_example'])
