@@ -499,11 +499,40 @@ __global__ __launch_bounds__(256) void k_expand(SlabPtrs slabs, int n_slabs, lon
         if (t1 > (unsigned long long)cap_tris) t1 = (unsigned long long)cap_tris;
         if (t0 >= t1) continue;
         const double of[3] = {xf[i * 6], xf[i * 6 + 1], xf[i * 6 + 2]}, sc[3] = {xf[i * 6 + 3], xf[i * 6 + 4], xf[i * 6 + 5]};
-        const unsigned long long e1 = t1 * 9ull;
-        for (unsigned long long e = t0 * 9ull + threadIdx.x; e < e1; e += 256) {
-            const int ax = (int)(e % 3ull);
-            const unsigned long long o = base * 9ull + e;
-            if (o < cap_out * 9ull) out[o] = (double)tris[e] * (ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2])) + (ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]));
+        // four coordinates per lane and pass (16-byte loads of the floats, 16-byte stores of the doubles), two passes'
+        // loads in flight before the first store; a work item's range starts at a multiple of 9 coordinates, so the
+        // axis of coordinate e is e % 3 whatever the item
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        const unsigned long long e_begin = t0 * 9ull, e1 = t1 * 9ull, lim = cap_out * 9ull;
+        for (unsigned long long e0 = e_begin + 4ull * threadIdx.x; e0 < e1; e0 += 2048) {
+            f4u f[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const unsigned long long e = e0 + 1024ull * k;
+                if (e + 3 < e1) f[k] = *reinterpret_cast<const f4u *>(tris + e);
+                else { f[k] = f4u{0.0f, 0.0f, 0.0f, 0.0f}; for (int j = 0; j < 3; j++) if (e + j < e1) f[k][j] = tris[e + j]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const unsigned long long e = e0 + 1024ull * k;
+                if (e >= e1) break;
+                const int ax = (int)(e % 3ull);        // axes of e .. e + 3: ax, ax + 1, ax + 2, ax (mod 3)
+                const double s0 = ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2]), o0 = ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]);
+                const double s1 = ax == 0 ? sc[1] : (ax == 1 ? sc[2] : sc[0]), o1 = ax == 0 ? of[1] : (ax == 1 ? of[2] : of[0]);
+                const double s2 = ax == 0 ? sc[2] : (ax == 1 ? sc[0] : sc[1]), o2 = ax == 0 ? of[2] : (ax == 1 ? of[0] : of[1]);
+                const double v0 = (double)f[k][0] * s0 + o0, v1 = (double)f[k][1] * s1 + o1, v2 = (double)f[k][2] * s2 + o2, v3 = (double)f[k][3] * s0 + o0;
+                const unsigned long long o = base * 9ull + e;
+                if (e + 3 < e1 && o + 3 < lim) {
+                    *reinterpret_cast<d2u *>(out + o) = d2u{v0, v1};
+                    *reinterpret_cast<d2u *>(out + o + 2) = d2u{v2, v3};
+                } else {
+                    if (o < lim) out[o] = v0;
+                    if (e + 1 < e1 && o + 1 < lim) out[o + 1] = v1;
+                    if (e + 2 < e1 && o + 2 < lim) out[o + 2] = v2;
+                    if (e + 3 < e1 && o + 3 < lim) out[o + 3] = v3;
+                }
+            }
         }
     }
 }

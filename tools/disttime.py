@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Fixed costs of the multi-GPU exchange path, measured on ONE GPU with a one-rank RCCL group (GPU box):
+    python tools/disttime.py [steps]
+The same job as bench.py (example at 512^3) through sdf_amd.dist: mesh into a slab, all-gather (one rank: a copy),
+k_expand, one host synchronisation per step; one and two steps in flight."""
+import os, sys, time, socket
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as td
+import bench
+from sdf_amd import core, engine, dist
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+with socket.socket() as s:
+    s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+torch.cuda.set_device(0)
+td.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+eng = engine.get_engine(0)
+f, _ = bench.build_model('example')
+tape = eng.tape_for(f)
+X, Y, Z, _ = core.grid_axes(bench.EXAMPLE_BOUNDS, samples=2 ** 27)
+dev = torch.device('cuda', 0)
+for chunks in (1, 2):
+    for depth in (1, 2):
+        for _ in range(5):
+            dist.generate_sharded_device(eng, tape, X, Y, Z, 32, True, device=dev, chunks=chunks)
+        torch.cuda.synchronize()
+        inflight, acc = [], []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            while len(inflight) >= depth:
+                acc.append(dist.collect_sharded(inflight.pop(0))[1])
+            inflight.append(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=dev, chunks=chunks, lane=i % 2))
+        while inflight:
+            acc.append(dist.collect_sharded(inflight.pop(0))[1])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        print('chunks %d, %d step(s) in flight: %.3f ms per step; device: mesh %.3f exchange %.3f expand %.3f ms; slab %.1f MB'
+              % (chunks, depth, 1e3 * dt, np.mean([a['ms_mesh'] for a in acc]), np.mean([a['ms_exchange'] for a in acc]),
+                 np.mean([a['ms_expand'] for a in acc]), acc[-1]['slab_bytes'] / 1e6), flush=True)
+td.destroy_process_group()
