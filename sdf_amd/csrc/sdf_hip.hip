@@ -192,7 +192,7 @@ __global__ __launch_bounds__(PRUNE_BLOCK) void k_prune_list(const uint32_t *__re
 // One workgroup per work item of this shard: which sampling tasks of the batch have to be evaluated
 // (cull_tasks, sdf_device.h).  The record goes to global memory; k_mesh picks it up.
 #define CULL_BLOCK 256
-template <bool FULL, bool RARE>
+template <bool FULL, bool RARE, int CB = CULL_BLOCK>
 __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
@@ -208,7 +208,7 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     const int b = __builtin_amdgcn_readfirstlane(worklist[w]);   // (uniform: the tape is then read with scalar loads)
     int ox, oy, oz, lx, ly, lz;
     batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-    for (int i = tid; i < 99; i += CULL_BLOCK) {
+    for (int i = tid; i < 99; i += CB) {
         if (i < 33) { if (i < lx) axes[i] = g.X[ox + i]; }
         else if (i < 66) { if (i - 33 < ly) axes[i] = g.Y[oy + i - 33]; }
         else if (i - 66 < lz) axes[i] = g.Z[oz + i - 66];
@@ -216,10 +216,10 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     __syncthreads();
     const uint32_t *wcode = code + (size_t)b * (size_t)tape_stride * 2;
     const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
-    const int ntl = cull_tasks<CULL_BLOCK, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd);
+    const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd);
     if (tid == 0) reinterpret_cast<unsigned short *>(scratch)[0] = ntl < 0 ? (unsigned short)0xFFFF : (unsigned short)ntl;
     __syncthreads();
-    for (int i = tid; i < CULL_RECORD / 4; i += CULL_BLOCK)
+    for (int i = tid; i < CULL_RECORD / 4; i += CB)
         reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD)[i] = reinterpret_cast<const unsigned *>(scratch)[i];
     __syncthreads();   // (axes / scratch are reused by the next work item)
     }
@@ -241,6 +241,15 @@ __global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                                                      unsigned char *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
     cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem);
+}
+// (experiment: the same with two waves per workgroup -- twelve workgroups fit a CU, every work item of the 512^3
+// example is resident at once instead of in two rounds)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean128(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
+                                                     const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
+                                                     int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
+                                                     unsigned char *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
+    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem);
 }
 
 // ordered compaction of the pending batches into the work list (single workgroup)
@@ -681,6 +690,7 @@ struct sdf_ctx {
     unsigned slot_seq = 0;
     int slot_streams = 1;             // SDF_SLOT_STREAMS=0: asynchronous calls stay on the context's stream (diagnostics)
     int cull_grid = 0;                // SDF_CULL_GRID: workgroups of k_cull (tuning; default 16 per compute unit)
+    int cull_block = 256;             // SDF_CULL_BLOCK=128: the two-wave variant of k_cull_lean (tuning)
 };
 
 struct sdf_tape {
@@ -821,6 +831,7 @@ static int ctx_init(sdf_ctx *c) {
     }
     if (const char *e = getenv("SDF_SLOT_STREAMS")) c->slot_streams = atoi(e);
     if (const char *e = getenv("SDF_CULL_GRID")) c->cull_grid = atoi(e);
+    if (const char *e = getenv("SDF_CULL_BLOCK")) c->cull_block = atoi(e);
     McTables t;
     memcpy(t.ntri, MC_NTRI, 256);
     memcpy(t.amb, MC_AMBIGUOUS, 256);
@@ -1320,11 +1331,13 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     if (culling) {
         if (m->cull.ensure((size_t)nb * CULL_RECORD)) return 1;
         const int ia_np = (int)std::max(t->n_p, 1u), ia_nd = (int)std::max(t->n_d, 1u);
-        const size_t ia_bytes = std::min<size_t>((size_t)CULL_BLOCK * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
-        const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         auto kc = t->full ? (t->ia_rare ? k_cull<true, true> : k_cull<true, false>) : (t->ia_rare ? k_cull<false, true> : k_cull_lean);
+        int cull_block = CULL_BLOCK;
+        if (c->cull_block == 128 && kc == k_cull_lean) { kc = k_cull_lean128; cull_block = 128; }
+        const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
+        const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kc, dim3((unsigned)std::min(nb, c->cull_grid > 0 ? c->cull_grid : c->n_cu * 16)), dim3(CULL_BLOCK), lds, st,
+        hipLaunchKernelGGL(kc, dim3((unsigned)std::min(nb, c->cull_grid > 0 ? c->cull_grid : c->n_cu * 16)), dim3(cull_block), lds, st,
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
                            (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
                            ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p);
