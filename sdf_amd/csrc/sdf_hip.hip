@@ -202,9 +202,11 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     unsigned char *scratch = cull_smem + 896;                                  // CULL_SCRATCH bytes
     double *ia_state = reinterpret_cast<double *>(cull_smem + 896 + CULL_SCRATCH);
     const int tid = threadIdx.x;
-    // (the host does not know the length of the work list: the grid is sized for the compute units, not for the batches,
-    // and every workgroup strides over this shard's work items)
-    for (int w = ctr->work_begin + (int)blockIdx.x; w < ctr->work_end; w += (int)gridDim.x) {
+    // (one workgroup per BATCH is launched -- the host does not know the length of the work list -- and the surplus ones
+    // leave here.  Striding over the list with a grid sized for the compute units was measured in r02: the loop costs the
+    // kernel 10 - 20 % (example 60 -> 70 us, gearlike 2^30 prepass 0.36 -> 0.43 ms), the empty workgroups nothing.)
+    const int w = ctr->work_begin + (int)blockIdx.x;
+    if (w >= ctr->work_end) return;
     const int b = __builtin_amdgcn_readfirstlane(worklist[w]);   // (uniform: the tape is then read with scalar loads)
     int ox, oy, oz, lx, ly, lz;
     batch_origin(g, b, ox, oy, oz, lx, ly, lz);
@@ -221,8 +223,6 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     __syncthreads();
     for (int i = tid; i < CULL_RECORD / 4; i += CB)
         reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD)[i] = reinterpret_cast<const unsigned *>(scratch)[i];
-    __syncthreads();   // (axes / scratch are reused by the next work item)
-    }
 }
 
 template <bool FULL, bool RARE>
@@ -689,7 +689,6 @@ struct sdf_ctx {
     CallSlot slots[SDF_CALL_SLOTS];
     unsigned slot_seq = 0;
     int slot_streams = 1;             // SDF_SLOT_STREAMS=0: asynchronous calls stay on the context's stream (diagnostics)
-    int cull_grid = 0;                // SDF_CULL_GRID: workgroups of k_cull (tuning; default 16 per compute unit)
     int cull_block = 256;             // SDF_CULL_BLOCK=128: the two-wave variant of k_cull_lean (tuning)
 };
 
@@ -830,7 +829,6 @@ static int ctx_init(sdf_ctx *c) {
         HIPCHK(hipStreamCreateWithFlags(&cs.stream, hipStreamNonBlocking));
     }
     if (const char *e = getenv("SDF_SLOT_STREAMS")) c->slot_streams = atoi(e);
-    if (const char *e = getenv("SDF_CULL_GRID")) c->cull_grid = atoi(e);
     if (const char *e = getenv("SDF_CULL_BLOCK")) c->cull_block = atoi(e);
     McTables t;
     memcpy(t.ntri, MC_NTRI, 256);
@@ -1337,7 +1335,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kc, dim3((unsigned)std::min(nb, c->cull_grid > 0 ? c->cull_grid : c->n_cu * 16)), dim3(cull_block), lds, st,
+        hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
                            (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
                            ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p);
