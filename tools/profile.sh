@@ -13,6 +13,7 @@ ARGS=${*:---steps 20 --warmup 3 --no-cpu-baseline}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+echo "$ARGS" > "$OUT/args.txt"
 export TMPDIR=/tmp
 cd /tmp
 run() {   # name, rocprof args...

@@ -47,8 +47,11 @@ def main():
         rows += list(csv.DictReader(open(p)))
     md = ['# rocprofv3 --kernel-trace --stats: %s' % tag, '']
     if bench_line:
-        md += ['command: `python bench.py --steps %d --warmup %d --no-cpu-baseline`  (workload: %s)' % (
-            bench_line['steps'], bench_line['warmup'], bench_line['config']['workload']), '',
+        args_file = os.path.join(raw, 'args.txt')
+        cmd = open(args_file).read().strip() if os.path.exists(args_file) else '--steps %d --warmup %d --no-cpu-baseline' % (
+            bench_line['steps'], bench_line['warmup'])
+        md += ['command: `python bench.py %s`  (workload: %s; %d step(s) in flight)' % (
+            cmd, bench_line['config']['workload'], bench_line.get('steps_in_flight', 1)), '',
             'bench line of the profiled run: value %.4g %s, %.4f ms/step, in-bench HIP-event k_mesh %.4f ms' % (
                 bench_line['value'], bench_line['unit'], bench_line['ms_per_step'], bench_line['roofline']['kernel_ms']), '']
     md += ['| kernel | calls | total ms | avg us | min us | max us | % |', '|---|---|---|---|---|---|---|']
