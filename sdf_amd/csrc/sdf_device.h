@@ -894,7 +894,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
 }
 
 // host-side launcher of one (T, FULL) family, defined in sdf_mesh_inst.hip (one translation
-// unit per family so the variants compile in parallel).  slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (4,4), 4 = (8,8)
+// unit per family so the variants compile in parallel).  slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (2,4), 4 = (4,4), 5 = (8,8)
 // register files; shape: 0 = 1024 threads x 1 sample per lane, 1 = 512 x 2, anything else = 1024 x 2 (where instantiated).
 #define SDF_DECLARE_MESH_LAUNCH(NAME, T) \
     int NAME(int slots, int shape, int grid, size_t lds, hipStream_t stream, const uint32_t *code, const T *consts, const MeshArgs &a)

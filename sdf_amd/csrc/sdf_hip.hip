@@ -1165,13 +1165,16 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     const size_t list_cap = std::min<size_t>((c->lds_max - list_off) / 4, 16384);
     a.list_off = (int)list_off; a.list_cap = (int)list_cap;
     const size_t lds = list_off + list_cap * 4;
-    // the smallest register-file variant that holds the tape's slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (4,4), 4 = (8,8)
+    // the first register-file variant that holds the tape's slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (2,4), 4 = (4,4), 5 = (8,8)
+    static const uint32_t kFile[6][2] = {{1, 1}, {2, 2}, {4, 2}, {2, 4}, {4, 4}, {8, 8}};
     const uint32_t np = std::max(t->n_p, 1u), nd = std::max(t->n_d, 1u);
-    int slots = (np <= 1 && nd <= 1) ? 0 : (np <= 2 && nd <= 2) ? 1 : (np <= 4 && nd <= 2) ? 2 : (np <= 4 && nd <= 4) ? 3 : 4;
-    if (c->mesh_slots >= 0) slots = std::max(slots, std::min(c->mesh_slots, 4));     // (tuning: force a larger file)
+    int slots = 5;
+    for (int k = 5; k >= 0; k--) if (np <= kFile[k][0] && nd <= kFile[k][1]) slots = k;
+    if (c->mesh_slots >= 0 && c->mesh_slots <= 5 && np <= kFile[c->mesh_slots][0] && nd <= kFile[c->mesh_slots][1])
+        slots = c->mesh_slots;                                                        // (tuning: another file that fits)
     // measured (profiles/r02b_shapes.txt): 4 waves per SIMD beat 2, and two samples per lane beat one
     // wherever that shape exists; the 8-slot file runs 1024 x 1
-    int shape = slots <= 3 ? 3 : 0;
+    int shape = slots <= 4 ? 3 : 0;
     if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
     int rc;
     if (precision == SDF_PRECISION_F64)

@@ -16,7 +16,7 @@ static int launch_one(int grid, size_t lds, hipStream_t stream, const uint32_t *
 
 // Register-file variants (NP point slots, ND distance slots) and launch shapes (threads x samples per lane).  Fewer
 // slots = fewer live VGPRs around the interpreter: the host picks the SMALLEST variant that holds the tape's slots
-// (exact fits for the BASELINE models: example / gearlike (1,1), blobby / knurling (2,2), weave (4,2), pawn (4,4)).
+// (exact fits for the models at hand: example / gearlike (1,1), blobby / knurling (2,2), weave (4,2), pawn (2,4)).
 // Only the shapes the host can select are instantiated: 1024 x 2 is the measured optimum wherever it exists
 // (profiles/r02b_shapes.txt: weave 2^33 47.5 ms vs 59.5 ms at 1024 x 1 and 64.7 ms at 512 x 2, although the 4-slot
 // variants spill at 128 VGPRs); the 8-slot file does not fit two samples per lane at 1024 threads at all.
@@ -34,7 +34,8 @@ SDF_DECLARE_MESH_LAUNCH(MESH_NAME, MESH_T) {
     case 0: return launch_one<1, 1, 2, 1024>(grid, lds, stream, code, consts, a);
     case 1: return launch_shape3<2, 2>(shape, grid, lds, stream, code, consts, a);
     case 2: return launch_one<4, 2, 2, 1024>(grid, lds, stream, code, consts, a);
-    case 3: return launch_shape3<4, 4>(shape, grid, lds, stream, code, consts, a);
+    case 3: return launch_one<2, 4, 2, 1024>(grid, lds, stream, code, consts, a);
+    case 4: return launch_shape3<4, 4>(shape, grid, lds, stream, code, consts, a);
     default: return shape == 1 ? launch_one<8, 8, 2, 512>(grid, lds, stream, code, consts, a)
                                : launch_one<8, 8, 1, 1024>(grid, lds, stream, code, consts, a);
     }
