@@ -72,6 +72,10 @@ int sdf_ctx_set_prune(sdf_ctx *ctx, int enabled);
  * interval excludes the surface are not sampled (SDF_CULL=0 sets the initial state; results are
  * identical either way) */
 int sdf_ctx_set_cull(sdf_ctx *ctx, int enabled);
+/* how sdf_generate meshes: 0 = one kernel (ordered look-back + parking inside the sampling kernel), 1 = three kernels
+ * (sample + classify / number the triangles / emit), -1 = the library's choice by the tape's length (default; the
+ * environment variable SDF_MESH_TWOPASS sets the initial state).  Results are identical either way. */
+int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
 int sdf_ctx_synchronize(sdf_ctx *ctx);
 
 /* Upload an op tape produced by sdf_amd/tape.py (2 x uint32 per instruction, float64 constants).

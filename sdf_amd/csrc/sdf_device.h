@@ -44,12 +44,14 @@ struct MeshCounters {   // zeroed before every k_mesh run
     unsigned int n_empty, n_nonempty;
     unsigned long long n_ambiguous;
     unsigned long long n_sampled;     // samples that went through the interpreter (the others were decided by intervals)
-    unsigned long long total;         // triangles of this shard (written by the workgroup of the last work item)
+    unsigned long long total;         // triangles of this shard (written by the workgroup of the last work item / by k_scan_items)
+    unsigned long long cell_cursor;   // two-pass meshing: surface-cell records / triangle-list entries handed out so far
+    unsigned long long list_cursor;
     // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
     // and this shard's slice of it, so k_mesh can start without a host round trip
     int nwork, work_begin, work_end, pad_;
 };
-enum { MESH_COUNTERS_RESET_BYTES = 56 };   // the part of MeshCounters cleared before every k_mesh run
+enum { MESH_COUNTERS_RESET_BYTES = 72 };   // the part of MeshCounters cleared before every k_mesh run
 
 struct GridDesc {
     const double *X, *Y, *Z;   // device copies of the np.arange axes
@@ -84,6 +86,20 @@ struct MeshArgs {
     int compact;
     double *xf;
     int xf_cap;
+    // two-pass meshing (k_mesh = sample + classify, k_scan_items, k_emit2 = triangles): per work item a descriptor,
+    // per surface cell a 36-byte record (cell, configuration, its 8 corner samples), per triangle a 4-byte entry
+    // (record << 4 | triangle of the cell) -- handed out from two arenas by atomic cursors, in any order
+    int twopass;
+    struct ItemDesc *desc;
+    unsigned *cells;                    // 9 dwords per record
+    unsigned *tlist;
+    unsigned long long cells_cap, tlist_cap;
+};
+
+struct ItemDesc {
+    unsigned ntri, ncells;
+    unsigned long long list_off, cell_off;   // ~0: the arenas were full (flagged: the call is repeated with larger ones)
+    double xf[6];                            // offset[3], scale[3] of `points * scale + offset` (reference sdf/core.py:58-60)
 };
 
 // dynamic LDS layout of k_mesh
@@ -408,7 +424,7 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
 #define SDF_SOUP_STORE(PTR, VAL) (*(PTR) = (VAL))
 #endif
 
-template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK>
+template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK, bool TWOPASS = false>
 __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
     typedef Vec<T, NS> V;
     constexpr int RPT = 1024 / BLOCK;   // (i0, i1) rows of cells per thread (a tile has <= 32 x 32 rows)
@@ -634,7 +650,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // (wave 0 first asks for the predecessors' status words -- of this batch and of the parked one --
         // so that the answers arrive while the cells are counted)
         unsigned long long pre_own = 0, pre_pend = 0;
-        if (tid < 64) {
+        if (tid < 64 && !TWOPASS) {
             pre_own = lookback_prefetch(a.status, w, work_begin);
             if (pq_count > 0) pre_pend = lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin);
         }
@@ -688,6 +704,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // behind them.) ----
         bool list_ready = false;
         constexpr int MESH_CELL_CHUNKS = 2;
+        unsigned cinfo[MESH_CELL_CHUNKS];
+        int cn[MESH_CELL_CHUNKS], coff[MESH_CELL_CHUNKS];
+        bool per_cell = false;            // the per-cell path ran (cinfo / cn / coff are valid)
         if (ncells <= MESH_CELL_CHUNKS * BLOCK && (size_t)a.list_cap >= (size_t)MESH_CELL_CHUNKS * BLOCK) {
             SDF_UNROLL
             for (int k = 0; k < RPT; k++) {
@@ -701,8 +720,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 }
             }
             __syncthreads();
-            unsigned cinfo[MESH_CELL_CHUNKS];
-            int cn[MESH_CELL_CHUNKS], coff[MESH_CELL_CHUNKS];
+            per_cell = true;
             SDF_UNROLL
             for (int k = 0; k < MESH_CELL_CHUNKS; k++) {
                 const int sidx = tid + k * BLOCK;
@@ -730,11 +748,15 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (k * BLOCK < ncells) { coff[k] += block_exclusive_scan<BLOCK>(n, wave_sums, tot); total += tot; }   // (uniform)
                 cinfo[k] = info; cn[k] = n;
             }
-            if (total <= a.list_cap) {
+            if (TWOPASS) {
+                list_ready = true;        // (no list in LDS: the entries go to the arena below)
+            } else if (total <= a.list_cap) {
                 SDF_UNROLL
                 for (int k = 0; k < MESH_CELL_CHUNKS; k++)
                     for (int j = 0; j < cn[k]; j++) list[coff[k] + j] = cinfo[k] | (unsigned)j;
                 list_ready = true;        // (made visible by the barriers of the allocation below)
+            } else {
+                per_cell = false;
             }
         }
         SDF_UNROLL for (int k = 0; k < RPT; k++) { row_tris[k] = 0; row_off[k] = 0; }
@@ -770,7 +792,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
         }
         // ---- the batch's count is public from here on; bookkeeping that needs no position ----
-        if (tid < 64) publish_count(a.status, w, work_begin, (unsigned long long)total);
+        if (tid < 64 && !TWOPASS) publish_count(a.status, w, work_begin, (unsigned long long)total);
         if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
             double *xf = a.xf + (size_t)(w - work_begin) * 6;
             xf[0] = axes[0]; xf[1] = axes[33]; xf[2] = axes[66];
@@ -782,6 +804,83 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             a.kinds[b] = total ? 2 : 1;
         }
         if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
+        if constexpr (TWOPASS) {
+            // ---- two-pass meshing: this kernel stops at the classification.  What k_emit2 needs to produce the batch's
+            // triangles -- per surface cell its configuration and 8 corner samples, per triangle which cell and which of
+            // the cell's triangles -- goes to the arenas, at offsets handed out by two atomic cursors (no order, hence
+            // nothing to wait for: no look-back, no parking, no placing); k_scan_items then numbers the triangles in
+            // work-list order and k_emit2 writes them, at full occupancy, straight to their final place ----
+            if (tid == 0) {
+                unsigned long long cb = 0, lb = 0;
+                if (total) {
+                    cb = atomicAdd(&a.ctr->cell_cursor, (unsigned long long)ncells);
+                    lb = atomicAdd(&a.ctr->list_cursor, (unsigned long long)total);
+                    if (cb + (unsigned long long)ncells > a.cells_cap || lb + (unsigned long long)total > a.tlist_cap) {
+                        atomicOr(&a.ctr->overflow, 1u);
+                        cb = lb = ~0ull;
+                    }
+                }
+                reinterpret_cast<unsigned long long *>(bcast + 2)[0] = cb;
+                reinterpret_cast<unsigned long long *>(bcast + 4)[0] = lb;
+                ItemDesc d;
+                d.ntri = (unsigned)total; d.ncells = (unsigned)ncells; d.list_off = lb; d.cell_off = cb;
+                d.xf[0] = axes[0]; d.xf[1] = axes[33]; d.xf[2] = axes[66];
+                d.xf[3] = axes[1] - axes[0]; d.xf[4] = axes[34] - axes[33]; d.xf[5] = axes[67] - axes[66];
+                a.desc[w] = d;
+            }
+            __syncthreads();
+            const unsigned long long cell_base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
+            const unsigned long long list_base = reinterpret_cast<unsigned long long *>(bcast + 4)[0];
+            if (total && cell_base != ~0ull) {
+                auto put_cell = [&](unsigned long long idx, unsigned info, int i0, int i1, int i2) {
+                    unsigned *rec = a.cells + idx * 9ull;
+                    const float *corner = vol + i0 * lyz + i1 * lz + i2;
+                    rec[0] = info;
+                    SDF_UNROLL
+                    for (int q = 0; q < 8; q++)     // corner q = 4 * o0 + 2 * o1 + o2
+                        rec[1 + q] = __float_as_uint(corner[(q >> 2) * lyz + ((q >> 1) & 1) * lz + (q & 1)]);
+                };
+                if (per_cell) {
+                    SDF_UNROLL
+                    for (int k = 0; k < MESH_CELL_CHUNKS; k++) {
+                        const int sidx = tid + k * BLOCK;
+                        if (sidx < ncells) {
+                            const int cell = (int)(cinfo[k] >> 13);
+                            put_cell(cell_base + (unsigned long long)sidx, cinfo[k], cell >> 10, (cell >> 5) & 31, cell & 31);
+                            for (int j = 0; j < cn[k]; j++) a.tlist[list_base + (unsigned long long)(coff[k] + j)] = ((unsigned)sidx << 4) | (unsigned)j;
+                        }
+                    }
+                } else {
+                    SDF_UNROLL
+                    for (int k = 0; k < RPT; k++) {
+                        if (row_tris[k] == 0) continue;
+                        const int r = tid + k * BLOCK;
+                        const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
+                        unsigned m = row_mask[k];
+                        int sidx = row_cell0[k], pos = row_off[k];
+                        while (m) {
+                            const int i2 = __ffs((int)m) - 1;
+                            m &= m - 1u;
+                            const unsigned cfg = cell_config(row_bits[k], i2);
+                            const unsigned en = ntri_lds[cfg];
+                            int n = (int)(en & 7u);
+                            if (en & 128u) {
+                                double lv[8];
+                                int off;
+                                mc33_load_cell(vol + i0 * lyz + i1 * lz + i2, lyz, lz, lv);
+                                n = mc33_cell(lv, a.mc->mc33, &off);
+                            }
+                            put_cell(cell_base + (unsigned long long)sidx, ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((en & 128u) << 5) | (cfg << 4), i0, i1, i2);
+                            for (int j = 0; j < n; j++, pos++) a.tlist[list_base + (unsigned long long)pos] = ((unsigned)sidx << 4) | (unsigned)j;
+                            sidx++;
+                        }
+                    }
+                }
+            }
+            SDF_PROF(2);
+            __syncthreads();   // vol / bcast are reused by the next batch
+            continue;
+        }
         // ---- a parked batch is older than this one: its predecessors have long published, place it ----
         { const long long tp0 = a.prof ? clock64() : 0;
         place_parked(pre_pend, false);
@@ -897,7 +996,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
 // unit per family so the variants compile in parallel).  slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (2,4), 4 = (4,4), 5 = (8,8)
 // register files; shape: 0 = 1024 threads x 1 sample per lane, 1 = 512 x 2, anything else = 1024 x 2 (where instantiated).
 #define SDF_DECLARE_MESH_LAUNCH(NAME, T) \
-    int NAME(int slots, int shape, int grid, size_t lds, hipStream_t stream, const uint32_t *code, const T *consts, const MeshArgs &a)
+    int NAME(int slots, int shape, int twopass, int grid, size_t lds, hipStream_t stream, const uint32_t *code, const T *consts, const MeshArgs &a)
 SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f64, double);
 SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f64_full, double);
 SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f32, float);

@@ -444,6 +444,94 @@ __global__ __launch_bounds__(256) void k_field_emit(const McTables *__restrict__
     }
 }
 
+// ---- two-pass meshing: the second and third kernel (the first is k_mesh with MeshArgs.twopass) ----
+// k_scan_items: the work items' triangle counts -> their inclusive prefix in work-list (= reference) order, written as
+// the same look-back words the one-pass kernel leaves (sdf_mesh_batch_offsets, k_pack_slab read them), and the total.
+__global__ __launch_bounds__(1024) void k_scan_items(const ItemDesc *__restrict__ desc, MeshCounters *__restrict__ ctr,
+                                                     unsigned long long *__restrict__ status) {
+    __shared__ int wave_sums[16];
+    const int w_begin = ctr->work_begin, w_end = ctr->work_end;
+    unsigned long long base = 0;
+    for (int start = w_begin; start < w_end; start += 1024) {
+        const int w = start + (int)threadIdx.x;
+        const int v = w < w_end ? (int)desc[w].ntri : 0;
+        int tot;
+        const int pos = block_exclusive_scan<1024>(v, wave_sums, tot);
+        if (w < w_end) status[w] = MESH_FLAG_PFX | (base + (unsigned long long)pos + (unsigned long long)v);
+        base += (unsigned long long)tot;
+    }
+    if (threadIdx.x == 0) ctr->total = base;
+}
+
+// k_emit2: one lane per TRIANGLE of the whole soup (256 consecutive triangles per workgroup, whatever work items they
+// belong to): find the triangle's work item in the prefix (binary search over the look-back words, L1-resident), fetch
+// its entry and its cell's record, run the three edge interpolations on the record's 8 corner samples (mc_vertex /
+// mc33_triangle -- the very functions the one-pass kernel runs on its LDS tile, with the strides of a 2 x 2 x 2 volume),
+// pass the 9 local coordinates through LDS so that consecutive lanes store consecutive coordinates, and write
+// `points * scale + offset` (reference sdf/core.py:58-60) of the triangle's own work item -- or, for the multi-GPU
+// exchange, the local float32 form -- straight to the final place.  The grid covers the soup's CAPACITY (the host does
+// not know the count); workgroups beyond the total leave at once.
+__global__ __launch_bounds__(256) void k_emit2(MeshArgs a) {
+    __shared__ float tri[256 * 9];
+    __shared__ unsigned recs[256 * 9];
+    __shared__ int item_of[256];
+    const unsigned long long total = a.ctr->total;
+    const unsigned long long T0 = (unsigned long long)blockIdx.x * 256ull;
+    if (T0 >= total) return;
+    if (total > a.out_cap || (a.ctr->overflow & 1u)) {       // the soup or the arenas were too small: flagged, the call is repeated
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&a.ctr->overflow, 1u);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const int nt = (int)min(256ull, total - T0);
+    const int w_begin = a.ctr->work_begin, w_end = a.ctr->work_end;
+    if (tid < nt) {
+        const unsigned long long T = T0 + (unsigned long long)tid;
+        int lo = w_begin, hi = w_end - 1;                    // the smallest w whose inclusive prefix exceeds T
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((a.status[mid] & MESH_VAL_MASK) > T) hi = mid; else lo = mid + 1;
+        }
+        const int w = lo;
+        const ItemDesc *d = a.desc + w;
+        const unsigned ntri = d->ntri;
+        const unsigned long long t = T - ((a.status[w] & MESH_VAL_MASK) - ntri);
+        const unsigned e = a.tlist[d->list_off + t];
+        const unsigned *src = a.cells + (d->cell_off + (unsigned long long)(e >> 4)) * 9ull;
+        unsigned *rec = recs + tid * 9;
+        for (int q = 0; q < 9; q++) rec[q] = src[q];
+        const unsigned info = rec[0];
+        const int j = (int)(e & 15u), cfg = (int)((info >> 4) & 255u), cell = (int)(info >> 13);
+        const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
+        const float *corner = reinterpret_cast<const float *>(rec + 1);          // 2 x 2 x 2 samples: strides 4, 2, 1
+        float *o = tri + tid * 9;
+        if (info & 4096u) {
+            float tmp[9];
+            mc33_triangle(corner, 4, 2, i0, i1, i2, a.mc->mc33, j, tmp);
+            for (int q = 0; q < 9; q++) o[q] = tmp[q];
+        } else {
+            const signed char *tt = &a.mc->tri[0][0] + cfg * 16 + 3 * j;
+            float v[3];
+            for (int q = 0; q < 3; q++) { mc_vertex(corner, 4, 2, i0, i1, i2, tt[q], v); o[3 * q] = v[0]; o[3 * q + 1] = v[1]; o[3 * q + 2] = v[2]; }
+        }
+        item_of[tid] = w;
+    }
+    __syncthreads();
+    const int n9 = nt * 9;
+    const unsigned long long at = T0 * 9ull;                  // (a multiple of 9: coordinate e of the workgroup belongs to axis e % 3)
+    if (a.compact) {
+        float *dst = reinterpret_cast<float *>(a.out) + at;
+        for (int e = tid; e < n9; e += 256) dst[e] = tri[e];
+    } else {
+        double *dst = a.out + at;
+        for (int e = tid; e < n9; e += 256) {
+            const double *xf = a.desc[item_of[e / 9]].xf;
+            const int ax = e % 3;
+            dst[e] = (double)tri[e] * xf[3 + ax] + xf[ax];
+        }
+    }
+}
+
 // ---- the multi-GPU exchange unit ("slab"): what one rank contributes to the all-gather (sdf_amd/dist.py) ----
 // [header 128 B | prefix[cap_items] u64 | xf[cap_items][6] f64 | tris[cap_tris][9] f32], a fixed capacity per call so
 // that ONE all-gather of equal-sized slabs moves everything: the counts travel in the header, the triangles in
@@ -690,6 +778,7 @@ struct sdf_ctx {
     unsigned slot_seq = 0;
     int slot_streams = 1;             // SDF_SLOT_STREAMS=0: asynchronous calls stay on the context's stream (diagnostics)
     int cull_block = 256;             // SDF_CULL_BLOCK=128: the two-wave variant of k_cull_lean (tuning)
+    int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
 };
 
 struct sdf_tape {
@@ -712,6 +801,7 @@ struct sdf_mesh {
     sdf_stats st = {};
     GridDesc g = {};
     DevBuf axes, kinds, worklist, status, out, prune, tapes, cull;
+    DevBuf desc, cellrecs, trilist;   // two-pass meshing: per work item / per surface cell / per triangle (sdf_device.h ItemDesc)
     bool pruned = false;
     hipStream_t stream = nullptr;  // the stream the generating call ran on (the context's, or a call slot's lane)
     DevBuf counters;               // this call's MeshCounters block (pooled in the context)
@@ -830,6 +920,7 @@ static int ctx_init(sdf_ctx *c) {
     }
     if (const char *e = getenv("SDF_SLOT_STREAMS")) c->slot_streams = atoi(e);
     if (const char *e = getenv("SDF_CULL_BLOCK")) c->cull_block = atoi(e);
+    if (const char *e = getenv("SDF_MESH_TWOPASS")) c->twopass = atoi(e);
     McTables t;
     memcpy(t.ntri, MC_NTRI, 256);
     memcpy(t.amb, MC_AMBIGUOUS, 256);
@@ -883,6 +974,12 @@ int sdf_ctx_set_prune(sdf_ctx *c, int enabled) {
 int sdf_ctx_set_cull(sdf_ctx *c, int enabled) {
     if (!c) return fail("sdf_ctx_set_cull: ctx is NULL");
     c->cull = enabled ? 1 : 0;
+    return 0;
+}
+
+int sdf_ctx_set_twopass(sdf_ctx *c, int mode) {
+    if (!c) return fail("sdf_ctx_set_twopass: ctx is NULL");
+    c->twopass = mode < 0 ? -1 : (mode ? 1 : 0);
     return 0;
 }
 
@@ -1178,11 +1275,11 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
     int rc;
     if (precision == SDF_PRECISION_F64)
-        rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, grid, lds, st, (const uint32_t *)code, t->d_c64, a)
-                     : sdf_launch_mesh_f64(slots, shape, grid, lds, st, (const uint32_t *)code, t->d_c64, a);
+        rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a)
+                     : sdf_launch_mesh_f64(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a);
     else
-        rc = t->full ? sdf_launch_mesh_f32_full(slots, shape, grid, lds, st, (const uint32_t *)code, t->d_c32, a)
-                     : sdf_launch_mesh_f32(slots, shape, grid, lds, st, (const uint32_t *)code, t->d_c32, a);
+        rc = t->full ? sdf_launch_mesh_f32_full(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c32, a)
+                     : sdf_launch_mesh_f32(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c32, a);
     if (rc) return fail(std::string("k_mesh launch: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
@@ -1379,6 +1476,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     for (int attempt = 0;; attempt++) {
         MeshArgs a;
         a.compact = 0; a.xf = nullptr; a.xf_cap = 0;
+        a.twopass = 0; a.desc = nullptr; a.cells = nullptr; a.tlist = nullptr; a.cells_cap = a.tlist_cap = 0;
         if (compact) {
             const SlabLayout L(slab_items, cap_out);
             a.out = reinterpret_cast<double *>((unsigned char *)d_out + L.tris_off); a.out_cap = (unsigned long long)cap_out;
@@ -1417,11 +1515,37 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
         a.tape_stride = pruning ? tape_stride : 0;
         a.n_instr = (int)n_instr;
+        // One pass or two?  The one-pass kernel orders the soup by a look-back over the batches' counts and parks what
+        // cannot be placed yet; a workgroup whose four park slots are full waits for the oldest one's predecessors.
+        // When the sampling time of a batch varies by an order of magnitude -- long tapes that the interval prepass
+        // prunes very differently from batch to batch: weave at 2^33 -- that wait was HALF of the kernel (SDF_MESH_PROF,
+        // r02: placing 14.4 of 29.6 G cycles), and cutting the ordering out of the sampling kernel wins 40 % (48.3 ->
+        // 28.8 ms).  With even batches the one-pass kernel hides its triangle traffic behind other workgroups'
+        // arithmetic, which three kernels in a row cannot (example 0.283 vs 0.305 ms, pawn 0.47 vs 0.58): the tape's
+        // length decides (SDF_MESH_TWOPASS=0 / 1 overrides).
+        const bool twopass = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
+        if (twopass) {
+            // the arenas of the two-pass scheme: a surface cell carries at least one triangle, so the soup's capacity
+            // bounds both (a call whose arenas turn out too small is flagged and repeated like one whose soup is)
+            const size_t cap_t = (size_t)a.out_cap;
+            if (m->desc.bytes < (size_t)nb * sizeof(ItemDesc) || m->cellrecs.bytes < cap_t * 36 || m->trilist.bytes < cap_t * 4) quiet = false;
+            if (m->desc.ensure((size_t)nb * sizeof(ItemDesc)) || m->cellrecs.ensure(cap_t * 36) || m->trilist.ensure(cap_t * 4)) return 1;
+            a.twopass = 1; a.desc = (ItemDesc *)m->desc.p; a.cells = (unsigned *)m->cellrecs.p; a.tlist = (unsigned *)m->trilist.p;
+            a.cells_cap = a.tlist_cap = (unsigned long long)cap_t;
+        }
         if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, st));
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         const bool own_start = attempt > 0 || a.prof || !quiet;   // (something was enqueued, or the host waited, since ev[2])
         if (own_start) HIPCHK(hipEventRecord(cs.e3, st));
         if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs, st)) return 1;
+        if (a.twopass) {
+            hipLaunchKernelGGL(k_scan_items, dim3(1), dim3(1024), 0, st, (const ItemDesc *)m->desc.p, (MeshCounters *)m->counters.p,
+                               (unsigned long long *)m->status.p);
+            const unsigned long long emit_blocks = (a.out_cap + 255ull) / 256ull;
+            if (emit_blocks > 0x7fffffffull) return fail("sdf_generate: soup capacity too large for one k_emit2 launch");
+            hipLaunchKernelGGL(k_emit2, dim3((unsigned)std::max<unsigned long long>(emit_blocks, 1ull)), dim3(256), 0, st, a);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipEventRecord(cs.e4, st));
         if (compact) {
             const unsigned pack_blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((slab_items + 255) / 256, 1), 1024);
@@ -1982,7 +2106,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
         m->out.p = nullptr; m->out.bytes = 0;
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
-    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull}) b->release();
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->desc, &m->cellrecs, &m->trilist}) b->release();
     (void)hipFree(m->weld_pts); (void)hipFree(m->weld_inv);
     delete m;
     return 0;

@@ -5,9 +5,9 @@
 
 namespace sdfk {
 
-template <int NP, int ND, int NS, int BLOCK>
+template <int NP, int ND, int NS, int BLOCK, bool TWOPASS = false>
 static int launch_one(int grid, size_t lds, hipStream_t stream, const uint32_t *code, const MESH_T *consts, const MeshArgs &a) {
-    auto fn = k_mesh<MESH_T, (MESH_FULL != 0), NP, ND, NS, BLOCK>;
+    auto fn = k_mesh<MESH_T, (MESH_FULL != 0), NP, ND, NS, BLOCK, TWOPASS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(BLOCK), lds, stream, code, consts, a);
@@ -30,6 +30,16 @@ static int launch_shape3(int shape, int grid, size_t lds, hipStream_t stream, co
 }
 
 SDF_DECLARE_MESH_LAUNCH(MESH_NAME, MESH_T) {
+    if (twopass) {   // sample + classify only (k_scan_items and k_emit2 follow): the default shape of each register file
+        switch (slots) {
+        case 0: return launch_one<1, 1, 2, 1024, true>(grid, lds, stream, code, consts, a);
+        case 1: return launch_one<2, 2, 2, 1024, true>(grid, lds, stream, code, consts, a);
+        case 2: return launch_one<4, 2, 2, 1024, true>(grid, lds, stream, code, consts, a);
+        case 3: return launch_one<2, 4, 2, 1024, true>(grid, lds, stream, code, consts, a);
+        case 4: return launch_one<4, 4, 2, 1024, true>(grid, lds, stream, code, consts, a);
+        default: return launch_one<8, 8, 1, 1024, true>(grid, lds, stream, code, consts, a);
+        }
+    }
     switch (slots) {
     case 0: return launch_one<1, 1, 2, 1024>(grid, lds, stream, code, consts, a);
     case 1: return launch_shape3<2, 2>(shape, grid, lds, stream, code, consts, a);

@@ -52,6 +52,7 @@ ABI = {
     'sdf_ctx_set_stream': (ctypes.c_int, [_vp, _vp]),
     'sdf_ctx_set_prune': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_cull': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'sdf_ctx_set_twopass': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_synchronize': (ctypes.c_int, [_vp]),
     'sdf_tape_create': (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _f64p, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
@@ -329,6 +330,11 @@ class Engine:
     def set_cull(self, enabled):
         """interval culling of cell groups inside a batch on / off (default on; results are identical)"""
         _check(self.lib, self.lib.sdf_ctx_set_cull(self.ctx, int(bool(enabled))))
+
+    def set_twopass(self, mode):
+        """meshing scheme: 0 one kernel (look-back + parking), 1 three kernels (sample / number / emit), -1 the
+        library's choice by the tape's length (default); results are identical"""
+        _check(self.lib, self.lib.sdf_ctx_set_twopass(self.ctx, int(mode)))
 
     def synchronize(self):
         _check(self.lib, self.lib.sdf_ctx_synchronize(self.ctx))

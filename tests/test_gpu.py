@@ -1059,3 +1059,68 @@ def test_estimate_bounds_failure_is_numpys(ns):
     # (and a model with a user closure takes the reference's host loop around the hybrid evaluation)
     f = fixtures.build('custom_leaf_in_example', ns)
     assert np.array_equal(np.array(core._estimate_bounds(f)), CUSTOM['bounds_custom_leaf_in_example'])
+
+
+# ---- the two meshing schemes (one kernel with look-back + parking / sample + number + emit) give the same soup ----
+
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 22), ('ex_gearlike', 2 ** 22), ('ex_blobby', 2 ** 23), ('ex_weave', 2 ** 22),
+                                          ('ex_knurling', 2 ** 21), ('ex_pawn', 2 ** 21), ('ex_custbox', 2 ** 18), ('wireframe_box', 2 ** 18)])
+def test_one_pass_and_two_pass_meshing_agree(name, samples, ns, eng):
+    import torch
+    f = fixtures.build(name, ns)
+    if name == 'ex_custbox':
+        bounds = ((-7.0, -4.0, -0.5), (7.0, 4.0, 2.5))
+    else:
+        bounds = tuple(map(tuple, BOUNDS[name]))
+    X, Y, Z, _ = core.grid_axes(bounds, samples=samples)
+    res = []
+    try:
+        for mode in (0, 1):
+            eng.set_twopass(mode)
+            for sparse in (True, False):
+                m = eng.generate(f, X, Y, Z, 32, sparse)
+                res.append((mode, sparse, m.points(), m.kinds(), m.stats(), m.batch_offsets()))
+                m.close()
+            # a caller buffer that is too small: flagged, repeated into library memory, guard intact
+            t = res[-2][4]['triangles']
+            if t > 10:
+                small = torch.full((9 * (t // 2) + 9,), -7.0, dtype=torch.float64, device='cuda:0')
+                m = eng.generate(f, X, Y, Z, 32, True, out_ptr=small.data_ptr(), out_cap=t // 2)
+                assert not m.emitted and m.n_triangles == t and np.array_equal(m.points(), res[-2][2])
+                assert float(small[-1]) == -7.0
+                m.close()
+    finally:
+        eng.set_twopass(-1)
+    for sparse in (True, False):
+        a = [r for r in res if r[0] == 0 and r[1] == sparse][0]
+        b = [r for r in res if r[0] == 1 and r[1] == sparse][0]
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[5], b[5])
+        for k in ('triangles', 'skipped', 'empty', 'nonempty', 'n_eval_voxels', 'n_ambiguous_cells', 'n_sampled_voxels', 'n_pruned_instrs'):
+            assert a[4][k] == b[4][k], k
+
+
+def test_two_pass_meshing_full_size_and_slabs(ns, oracle_lib, eng):
+    """the two-pass scheme at BASELINE config 2: the reference's soup hash; and as the source of exchange slabs"""
+    import torch
+    f = fixtures.build('ex_example', ns)
+    d = np.load(os.path.join(GOLDEN, 'full_c2_example_s27.npz'))
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
+    eng.set_twopass(1)
+    try:
+        m = eng.generate(f, X, Y, Z)
+        pts = m.points(); m.close()
+        assert hashlib.sha256(pts.tobytes()).digest() == d['sha256'].tobytes()
+        T, n = len(pts) // 3, 3
+        cap_items, cap_tris = 1744 // n + 2, T // n + T // 4
+        sb = eng.slab_bytes(cap_items, cap_tris)
+        buf = torch.zeros(n * sb, dtype=torch.uint8, device='cuda:0')
+        out = torch.empty(9 * T, dtype=torch.float64, device='cuda:0')
+        torch.cuda.synchronize()
+        meshes = [eng.generate_compact(f, X, Y, Z, 32, True, (i, n), buf.data_ptr() + i * sb, cap_items, cap_tris) for i in range(n)]
+        eng.expand_slabs([buf.data_ptr() + i * sb for i in range(n)], cap_items, cap_tris, out.data_ptr(), T)
+        eng.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(-1, 3), pts)
+        for mm in meshes:
+            mm.close()
+    finally:
+        eng.set_twopass(-1)
