@@ -103,7 +103,7 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _lib_lock = threading.Lock()
