@@ -202,3 +202,20 @@ def test_pinned_result_buffers_fall_back_to_pageable_memory_without_a_device():
     assert big.shape == (1 << 18, 3) and big.dtype == np.float64
     big[:] = 1.0                                                       # writable either way
     assert float(big.sum()) == 3.0 * (1 << 18)
+
+
+def test_long_tapes_carry_no_prune_info_and_big_pools_fail_cleanly(ns):
+    """operand ranges are 16-bit and only used for tapes of <= 256 instructions -- longer tapes must lower
+    without them (they ran into an OverflowError beyond 65535 instructions); a constant pool beyond the 24-bit offset
+    of an instruction is a ValueError, not a bare assert"""
+    from sdf_amd import tape
+    parts = [ns['sphere'](0.1).translate((0.01 * i, 0, 0)) for i in range(200)]
+    t = tape.lower(ns['union'](*parts))
+    assert t.n_instr > tape.PRUNE_MAX_INSTR and t.rstart is None and t.lstart is None
+    small = tape.lower(ns['union'](*parts[:20]))
+    assert small.rstart is not None and len(small.rstart) == small.n_instr
+    lw = tape._Lowering()
+    lw.consts.extend([0.0] * (tape.COFF_MASK - 6))
+    lw.emit('L_SPHERE', consts=(1.0, 0.0, 0.0, 0.0))            # still addressable
+    with pytest.raises(ValueError):
+        lw.emit('L_SPHERE', consts=(1.0, 0.0, 0.0, 0.0))
