@@ -191,6 +191,10 @@ def main():
             torch.cuda.synchronize()
 
     mesh_ms, exch_ms = [], []
+    if world == 1:          # set-up, not a step: every call lane allocates its staging on first use (hundreds of MB each)
+        for _ in range(DEPTH + 1):
+            one_step()
+        sync()
     for _ in range(args.warmup):
         one_step()
     sync()

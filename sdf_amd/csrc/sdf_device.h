@@ -103,7 +103,12 @@ struct ItemDesc {
 };
 
 // dynamic LDS layout of k_mesh
-enum { MESH_PARK_DEPTH = 4 };   // batches a workgroup may have parked before it has to wait for the oldest one's place
+// batches a workgroup may have parked before it has to wait for the oldest one's place.  Four were enough for even
+// batches; where the sampling time of a batch varies by an order of magnitude (weave at 2^33: a 244-instruction tape
+// of which the interval prepass leaves 10 % here and 60 % there) a workgroup with four full slots spent HALF of the
+// kernel waiting for a slow predecessor of its oldest parked batch (SDF_MESH_PROF: placing 14.4 of 29.6 G cycles):
+// depth 4: 48.3 ms, 8: 33.6, 16: 27.7, 32: 27.1 ms; the example, gearlike, blobby, pawn do not care, knurling gains 4 %.
+enum { MESH_PARK_DEPTH = 16 };
 enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_PEND = 1184, MESH_LDS_VOL = 1184 + 64 * MESH_PARK_DEPTH };   // PEND: per parked batch 6 doubles + 2 ints
 
 __device__ __forceinline__ void batch_origin(const GridDesc &g, int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {

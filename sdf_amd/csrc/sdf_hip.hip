@@ -752,6 +752,8 @@ struct CallSlot {
     DevBuf park;                                                          // ... and its k_mesh staging slots
 };
 #define SDF_PARK_TRIS 8192   // triangles per workgroup staging slot of k_mesh (36 bytes each); larger batches wait instead
+                             // (16 slots per workgroup: 1.2 GB per call lane, allocated on a lane's first use; with 4096
+                             // per slot weave at 2^33 has batches that cannot park: 30.3 instead of 27.7 ms)
 
 struct sdf_ctx {
     int device = 0;
@@ -778,7 +780,7 @@ struct sdf_ctx {
     unsigned slot_seq = 0;
     int slot_streams = 1;             // SDF_SLOT_STREAMS=0: asynchronous calls stay on the context's stream (diagnostics)
     int cull_block = 256;             // SDF_CULL_BLOCK=128: the two-wave variant of k_cull_lean (tuning)
-    int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
+    int twopass = -1;                 // SDF_MESH_TWOPASS=1: k_mesh / k_scan_items / k_emit2 instead of the one-pass k_mesh (look-back + parking); -1, 0: one pass
 };
 
 struct sdf_tape {
@@ -1515,15 +1517,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
         a.tape_stride = pruning ? tape_stride : 0;
         a.n_instr = (int)n_instr;
-        // One pass or two?  The one-pass kernel orders the soup by a look-back over the batches' counts and parks what
-        // cannot be placed yet; a workgroup whose four park slots are full waits for the oldest one's predecessors.
-        // When the sampling time of a batch varies by an order of magnitude -- long tapes that the interval prepass
-        // prunes very differently from batch to batch: weave at 2^33 -- that wait was HALF of the kernel (SDF_MESH_PROF,
-        // r02: placing 14.4 of 29.6 G cycles), and cutting the ordering out of the sampling kernel wins 40 % (48.3 ->
-        // 28.8 ms).  With even batches the one-pass kernel hides its triangle traffic behind other workgroups'
-        // arithmetic, which three kernels in a row cannot (example 0.283 vs 0.305 ms, pawn 0.47 vs 0.58): the tape's
-        // length decides (SDF_MESH_TWOPASS=0 / 1 overrides).
-        const bool twopass = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
+        // One pass or two?  The one-pass kernel (look-back + parking inside the sampling kernel) is the default: with its
+        // sixteen park slots per workgroup it is as fast as the two-pass scheme where that one shines (weave at 2^33:
+        // 27.7 vs 28.0 ms) and 7 - 20 % faster elsewhere (it hides its triangle traffic behind other workgroups'
+        // arithmetic, which three kernels in a row cannot).  The two-pass scheme (sdf_ctx_set_twopass(1) /
+        // SDF_MESH_TWOPASS=1) moves 1.6 x the algorithmic bytes instead of 2.4 x and needs no ordering protocol.
+        const bool twopass = c->twopass > 0;
         if (twopass) {
             // the arenas of the two-pass scheme: a surface cell carries at least one triangle, so the soup's capacity
             // bounds both (a call whose arenas turn out too small is flagged and repeated like one whose soup is)
