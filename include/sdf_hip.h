@@ -73,7 +73,7 @@ int sdf_ctx_set_prune(sdf_ctx *ctx, int enabled);
  * identical either way) */
 int sdf_ctx_set_cull(sdf_ctx *ctx, int enabled);
 /* how sdf_generate meshes: 0 = one kernel (ordered look-back + parking inside the sampling kernel), 1 = three kernels
- * (sample + classify / number the triangles / emit), -1 = the library's choice (default: one kernel; the
+ * (sample + classify / number the triangles / emit), -1 = the library's choice by the tape's length (default; the
  * environment variable SDF_MESH_TWOPASS sets the initial state).  Results are identical either way. */
 int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
 int sdf_ctx_synchronize(sdf_ctx *ctx);

@@ -780,7 +780,7 @@ struct sdf_ctx {
     unsigned slot_seq = 0;
     int slot_streams = 1;             // SDF_SLOT_STREAMS=0: asynchronous calls stay on the context's stream (diagnostics)
     int cull_block = 256;             // SDF_CULL_BLOCK=128: the two-wave variant of k_cull_lean (tuning)
-    int twopass = -1;                 // SDF_MESH_TWOPASS=1: k_mesh / k_scan_items / k_emit2 instead of the one-pass k_mesh (look-back + parking); -1, 0: one pass
+    int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
 };
 
 struct sdf_tape {
@@ -1517,12 +1517,13 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
         a.tape_stride = pruning ? tape_stride : 0;
         a.n_instr = (int)n_instr;
-        // One pass or two?  The one-pass kernel (look-back + parking inside the sampling kernel) is the default: with its
-        // sixteen park slots per workgroup it is as fast as the two-pass scheme where that one shines (weave at 2^33:
-        // 27.7 vs 28.0 ms) and 7 - 20 % faster elsewhere (it hides its triangle traffic behind other workgroups'
-        // arithmetic, which three kernels in a row cannot).  The two-pass scheme (sdf_ctx_set_twopass(1) /
-        // SDF_MESH_TWOPASS=1) moves 1.6 x the algorithmic bytes instead of 2.4 x and needs no ordering protocol.
-        const bool twopass = c->twopass > 0;
+        // One pass or two?  The one-pass kernel (look-back + parking inside the sampling kernel) is 7 - 20 % faster on
+        // short tapes: it hides its triangle traffic behind other workgroups' arithmetic, which three kernels in a row
+        // cannot.  On long tapes (weave at 2^33, 244 instructions) the two schemes tie -- 27.5 vs 28.0 ms -- and the
+        // two-pass one moves a third of the bytes (9 GB against 25 GB per call: no parking, and the 4-slot sampling
+        // kernel spills less without the emit phases): the tape's length decides (sdf_ctx_set_twopass / SDF_MESH_TWOPASS
+        // override).
+        const bool twopass = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
         if (twopass) {
             // the arenas of the two-pass scheme: a surface cell carries at least one triangle, so the soup's capacity
             // bounds both (a call whose arenas turn out too small is flagged and repeated like one whose soup is)
