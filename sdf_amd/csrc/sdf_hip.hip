@@ -1471,7 +1471,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             // a guess, not a need (the overflow re-run finds the exact size): never more than half the free memory
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                cap = std::min<unsigned long long>(cap, std::max<unsigned long long>(free_b / 2 / 72, 1ull << 16));
+                cap = std::min<unsigned long long>(cap, std::max<unsigned long long>(free_b / 2 / (72 + 40), 1ull << 16));   // (+ 40 B per triangle: the two-pass arenas)
         }
     }
     float ms = 0;
