@@ -8,8 +8,14 @@ namespace sdfk {
 template <int NP, int ND, int NS, int BLOCK, bool TWOPASS = false>
 static int launch_one(int grid, size_t lds, hipStream_t stream, const uint32_t *code, const MESH_T *consts, const MeshArgs &a) {
     auto fn = k_mesh<MESH_T, (MESH_FULL != 0), NP, ND, NS, BLOCK, TWOPASS>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    static size_t lds_set[16] = {};      // per device: the dynamic-LDS limit this instantiation was last raised to
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || lds_set[dev] < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0 && dev < 16) lds_set[dev] = lds;
+    }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(BLOCK), lds, stream, code, consts, a);
     return (int)hipGetLastError();
 }
