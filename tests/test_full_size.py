@@ -156,3 +156,19 @@ def test_c4_weave_at_2_33_sampled_batches_match_oracle(ns, oracle_lib, eng):
     finally:
         eng.set_prune(True); eng.set_cull(True)
     assert h_on.digest() == h_off.digest()
+    # the other meshing scheme (a 244-instruction tape takes the two-pass scheme by default: force one pass, whose
+    # sixteen-deep park FIFO this size exercises like no other): the same soup
+    eng.set_twopass(0)
+    try:
+        m = eng.generate(f, X, Y, Z, 32, True)
+        try:
+            assert m.stats()['triangles'] == st['triangles'] and np.array_equal(m.kinds(), kinds)
+            assert np.array_equal(m.batch_offsets(), offs)
+            h_one = hashlib.sha256()
+            for t0 in range(0, st['triangles'], step):
+                h_one.update(m.points_range(t0, min(step, st['triangles'] - t0)).tobytes())
+        finally:
+            m.close()
+    finally:
+        eng.set_twopass(-1)
+    assert h_one.digest() == h_on.digest()
