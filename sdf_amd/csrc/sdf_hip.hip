@@ -482,12 +482,26 @@ __global__ __launch_bounds__(256) void k_emit2(MeshArgs a) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&a.ctr->overflow, 1u);
         return;
     }
+    __shared__ int w_range[2];
     const int tid = threadIdx.x;
     const int nt = (int)min(256ull, total - T0);
     const int w_begin = a.ctr->work_begin, w_end = a.ctr->work_end;
+    // the work item of a triangle T: the smallest w whose inclusive prefix exceeds T.  The workgroup's 256 consecutive
+    // triangles span one or two items as a rule: two lanes search the whole prefix (for the first and the last
+    // triangle), everybody else only between their answers
+    if (tid < 2) {
+        const unsigned long long T = tid == 0 ? T0 : T0 + (unsigned long long)(nt - 1);
+        int lo = w_begin, hi = w_end - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((a.status[mid] & MESH_VAL_MASK) > T) hi = mid; else lo = mid + 1;
+        }
+        w_range[tid] = lo;
+    }
+    __syncthreads();
     if (tid < nt) {
         const unsigned long long T = T0 + (unsigned long long)tid;
-        int lo = w_begin, hi = w_end - 1;                    // the smallest w whose inclusive prefix exceeds T
+        int lo = w_range[0], hi = w_range[1];
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if ((a.status[mid] & MESH_VAL_MASK) > T) hi = mid; else lo = mid + 1;
