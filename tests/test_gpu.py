@@ -1124,3 +1124,13 @@ def test_two_pass_meshing_full_size_and_slabs(ns, oracle_lib, eng):
             mm.close()
     finally:
         eng.set_twopass(-1)
+
+
+def test_integration_md_bindings_work_as_written():
+    """INTEGRATION.md sections 2 / 2b (the reference-side ctypes bindings) as a program: tools/integration_check.py"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(GOLDEN))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'integration_check.py')], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'bindings ok' in out.stdout
