@@ -72,17 +72,23 @@ __global__ __launch_bounds__(256) void k_eval_points_ext(const uint32_t *__restr
     if (!dump) out[i] = (double)v;
 }
 
-// `_estimate_bounds` (reference sdf/core.py:62-82) as ONE launch of one workgroup: up to 32 rounds of a 16^3 probe grid
+// `_estimate_bounds` (reference sdf/core.py:62-82) as ONE launch (four workgroups): up to 32 rounds of a 16^3 probe grid
 // (np.linspace per axis: lo + i * step, the last sample forced to hi), threshold = |d| / 2, the box of the samples with
 // |f| <= threshold, grown by half a probe cell -- float64 throughout, operation by operation like the reference (and
 // the oracle's restatement).  The host loop it replaces paid a kernel launch, two copies and a synchronisation per
 // round: 3 ms per model, 40 % of a default-resolution `f.save`.  out[0..6) = lo, hi; out[6] = 1 when a round found no
 // sample within its threshold (the reference raises there: `where.max` of an empty array).
 template <typename T, bool FULL>
-__global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__restrict__ code, const T *__restrict__ consts, double *__restrict__ out) {
+__global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__restrict__ code, const T *__restrict__ consts, double *__restrict__ out,
+                                                          int *__restrict__ work) {
+    // FOUR workgroups share a round's 4096 probes (one per lane) and keep in lockstep through a counter in device
+    // memory (they are co-resident on any gfx950: four workgroups, 256 compute units); every workgroup carries the
+    // whole state -- the same arithmetic on the same reduced indices -- so nothing but the hit box is exchanged:
+    // work[0] = arrivals at the barrier, work[1 + 6 * round ..] = the round's hit box, as maxima of 16 - index
+    // (lower corner) and index + 1 (upper corner) so that a zeroed buffer is "no hit"
     __shared__ double ax[3][16];
     __shared__ double lo[3], hi[3], d[3], thr, prev;
-    __shared__ int mn[3], mx[3], stop;
+    __shared__ int box[6], stop;
     const int tid = threadIdx.x;
     if (tid < 3) { lo[tid] = -1e9; hi[tid] = 1e9; }
     if (tid == 0) { prev = -1.0; stop = 0; }
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__rest
             const double step = (hi[a] - lo[a]) / 15.0;
             ax[a][i] = i == 15 ? hi[a] : lo[a] + (double)i * step;
         }
-        if (tid < 3) { mn[tid] = 16; mx[tid] = -1; }
+        if (tid < 6) box[tid] = 0;
         __syncthreads();
         if (tid == 0) {
             for (int a = 0; a < 3; a++) d[a] = ax[a][1] - ax[a][0];
@@ -102,26 +108,43 @@ __global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__rest
             prev = t; thr = t;
         }
         __syncthreads();
-        if (stop) break;
-        for (int q = tid; q < 4096; q += 1024) {
+        if (stop) break;                                       // (every workgroup takes the same decision)
+        {
+            const int q = (int)blockIdx.x * 1024 + tid;
             const int i = q >> 8, j = (q >> 4) & 15, k = q & 15;
             const double v = (double)run_tape1<T, FULL>(code, consts, (T)ax[0][i], (T)ax[1][j], (T)ax[2][k]);
             if (fabs(v) <= thr) {
-                atomicMin(&mn[0], i); atomicMax(&mx[0], i); atomicMin(&mn[1], j); atomicMax(&mx[1], j);
-                atomicMin(&mn[2], k); atomicMax(&mx[2], k);
+                atomicMax(&box[0], 16 - i); atomicMax(&box[1], 16 - j); atomicMax(&box[2], 16 - k);
+                atomicMax(&box[3], i + 1); atomicMax(&box[4], j + 1); atomicMax(&box[5], k + 1);
             }
         }
         __syncthreads();
-        if (mx[0] < 0) { if (tid == 0) out[6] = 1.0; return; }
+        int *slot = work + 1 + 6 * it;
+        if (tid < 6 && box[tid]) atomicMax(&slot[tid], box[tid]);
+        __syncthreads();
+        if (tid == 0) {                                         // the round's barrier over the four workgroups
+            __threadfence();
+            atomicAdd(&work[0], 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(&work[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * (it + 1) && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
+            __threadfence();
+        }
+        __syncthreads();
+        if (tid < 6) box[tid] = __hip_atomic_load(&slot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (box[3] == 0) { if (blockIdx.x == 0 && tid == 0) out[6] = 1.0; return; }       // no probe within the threshold
         if (tid < 3) {
             const double l0 = lo[tid];
-            hi[tid] = l0 + (double)mx[tid] * d[tid] + d[tid] / 2;
-            lo[tid] = l0 + (double)mn[tid] * d[tid] - d[tid] / 2;
+            const int mn = 16 - box[tid], mx = box[3 + tid] - 1;
+            hi[tid] = l0 + (double)mx * d[tid] + d[tid] / 2;
+            lo[tid] = l0 + (double)mn * d[tid] - d[tid] / 2;
         }
         __syncthreads();
     }
-    if (tid < 3) { out[tid] = lo[tid]; out[3 + tid] = hi[tid]; }
-    if (tid == 0) out[6] = 0.0;
+    if (blockIdx.x == 0) {
+        if (tid < 3) { out[tid] = lo[tid]; out[3 + tid] = hi[tid]; }
+        if (tid == 0) out[6] = 0.0;
+    }
 }
 
 // reference sdf/core.py:28-43.  16 lanes per batch: lane 0 = centre, lanes 1..8 = corners in
@@ -1160,8 +1183,10 @@ int sdf_estimate_bounds(sdf_tape *t, double *h_out6, int precision) {
     if (t->n_extern) return fail("sdf_estimate_bounds: the tape reads user closures (L_EXTERN): probe it through the *_extern_* entry points");
     sdf_ctx *c = t->ctx;
     HIPCHK(hipSetDevice(c->device));
-    if (c->scratch_out.ensure(64)) return 1;
-    LAUNCH_TAPE(k_estimate_bounds, dim3(1), dim3(1024), 0, t, precision, (double *)c->scratch_out.p);
+    if (c->scratch_out.ensure(2048)) return 1;
+    int *work = reinterpret_cast<int *>((char *)c->scratch_out.p + 64);
+    HIPCHK(hipMemsetAsync(work, 0, (1 + 6 * 32) * sizeof(int), c->stream));
+    LAUNCH_TAPE(k_estimate_bounds, dim3(4), dim3(1024), 0, t, precision, (double *)c->scratch_out.p, work);
     HIPCHK(hipGetLastError());
     double h[7];
     HIPCHK(hipMemcpyAsync(h, c->scratch_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
