@@ -337,6 +337,74 @@ int main() {
         printf("leaf boxes %ld, sign decided for %ld\n", boxes, decided);
         CHECK(decided * 2 > boxes, "the leaf intervals decide fewer than half of the boxes: are the forms reached?");
     }
+    // ---- the voxel-grid leaf (L_GRID3D: mesh.py:96-105): trilinear look-up in scipy's operation order, box estimator ----
+    {
+        auto grid_value = [&](const double *c, double x, double y, double z) -> double {       // sdf_interp.h grid3d_lookup + L_L_GRID3D
+            const int n[3] = {(int)c[0], (int)c[1], (int)c[2]};
+            const double bg = c[3];
+            const double *g[3] = {c + 10, c + 10 + n[0], c + 10 + n[0] + n[1]};
+            const double *vox = c + 10 + n[0] + n[1] + n[2];
+            const double qx = fabs(x - c[4]) - c[7], qy = fabs(y - c[5]) - c[8], qz = fabs(z - c[6]) - c[9];
+            auto mx = [](double a, double b) { return (a >= b || a != a) ? a : b; };
+            auto mn = [](double a, double b) { return (a < b || a != a) ? a : b; };
+            const double e = std::sqrt((mx(qx, 0) * mx(qx, 0) + mx(qy, 0) * mx(qy, 0)) + mx(qz, 0) * mx(qz, 0)) + mn(mx(mx(qx, qy), qz), 0);
+            const double p[3] = {x, y, z};
+            int idx[3]; double w[3]; bool oob = false;
+            for (int a = 0; a < 3; a++) {
+                int lo = 0, hi = n[a];
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (g[a][mid] < p[a]) lo = mid + 1; else hi = mid; }
+                int i = lo - 1; if (i < 0) i = 0; if (i > n[a] - 2) i = n[a] - 2;
+                idx[a] = i; w[a] = (p[a] - g[a][i]) / (g[a][i + 1] - g[a][i]);
+                oob = oob || p[a] < g[a][0] || p[a] > g[a][n[a] - 1];
+            }
+            double acc = 0.0;
+            for (int q = 0; q < 8; q++) {
+                const int o0 = q >> 2, o1 = (q >> 1) & 1, o2 = q & 1;
+                double wt = o0 ? w[0] : 1 - w[0];
+                wt *= o1 ? w[1] : 1 - w[1];
+                wt *= o2 ? w[2] : 1 - w[2];
+                acc += vox[((size_t)(idx[0] + o0) * n[1] + (idx[1] + o1)) * n[2] + (idx[2] + o2)] * wt;
+            }
+            const double d = oob ? bg : acc;
+            return e > bg ? e : d;
+        };
+        long decided = 0, boxes = 0;
+        for (int it = 0; it < 40000; it++) {
+            const int n0 = 4 + (int)(rng() % 9), n1 = 4 + (int)(rng() % 9), n2 = 4 + (int)(rng() % 9);
+            static double c[10 + 36 + 12 * 12 * 12];
+            c[0] = n0; c[1] = n1; c[2] = n2;
+            const double bg = pick(0.05, 0.4);
+            c[3] = bg;
+            c[4] = pick(-0.1, 0.1); c[5] = pick(-0.1, 0.1); c[6] = pick(-0.1, 0.1);             // estimator box: centre, half size
+            c[7] = pick(0.5, 0.9); c[8] = pick(0.5, 0.9); c[9] = pick(0.5, 0.9);
+            double *g = c + 10;
+            const int nn[3] = {n0, n1, n2};
+            for (int a = 0; a < 3; a++) { double t = -1.0; for (int i = 0; i < nn[a]; i++) { g[i] = t; t += pick(0.05, 2.2 / nn[a] * 1.6); } g += nn[a]; }   // non-uniform, ascending
+            const double cx0 = pick(-0.3, 0.3), cy0 = pick(-0.3, 0.3), cz0 = pick(-0.3, 0.3), rr = pick(0.3, 0.7);
+            const double *gx = c + 10, *gy = gx + n0, *gz = gy + n1;
+            for (int i = 0; i < n0; i++) for (int j = 0; j < n1; j++) for (int k = 0; k < n2; k++) {
+                double d = std::sqrt((gx[i] - cx0) * (gx[i] - cx0) + (gy[j] - cy0) * (gy[j] - cy0) + (gz[k] - cz0) * (gz[k] - cz0)) - rr;
+                if (it % 7 == 0) d = pick(-bg, bg);                                                  // noise now and then
+                g[((size_t)i * n1 + j) * n2 + k] = (double)(float)std::fmin(std::fmax(d, -bg), bg);   // a narrow band, float32 voxels
+            }
+            const double sz = std::pow(10.0, pick(-3.0, 0.2));
+            const double cx = it % 4 ? pick(-1.6, 1.6) : gx[rng() % n0], cy = it % 5 ? pick(-1.6, 1.6) : gy[rng() % n1], cz = it % 6 ? pick(-1.6, 1.6) : gz[rng() % n2];
+            Ival X{cx - sz * U(rng), cx + sz * U(rng)}, Y{cy - sz * U(rng), cy + sz * U(rng)}, Z{cz - sz * U(rng), cz + sz * U(rng)};
+            if (it % 9 == 0) X.hi = X.lo;
+            const Ival v = ia_leaf_rare(OP_L_GRID3D, c, X, Y, Z);
+            boxes++; if (v.lo > 0 || v.hi < 0) decided++;
+            for (int k = 0; k < 14; k++) {
+                const double px = k & 1 ? (k < 8 ? X.lo : pick(X.lo, X.hi)) : (k < 8 ? X.hi : pick(X.lo, X.hi));
+                const double py = k & 2 ? (k < 8 ? Y.lo : pick(Y.lo, Y.hi)) : (k < 8 ? Y.hi : pick(Y.lo, Y.hi));
+                const double pz = k & 4 ? (k < 8 ? Z.lo : pick(Z.lo, Z.hi)) : (k < 8 ? Z.hi : pick(Z.lo, Z.hi));
+                const double pv = grid_value(c, px, py, pz);
+                CHECK(pv != pv || in(v, pv), "grid3d: box x[%.17g,%.17g] y[%.17g,%.17g] z[%.17g,%.17g] p(%.17g,%.17g,%.17g) v=%.17g not in [%.17g,%.17g]",
+                      X.lo, X.hi, Y.lo, Y.hi, Z.lo, Z.hi, px, py, pz, pv, v.lo, v.hi);
+            }
+        }
+        printf("grid boxes %ld, sign decided for %ld\n", boxes, decided);
+        CHECK(decided * 4 > boxes, "the grid leaf's interval decides fewer than a quarter of the boxes");
+    }
     // ---- interval product ----
     for (int it = 0; it < 100000; it++) {
         const Ival a{pick(-3, 3), 0}, b{pick(-3, 3), 0};

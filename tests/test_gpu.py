@@ -1134,3 +1134,38 @@ def test_integration_md_bindings_work_as_written():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'integration_check.py')], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'bindings ok' in out.stdout
+
+
+# ---- float32 sampling (SDF_PRECISION_F32: the fast mode, not the headline): SURVEY.md 8d's order-invariant check ----
+
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 22), ('ex_gearlike', 2 ** 21), ('ex_blobby', 2 ** 22)])
+def test_float32_sampling_is_close_to_float64(name, samples, ns, eng):
+    from scipy.spatial import cKDTree
+    from sdf_amd import engine
+    f = fixtures.build(name, ns)
+    bounds = tuple(map(tuple, BOUNDS[name]))
+    X, Y, Z, _ = core.grid_axes(bounds, samples=samples)
+    m = eng.generate(f, X, Y, Z)
+    p64, s64 = m.points(), m.stats()
+    m.close()
+    res = []
+    eng.precision = engine.PRECISION_F32
+    try:
+        for mode in (0, 1):
+            eng.set_twopass(mode)
+            m = eng.generate(f, X, Y, Z)
+            res.append((m.points(), m.kinds(), m.stats()))
+            m.close()
+    finally:
+        eng.precision = engine.PRECISION_F64
+        eng.set_twopass(-1)
+    (p32, k32, s32), (q32, l32, t32) = res
+    assert np.array_equal(p32, q32) and np.array_equal(k32, l32)          # both meshing schemes, same float32 samples
+    assert s32['n_pruned_instrs'] == 0 and s32['n_sampled_voxels'] == s32['n_eval_voxels']   # (the interval passes bound float64 only)
+    T = s64['triangles']
+    assert abs(s32['triangles'] - T) <= max(1e-4 * T, 2)
+    assert abs(s32['skipped'] - s64['skipped']) <= 2
+    extent = np.ptp(np.array(bounds), axis=0).max()
+    d1, _ = cKDTree(p64).query(p32)
+    d2, _ = cKDTree(p32).query(p64)
+    assert max(d1.max(), d2.max()) <= 1e-5 * extent * 4      # symmetric nearest-vertex distance (float32 coordinates: a few ulp of the extent)
