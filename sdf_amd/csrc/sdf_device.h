@@ -142,6 +142,22 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_sums, int &
     return base + inc - v;
 }
 
+// the same for a predicate: a ballot and a masked bit count instead of six shuffles
+template <int BLOCK>
+__device__ __forceinline__ int block_exclusive_count(bool p, int *wave_sums, int &total) {
+    const unsigned long long m = __ballot(p);
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) wave_sums[wid] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) { const int s = wave_sums[w]; if (w < wid) base += s; tot += s; }
+    total = tot;
+    __syncthreads();
+    return base + below;
+}
+
 // sign bits of the four samples (o0,o1) in {0,1}^2 of one i2-plane, bit (2*o0+o1) set when > 0
 __device__ __forceinline__ unsigned plane_bits(const float *v, int s0, int s1) {
     return (v[0] > 0.0f ? 1u : 0u) | (v[s1] > 0.0f ? 2u : 0u) | (v[s0] > 0.0f ? 4u : 0u) | (v[s0 + s1] > 0.0f ? 8u : 0u);
@@ -318,8 +334,15 @@ enum { CULL_GSTATE = 1152, CULL_COUNT = 1664, CULL_RECORD = 1664, CULL_SCRATCH =
 template <int BLOCK, bool FULL, bool RARE>
 __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *consts, int n_instr_w, int lx, int ly, int lz,
                                        const double *axes, double *ia_state, int ia_bytes, unsigned char *scratch, int *wave_sums,
-                                       int ia_np, int ia_nd) {
+                                       int ia_np, int ia_nd, unsigned long long *prof = nullptr) {
     const int tid = threadIdx.x;
+    // SDF_MESH_PROF: cycles of thread 0 per phase, collected in LDS (12 words behind the group list) and added to the
+    // global counters by the caller when the workgroup is done (an atomic per phase would stall the phases it measures:
+    // the workgroups of a launch run in step)
+    long long tprev = prof ? clock64() : 0;
+    unsigned *pacc = reinterpret_cast<unsigned *>(scratch + CULL_COUNT + 80 + 1024);
+    if (prof && tid == 0) for (int k = 0; k < 12; k++) pacc[k] = 0;
+#define SDF_CULL_PROF(K) do { if (prof && tid == 0) { const long long tn = clock64(); pacc[(K) - 16] += (unsigned)(tn - tprev); tprev = tn; } } while (0)
     const TileTasks tt(lx, ly, lz);
     const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
     const int per_pass = min(BLOCK, ia_bytes / ((6 * ia_np + 2 * ia_nd) * 8)) & ~63;
@@ -338,45 +361,67 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
         return v.lo > 1e-30 ? 1 : (v.hi < -1e-30 ? 2 : 0);
     };
     // two levels: the (up to) 4^3 boxes of 8^3 cells first, one wave; then only the groups inside the
-    // boxes that could not be decided
+    // boxes that could not be decided, per_pass at a time.  ONE loop over both (stage 0 = the boxes) so that the
+    // interval interpreter is instantiated once per kernel, not once per level.
     unsigned char *mstate = scratch + CULL_COUNT + 16;                                 // 64 bytes
     unsigned short *elist = reinterpret_cast<unsigned short *>(scratch + CULL_COUNT + 80);   // up to 512 groups to evaluate
-    if (tid < 64) {
-        const int m0 = tid >> 4, m1 = (tid >> 2) & 3, m2 = tid & 3;
-        const bool live = 8 * m0 < c0 && 8 * m1 < c1 && 8 * m2 < c2;
-        const unsigned char st = box_state(live ? 8 * m0 : 0, 8 * m0 + 8, live ? 8 * m1 : 0, 8 * m1 + 8, live ? 8 * m2 : 0, 8 * m2 + 8);
-        mstate[tid] = live ? st : 1;
-    }
-    __syncthreads();
     int nev = 0;
-    for (int g0 = 0; g0 < 512; g0 += BLOCK) {   // a group inherits the state of its box; the undecided ones are listed
-        const int gq = g0 + tid;
-        const int a0 = gq >> 6, a1 = (gq >> 3) & 7, a2 = gq & 7;
-        const bool exists = gq < 512 && 4 * a0 < c0 && 4 * a1 < c1 && 4 * a2 < c2;
-        const unsigned char ms = exists ? mstate[((a0 >> 1) * 4 + (a1 >> 1)) * 4 + (a2 >> 1)] : 1;
-        if (gq < 512) gstate[gq] = ms;
-        int n;
-        const int pos = nev + block_exclusive_scan<BLOCK>(ms == 0 ? 1 : 0, wave_sums, n);
-        if (ms == 0) elist[pos] = (unsigned short)gq;
-        nev += n;
+    for (int stage = 0;; stage++) {
+        const int e0 = (stage - 1) * per_pass;
+        if (stage > 0 && e0 >= nev) break;                                             // (uniform)
+        const bool run = stage == 0 ? tid < 64 : (tid < per_pass && e0 + (tid & ~63) < nev);   // (whole waves)
+        int gq = 0, x0, y0, z0, ext;
+        bool live;
+        if (stage == 0) {
+            const int m0 = tid >> 4, m1 = (tid >> 2) & 3, m2 = tid & 3;
+            live = 8 * m0 < c0 && 8 * m1 < c1 && 8 * m2 < c2;
+            x0 = live ? 8 * m0 : 0; y0 = live ? 8 * m1 : 0; z0 = live ? 8 * m2 : 0; ext = 8;
+        } else {
+            live = e0 + tid < nev;
+            gq = run ? (int)elist[min(e0 + tid, nev - 1)] : 0;
+            x0 = 4 * (gq >> 6); y0 = 4 * ((gq >> 3) & 7); z0 = 4 * (gq & 7); ext = 4;
+        }
+        if (run) {
+            const unsigned char st = box_state(x0, x0 + ext, y0, y0 + ext, z0, z0 + ext);
+            if (stage == 0) mstate[tid & 63] = live ? st : 1;
+            else if (live) gstate[gq] = st;
+        }
+        if (stage > 0) { SDF_CULL_PROF(19); if (prof && tid == 0) pacc[7]++; continue; }
+        SDF_CULL_PROF(17);
+        __syncthreads();
+        for (int g0 = 0; g0 < 512; g0 += BLOCK) {   // a group inherits the state of its box; the undecided ones are listed
+            const int gi = g0 + tid;
+            const int a0 = gi >> 6, a1 = (gi >> 3) & 7, a2 = gi & 7;
+            const bool exists = gi < 512 && 4 * a0 < c0 && 4 * a1 < c1 && 4 * a2 < c2;
+            const unsigned char ms = exists ? mstate[((a0 >> 1) * 4 + (a1 >> 1)) * 4 + (a2 >> 1)] : 1;
+            if (gi < 512) gstate[gi] = ms;
+            int n;
+            const int pos = nev + block_exclusive_count<BLOCK>(ms == 0, wave_sums, n);
+            if (ms == 0) elist[pos] = (unsigned short)gi;
+            nev += n;
+        }
+        __syncthreads();
+        SDF_CULL_PROF(18);
+        if (prof && tid == 0) pacc[6] = (unsigned)nev;
     }
     __syncthreads();
-    for (int e0 = 0; e0 < nev; e0 += per_pass) {
-        if (tid < per_pass && (e0 + (tid & ~63)) < nev) {   // (whole waves)
-            const bool live = e0 + tid < nev;
-            const int gq = elist[min(e0 + tid, nev - 1)];
-            const int a0 = gq >> 6, a1 = (gq >> 3) & 7, a2 = gq & 7;
-            const unsigned char st = box_state(4 * a0, 4 * a0 + 4, 4 * a1, 4 * a1 + 4, 4 * a2, 4 * a2 + 4);
-            if (live) gstate[gq] = st;
-        }
+    SDF_CULL_PROF(19);
+    // the undecided groups as bit rows: ubits[q0 * 8 + q1] has bit q2 set (the 64 bytes of the box states, done with)
+    unsigned char *ubits = mstate;
+    if (tid < 64) {
+        const unsigned long long g8 = *reinterpret_cast<const unsigned long long *>(gstate + 8 * tid);
+        unsigned bitsq = 0;
+        SDF_UNROLL for (int k = 0; k < 8; k++) bitsq |= ((g8 >> (8 * k)) & 255ull) == 0ull ? 1u << k : 0u;
+        ubits[tid] = (unsigned char)bitsq;
     }
     __syncthreads();
     auto unknown_in = [&](int j0lo, int j0hi, int j1lo, int j1hi, int j2lo, int j2hi) -> bool {   // any undecided group in a box of cells
-        bool u = false;
+        const int z0 = max(j2lo, 0) >> 2, z1 = min(j2hi, c2 - 1) >> 2;
+        const unsigned zmask = z1 >= z0 ? ((2u << z1) - 1u) & ~((1u << z0) - 1u) : 0u;
+        unsigned u = 0;
         for (int q0 = max(j0lo, 0) >> 2; q0 <= (min(j0hi, c0 - 1) >> 2); q0++)
-            for (int q1 = max(j1lo, 0) >> 2; q1 <= (min(j1hi, c1 - 1) >> 2); q1++)
-                for (int q2 = max(j2lo, 0) >> 2; q2 <= (min(j2hi, c2 - 1) >> 2); q2++) u |= gstate[(q0 * 8 + q1) * 8 + q2] == 0;
-        return u;
+            for (int q1 = max(j1lo, 0) >> 2; q1 <= (min(j1hi, c1 - 1) >> 2); q1++) u |= ubits[q0 * 8 + q1];
+        return (u & zmask) != 0u;
     };
     // one thread per task: the cells around its samples, as a box (for the tasks that are runs of
     // samples the box spans the rows / planes the run touches); the listed tasks in ascending order
@@ -394,9 +439,11 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
                     if (y0 == y1) { z0 = i0 - x0 * tt.lyz - y0 * lz; z1 = i1 - x0 * tt.lyz - y0 * lz; }
                 }
                 need = unknown_in(x0 - 1, x1, y0 - 1, y1, z0 - 1, z1);
-            } else if (task < 512) {
-                const int x0 = 4 * (task >> 6), y0 = 4 * ((task >> 3) & 7), z0 = 4 * (task & 7);
-                need = unknown_in(x0 - 1, x0 + 3, y0 - 1, y0 + 3, z0 - 1, z0 + 3);
+            } else if (task < 512) {   // a cube of 4^3 samples touches the cells of groups a - 1 and a along every axis
+                const int a0 = task >> 6, a1 = (task >> 3) & 7, a2 = task & 7;
+                const int p0 = max(a0 - 1, 0), p1 = max(a1 - 1, 0);
+                const unsigned u = ubits[a0 * 8 + a1] | ubits[p0 * 8 + a1] | ubits[a0 * 8 + p1] | ubits[p0 * 8 + p1];
+                need = (u & ((3u << a2) >> 1)) != 0u;
             } else if (task < 530) {
                 const int p0 = (task - 512) * 64, r0 = p0 / 33, r1 = min(p0 + 63, 1088) / 33;
                 need = unknown_in(31, 31, r0 - 1, r1, 0, 31);
@@ -408,12 +455,16 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
                 need = unknown_in(r0 - 1, r1, 0, 31, 31, 31);
             }
         }
+        SDF_CULL_PROF(24);
         int n;
-        const int pos = ntl + block_exclusive_scan<BLOCK>(need ? 1 : 0, wave_sums, n);
+        const int pos = ntl + block_exclusive_count<BLOCK>(need, wave_sums, n);
+        SDF_CULL_PROF(25);
         if (need) tlist[pos] = (unsigned short)task;
         ntl += n;
     }
     __syncthreads();
+    SDF_CULL_PROF(20);
+#undef SDF_CULL_PROF
     return ntl;
 }
 

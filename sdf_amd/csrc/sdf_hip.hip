@@ -152,9 +152,11 @@ __global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__rest
 // Workgroups >= pa.first_block run the interval pass of the same batches instead (sdf_prune.h).
 template <typename T, bool FULL, bool RARE>
 __device__ __forceinline__ void skip_body(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
-                                              int nbatches, unsigned char *__restrict__ kinds, const PruneArgs &pa, double *prune_lds) {
+                                              int nbatches, unsigned char *__restrict__ kinds, const PruneArgs &pa,
+                                              const double *__restrict__ c64, const uint16_t *__restrict__ rstart,
+                                              const uint16_t *__restrict__ lstart, double *prune_lds) {
     if ((int)blockIdx.x >= pa.first_block) {   // (uniform)
-        prune_block<FULL, RARE>(code, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
+        prune_block<FULL, RARE>(code, c64, rstart, lstart, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
         return;
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,15 +192,17 @@ __device__ __forceinline__ void skip_body(const uint32_t *__restrict__ code, con
 // them, the others keep the leaner one -- a kernel's registers and scratch are those of its hungriest callee)
 template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
-                                              int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa) {
+                                              int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa,
+                                              const double *__restrict__ c64, const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart) {
     extern __shared__ double prune_lds[];
-    skip_body<T, FULL, false>(code, consts, g, nbatches, kinds, pa, prune_lds);
+    skip_body<T, FULL, false>(code, consts, g, nbatches, kinds, pa, c64, rstart, lstart, prune_lds);
 }
 template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void k_skip_rare(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
-                                                   int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa) {
+                                                   int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa,
+                                                   const double *__restrict__ c64, const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart) {
     extern __shared__ double prune_lds[];
-    skip_body<T, FULL, true>(code, consts, g, nbatches, kinds, pa, prune_lds);
+    skip_body<T, FULL, true>(code, consts, g, nbatches, kinds, pa, c64, rstart, lstart, prune_lds);
 }
 
 // The interval pass of sdf_prune.h as a kernel of its own, over this shard's work list: for grids with many
@@ -206,10 +210,12 @@ __global__ __launch_bounds__(256) void k_skip_rare(const uint32_t *__restrict__ 
 // survivors is worth the extra launch behind k_compact; small grids keep it fused into k_skip's launch, where
 // it costs nothing on the critical path.
 template <bool FULL, bool RARE>
-__global__ __launch_bounds__(PRUNE_BLOCK) void k_prune_list(const uint32_t *__restrict__ code, GridDesc g, int nbatches, PruneArgs pa) {
+__global__ __launch_bounds__(PRUNE_BLOCK) void k_prune_list(const uint32_t *__restrict__ code, GridDesc g, int nbatches, PruneArgs pa,
+                                                               const double *__restrict__ c64, const uint16_t *__restrict__ rstart,
+                                                               const uint16_t *__restrict__ lstart) {
     extern __shared__ double prune_list_lds[];
     if ((long long)blockIdx.x * (PRUNE_BLOCK / 8) >= (long long)(pa.ctr->work_end - pa.ctr->work_begin)) return;   // (uniform)
-    prune_block<FULL, RARE>(code, pa, g, nbatches, (int)blockIdx.x, prune_list_lds);
+    prune_block<FULL, RARE>(code, c64, rstart, lstart, pa, g, nbatches, (int)blockIdx.x, prune_list_lds);
 }
 
 // One workgroup per work item of this shard: which sampling tasks of the batch have to be evaluated
@@ -219,18 +225,25 @@ template <bool FULL, bool RARE, int CB = CULL_BLOCK>
 __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out, unsigned char *cull_smem) {
+                                                     unsigned char *__restrict__ out, unsigned char *cull_smem, unsigned long long *prof) {
     int *wave_sums = reinterpret_cast<int *>(cull_smem);                       // 64 B
     double *axes = reinterpret_cast<double *>(cull_smem + 64);                 // 3 * 33 doubles
     unsigned char *scratch = cull_smem + 896;                                  // CULL_SCRATCH bytes
     double *ia_state = reinterpret_cast<double *>(cull_smem + 896 + CULL_SCRATCH);
     const int tid = threadIdx.x;
+    const long long tstart = prof ? clock64() : 0;
     // (one workgroup per BATCH is launched -- the host does not know the length of the work list -- and the surplus ones
     // leave here.  Striding over the list with a grid sized for the compute units was measured in r02: the loop costs the
     // kernel 10 - 20 % (example 60 -> 70 us, gearlike 2^30 prepass 0.36 -> 0.43 ms), the empty workgroups nothing.)
     const int w = ctr->work_begin + (int)blockIdx.x;
     if (w >= ctr->work_end) return;
     const int b = __builtin_amdgcn_readfirstlane(worklist[w]);   // (uniform: the tape is then read with scalar loads)
+    auto now_drained = [&]() -> long long {   // (profiling: the clock once every outstanding load has arrived)
+        long long t;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(b) : "memory");
+        return t;
+    };
+    const long long t_b = prof ? now_drained() : 0;
     int ox, oy, oz, lx, ly, lz;
     batch_origin(g, b, ox, oy, oz, lx, ly, lz);
     for (int i = tid; i < 99; i += CB) {
@@ -239,40 +252,55 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
         else if (i - 66 < lz) axes[i] = g.Z[oz + i - 66];
     }
     __syncthreads();
+    const long long t_axes = prof ? now_drained() : 0;
     const uint32_t *wcode = code + (size_t)b * (size_t)tape_stride * 2;
     const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
-    const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd);
+    long long tstart1 = 0;
+    if (prof) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart1) : "s"(n_instr_w) : "memory");
+    const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd, prof);
+    const long long tw = prof ? clock64() : 0;
     if (tid == 0) reinterpret_cast<unsigned short *>(scratch)[0] = ntl < 0 ? (unsigned short)0xFFFF : (unsigned short)ntl;
     __syncthreads();
     for (int i = tid; i < CULL_RECORD / 4; i += CB)
         reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD)[i] = reinterpret_cast<const unsigned *>(scratch)[i];
+    if (prof && tid == 0) {
+        const unsigned *pacc = reinterpret_cast<const unsigned *>(scratch + CULL_COUNT + 80 + 1024);
+        atomicAdd(&prof[16], (unsigned long long)(tstart1 - tstart));
+        atomicAdd(&prof[27], (unsigned long long)(t_b - tstart));
+        atomicAdd(&prof[28], (unsigned long long)(t_axes - t_b));
+        atomicAdd(&prof[29], (unsigned long long)(tstart1 - t_axes));
+        if (blockIdx.x >= 1536) atomicAdd(&prof[30], (unsigned long long)(t_axes - t_b));
+        atomicMax(&prof[31], (unsigned long long)(t_axes - t_b));
+        atomicAdd(&prof[21], (unsigned long long)(clock64() - tw));
+        for (int k = 1; k < 10; k++) if (k != 5) atomicAdd(&prof[16 + k], (unsigned long long)pacc[k]);
+    }
 }
 
 template <bool FULL, bool RARE>
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out) {
+                                                     unsigned char *__restrict__ out, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<FULL, RARE>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem);
+    cull_body<FULL, RARE>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof);
 }
 // the variant for tapes without trigonometry and without the rarer leaves fits 80 VGPRs without spilling:
 // six waves per SIMD instead of five (the others would spill 64-160 bytes per lane at that budget)
 __global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out) {
+                                                     unsigned char *__restrict__ out, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem);
+    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof);
 }
 // (experiment: the same with two waves per workgroup -- twelve workgroups fit a CU, every work item of the 512^3
 // example is resident at once instead of in two rounds)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean128(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out) {
+                                                     unsigned char *__restrict__ out, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem);
+    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof);
 }
 
 // ordered compaction of the pending batches into the work list (single workgroup)
@@ -974,7 +1002,7 @@ static int ctx_init(sdf_ctx *c) {
     if (const char *e = getenv("SDF_PRUNE_LIST_MIN")) c->prune_list_min = std::max(atoi(e), 0);
     if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
-    if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(128)) return 1; }
+    if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(256)) return 1; }
     return 0;
 }
 
@@ -1432,7 +1460,6 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     size_t prune_lds = 0;
     if (pruning) {
         if (m->prune.ensure((size_t)nb * 64) || m->tapes.ensure((size_t)nb * tape_stride * 8)) return 1;
-        pa.consts = (const double *)t->d_c64; pa.rstart = t->d_rstart; pa.lstart = t->d_lstart;
         pa.n_instr = (int)n_instr; pa.n_p = std::max(t->n_p, 1u); pa.n_d = std::max(t->n_d, 1u);
         pa.masks_out = (uint32_t *)m->prune.p; pa.tapes_out = (unsigned long long *)m->tapes.p; pa.tape_stride = tape_stride;
         pa.zero_off = t->n_consts;
@@ -1449,8 +1476,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
         }
         const size_t skip_lds = prune_blocks ? prune_lds : 0;
-        if (t->ia_rare) LAUNCH_TAPE_ON(st, k_skip_rare, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
-        else LAUNCH_TAPE_ON(st, k_skip, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa);
+        if (t->ia_rare) LAUNCH_TAPE_ON(st, k_skip_rare, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa,
+                                       (const double *)t->d_c64, (const uint16_t *)t->d_rstart, (const uint16_t *)t->d_lstart);
+        else LAUNCH_TAPE_ON(st, k_skip, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa,
+                            (const double *)t->d_c64, (const uint16_t *)t->d_rstart, (const uint16_t *)t->d_lstart);
     }
     if (!sparse) HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, st));
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
@@ -1462,12 +1491,14 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         auto kp = t->full ? (t->ia_rare ? k_prune_list<true, true> : k_prune_list<true, false>) : (t->ia_rare ? k_prune_list<false, true> : k_prune_list<false, false>);
         if (prune_lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
         hipLaunchKernelGGL(kp, dim3((unsigned)(((long long)nb * 8 + PRUNE_BLOCK - 1) / PRUNE_BLOCK)), dim3(PRUNE_BLOCK), prune_lds, st,
-                           (const uint32_t *)t->d_code, g, nb, pa);
+                           (const uint32_t *)t->d_code, g, nb, pa, (const double *)t->d_c64, (const uint16_t *)t->d_rstart,
+                           (const uint16_t *)t->d_lstart);
         HIPCHK(hipGetLastError());
     }
     // second interval pass, per surviving batch: the groups of 4^3 cells the surface cannot be in are not sampled
     const bool culling = c->cull && intervals_ok && t->ia_complete;
     if (culling) {
+        if (c->prof.p) HIPCHK(hipMemsetAsync((unsigned char *)c->prof.p + 128, 0, 128, st));
         if (m->cull.ensure((size_t)nb * CULL_RECORD)) return 1;
         const int ia_np = (int)std::max(t->n_p, 1u), ia_nd = (int)std::max(t->n_d, 1u);
         auto kc = t->full ? (t->ia_rare ? k_cull<true, true> : k_cull<true, false>) : (t->ia_rare ? k_cull<false, true> : k_cull_lean);
@@ -1479,7 +1510,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
                            (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
-                           ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p);
+                           ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p, (unsigned long long *)c->prof.p);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(cs.e2, st));
@@ -1572,7 +1603,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             a.twopass = 1; a.desc = (ItemDesc *)m->desc.p; a.cells = (unsigned *)m->cellrecs.p; a.tlist = (unsigned *)m->trilist.p;
             a.cells_cap = a.tlist_cap = (unsigned long long)cap_t;
         }
-        if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, st));
+        if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, st));   // (words 16.. are k_cull's: cleared before the prepass)
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         const bool own_start = attempt > 0 || a.prof || !quiet;   // (something was enqueued, or the host waited, since ev[2])
         if (own_start) HIPCHK(hipEventRecord(cs.e3, st));
@@ -1610,8 +1641,11 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipEventElapsedTime(&ms, own_start ? cs.e3 : cs.e2, cs.e4));
         m->st.ms_mesh = ms;
         if (c->prof.p) {
-            unsigned long long pc[16];
-            HIPCHK(hipMemcpy(pc, c->prof.p, 128, hipMemcpyDeviceToHost));
+            unsigned long long pc[32];
+            HIPCHK(hipMemcpy(pc, c->prof.p, 256, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[k_cull prof] cycles of thread 0, summed over the workgroups: start %llu boxes %llu list %llu groups %llu (%llu passes, %llu groups) tasks %llu record %llu\n",
+                    pc[16], pc[17], pc[18], pc[19], pc[23], pc[22], pc[20], pc[21]);
+            fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu; start: work item %llu axes %llu (workgroups 1536..: %llu; max %llu) tape length %llu\n", pc[24], pc[25], pc[27], pc[28], pc[30], pc[31], pc[29]);
             fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu\n", pc[8], pc[9], pc[10], pc[11]);
             fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked\n",
                     ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7]);

@@ -61,46 +61,45 @@ SDF_IA Ival pt(double c) { return Ival{c, c}; }
 SDF_IA bool bad(const Ival &a) { return !(a.lo <= a.hi); }                 // NaN or empty
 SDF_IA Ival fix(const Ival &a) { return bad(a) ? top() : a; }
 SDF_IA Ival wide(double lo, double hi) { return fix(Ival{lo, hi}); }   // (NaN -> the whole line)
-SDF_IA Ival add(const Ival &a, const Ival &b) { return wide(a.lo + b.lo, a.hi + b.hi); }
-SDF_IA Ival sub(const Ival &a, const Ival &b) { return wide(a.lo - b.hi, a.hi - b.lo); }
-SDF_IA Ival addc(const Ival &a, double c) { return wide(a.lo + c, a.hi + c); }
-SDF_IA Ival subc(const Ival &a, double c) { return wide(a.lo - c, a.hi - c); }
-SDF_IA Ival csub(double c, const Ival &a) { return wide(c - a.hi, c - a.lo); }
+// Intervals never hold a NaN; an operation that can produce one (inf - inf, 0 * inf) maps it to "no bound".
+// For the operations whose lower result depends on lower bounds only and whose upper result on upper bounds only
+// (sums, differences, products with a constant: monotone term by term) that can be done PER BOUND, with one
+// instruction each -- maxNum / minNum return the operand that is not a NaN: a lower bound that came out as NaN
+// is -inf, an upper one +inf, and the other bound stays what it is (it was computed from valid bounds of its
+// own side).  The general form (`wide`: compare, then four selects) used to be two thirds of the instructions
+// of a leaf like the box.
+SDF_IA Ival side(double lo, double hi) { return Ival{fmax(lo, -__builtin_inf()), fmin(hi, __builtin_inf())}; }
+SDF_IA Ival add(const Ival &a, const Ival &b) { return side(a.lo + b.lo, a.hi + b.hi); }
+SDF_IA Ival sub(const Ival &a, const Ival &b) { return side(a.lo - b.hi, a.hi - b.lo); }
+SDF_IA Ival addc(const Ival &a, double c) { return side(a.lo + c, a.hi + c); }        // (a NaN constant: both bounds NaN -> the whole line)
+SDF_IA Ival subc(const Ival &a, double c) { return side(a.lo - c, a.hi - c); }
+SDF_IA Ival csub(double c, const Ival &a) { return side(c - a.hi, c - a.lo); }
 SDF_IA Ival neg(const Ival &a) { return Ival{-a.hi, -a.lo}; }
-SDF_IA Ival mulc(const Ival &a, double c) {      // a * c (== c * a)
-    const double p = a.lo * c, q = a.hi * c;
-    if (p != p || q != q) return top();                              // (0 * inf, a NaN constant)
-    return wide(fmin(p, q), fmax(p, q));
+// a * c (== c * a): the sign of the (wave-uniform) constant says which end gives which bound
+SDF_IA Ival mulc(const Ival &a, double c) {
+    return c >= 0 ? side(a.lo * c, a.hi * c) : side(a.hi * c, a.lo * c);
 }
 // fma(x, c, r) with a constant c: monotone in x (direction = sign of c) and in r
 SDF_IA Ival fmac(const Ival &x, double c, const Ival &r) {
-    const double l = c >= 0 ? fma(x.lo, c, r.lo) : fma(x.hi, c, r.lo);
-    const double h = c >= 0 ? fma(x.hi, c, r.hi) : fma(x.lo, c, r.hi);
-    if (c != c || l != l || h != h) return top();
-    return wide(l, h);
+    return c >= 0 ? side(fma(x.lo, c, r.lo), fma(x.hi, c, r.hi)) : side(fma(x.hi, c, r.lo), fma(x.lo, c, r.hi));
 }
 SDF_IA Ival divc(const Ival &a, double c) {
     if (!(c != 0.0)) return top();                                   // 0 or NaN
-    const double p = a.lo / c, q = a.hi / c;
-    if (p != p || q != q) return top();
-    return wide(fmin(p, q), fmax(p, q));
+    return c > 0 ? side(a.lo / c, a.hi / c) : side(a.hi / c, a.lo / c);   // (inf / inf)
 }
-SDF_IA Ival sqr(const Ival &a) {                 // x * x
-    const double l = a.lo * a.lo, h = a.hi * a.hi;
-    if (l != l || h != h) return top();
-    if (a.lo >= 0) return Ival{l, h};
-    if (a.hi <= 0) return Ival{h, l};
-    return Ival{0.0, fmax(l, h)};
+// x * x: with m <= |x| <= M over the interval (m = 0 when it straddles zero), [m * m, M * M] -- the rounded
+// square is monotone in |x|; no products of infinities with zero, no comparisons
+SDF_IA Ival sqr(const Ival &a) {
+    const double m = fmax(fmax(a.lo, -a.hi), 0.0), M = fmax(-a.lo, a.hi);
+    return Ival{m * m, M * M};
 }
 SDF_IA Ival sqrt_(const Ival &a) {
     // only sums of squares get here: never negative, never NaN unless a bound already is
     if (bad(a) || a.lo < 0) return top();
     return Ival{sqrt(a.lo), sqrt(a.hi)};
 }
-SDF_IA Ival abs_(const Ival &a) {
-    if (a.lo >= 0) return a;
-    if (a.hi <= 0) return neg(a);
-    return Ival{0.0, fmax(-a.lo, a.hi)};
+SDF_IA Ival abs_(const Ival &a) {   // (branch-free: the three cases of the sign are these two maxima)
+    return Ival{fmax(fmax(a.lo, -a.hi), 0.0), fmax(-a.lo, a.hi)};
 }
 SDF_IA Ival min_(const Ival &a, const Ival &b) { return Ival{fmin(a.lo, b.lo), fmin(a.hi, b.hi)}; }
 SDF_IA Ival max_(const Ival &a, const Ival &b) { return Ival{fmax(a.lo, b.lo), fmax(a.hi, b.hi)}; }
@@ -309,7 +308,7 @@ SDF_IA Ival ia_box_like(const Ival &qx, const Ival &qy, const Ival &qz) {
 
 // value interval of a leaf (the formulas of sdf_interp.h, operation by operation), or the whole
 // line for leaves without an interval form
-__host__ __device__ __attribute__((noinline)) inline Ival ia_leaf(uint32_t op, const double *c, const Ival &x, const Ival &y, const Ival &z) {
+SDF_IA Ival ia_leaf(uint32_t op, const double *c, const Ival &x, const Ival &y, const Ival &z) {
     using namespace ia;
     switch (op) {
     case OP_L_SPHERE: return subc(len3(subc(x, c[1]), subc(y, c[2]), subc(z, c[3])), c[0]);

@@ -6,9 +6,10 @@
 
 namespace sdfk {
 
+// (the tape's float64 constant pool and rstart / lstart -- per instruction: first instruction of the right operand /
+// of the left chain -- are kernel parameters of their own: as `__restrict__` arguments their loads are scalar
+// loads; as members of this struct they were vector loads the arithmetic waited for)
 struct PruneArgs {
-    const double *consts;            // float64 constant pool of the tape
-    const uint16_t *rstart, *lstart; // per instruction: first instruction of the right operand / the left chain
     int n_instr;                     // instructions of the tape, END included
     int n_p, n_d;                    // saved-point / saved-distance slots the tape uses (>= 1 each)
     uint32_t *masks_out;             // [batch][16]: skip / forced bits (diagnostics)
@@ -25,8 +26,9 @@ struct PruneArgs {
 // It runs for EVERY batch, next to the skip test rather than after it: the work list is not known
 // yet, and a launch of its own behind k_compact would sit on the critical path.
 template <bool FULL, bool RARE>
-__device__ __forceinline__ void prune_block(const uint32_t *__restrict__ code, const PruneArgs &pa, const GridDesc &g,
-                                            int nbatches, int block, double *lds) {
+__device__ __forceinline__ void prune_block(const uint32_t *__restrict__ code, const double *__restrict__ c64,
+                                            const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart,
+                                            const PruneArgs &pa, const GridDesc &g, int nbatches, int block, double *lds) {
     const int gid = block * PRUNE_BLOCK + threadIdx.x;
     const int oct = gid & 7;
     int b = gid >> 3;
@@ -51,7 +53,7 @@ __device__ __forceinline__ void prune_block(const uint32_t *__restrict__ code, c
     }
     uint32_t masks[16];
     for (int k = 0; k < 16; k++) masks[k] = 0;
-    ia_run_tape<true, FULL, RARE>(code, pa.consts, pa.rstart, pa.lstart, pa.n_instr, bx, by, bz, live, IaShared{lds, pa.n_p, PRUNE_BLOCK}, pa.n_d, masks);
+    ia_run_tape<true, FULL, RARE>(code, c64, rstart, lstart, pa.n_instr, bx, by, bz, live, IaShared{lds, pa.n_p, PRUNE_BLOCK}, pa.n_d, masks);
     const bool store = live && oct == 0;
     unsigned long long *out = pa.tapes_out + (size_t)(live ? b : 0) * pa.tape_stride;
     const int n = compact_tape(reinterpret_cast<const unsigned long long *>(code), pa.n_instr, masks, out, store, pa.zero_off);

@@ -16,7 +16,7 @@ import numpy as np
 from . import tape as _tape
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsdf_hip.so')
+LIB_PATH = os.environ.get('SDF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libsdf_hip.so')   # (SDF_HIP_LIB: another build of the library, for A/B timing)
 
 PRECISION_F64 = 0
 PRECISION_F32 = 1

@@ -405,6 +405,45 @@ int main() {
         printf("grid boxes %ld, sign decided for %ld\n", boxes, decided);
         CHECK(decided * 4 > boxes, "the grid leaf's interval decides fewer than a quarter of the boxes");
     }
+    // ---- the arithmetic primitives, bounds and constants from a set with the special values in it: the result holds
+    // no NaN, is not empty, and encloses the operation at points of the operands (a point at an infinite bound
+    // stands for "any value": there the check is that the bound on that side is infinite as well) ----
+    {
+        const double inf = __builtin_inf(), nan = __builtin_nan("");
+        const double sp[] = {-inf, -1e308, -3.5, -1.0, -1e-300, -0.0, 0.0, 1e-300, 0.5, 1.0, 7.25, 1e308, inf};
+        const int nsp = (int)(sizeof sp / sizeof sp[0]);
+        auto ival = [&]() { int i = (int)(rng() % nsp), j = (int)(rng() % nsp); if (i > j) { const int t = i; i = j; j = t; } return Ival{sp[i], sp[j]}; };
+        auto konst = [&]() { const unsigned r = (unsigned)(rng() % 16); return r == 0 ? nan : sp[rng() % nsp]; };
+        auto point = [&](const Ival &a) {   // a finite point of a (the finite end, or something large, where a bound is infinite)
+            const double lo = a.lo == -inf ? (a.hi == inf ? -1e3 : fmin(a.hi, 0.0) - 1e3) : a.lo, hi = a.hi == inf ? fmax(lo, 0.0) + 1e3 : a.hi;
+            const unsigned r = (unsigned)(rng() % 4);
+            const double t = U(rng);
+            return r == 0 ? lo : (r == 1 ? hi : fmin(fmax(lo * (1.0 - t) + hi * t, lo), hi));
+        };
+        auto sane = [&](const Ival &r) { return r.lo == r.lo && r.hi == r.hi && r.lo <= r.hi; };
+        auto holds = [&](const Ival &r, double v) { return v != v || (v >= r.lo && v <= r.hi); };   // (a NaN result of the point operation: inf - inf at a point, nothing to enclose)
+        for (int it = 0; it < 400000; it++) {
+            const Ival a = ival(), b = ival();
+            if ((a.lo == inf) || (a.hi == -inf) || (b.lo == inf) || (b.hi == -inf)) continue;   // (an interval AT infinity holds no finite point)
+            const double c = konst(), u = point(a), v = point(b);
+            Ival r;
+            r = ia::add(a, b); CHECK(sane(r) && holds(r, u + v), "add [%g,%g]+[%g,%g] = [%g,%g]", a.lo, a.hi, b.lo, b.hi, r.lo, r.hi);
+            r = ia::sub(a, b); CHECK(sane(r) && holds(r, u - v), "sub [%g,%g]-[%g,%g] = [%g,%g]", a.lo, a.hi, b.lo, b.hi, r.lo, r.hi);
+            r = ia::addc(a, c); CHECK(sane(r) && holds(r, u + c), "addc [%g,%g]+%g = [%g,%g]", a.lo, a.hi, c, r.lo, r.hi);
+            r = ia::subc(a, c); CHECK(sane(r) && holds(r, u - c), "subc [%g,%g]-%g = [%g,%g]", a.lo, a.hi, c, r.lo, r.hi);
+            r = ia::csub(c, a); CHECK(sane(r) && holds(r, c - u), "csub %g-[%g,%g] = [%g,%g]", c, a.lo, a.hi, r.lo, r.hi);
+            r = ia::mulc(a, c); CHECK(sane(r) && holds(r, u * c), "mulc [%g,%g]*%g = [%g,%g] (%g)", a.lo, a.hi, c, r.lo, r.hi, u * c);
+            r = ia::divc(a, c); CHECK(sane(r) && (c == 0.0 || holds(r, u / c)), "divc [%g,%g]/%g = [%g,%g] (%g)", a.lo, a.hi, c, r.lo, r.hi, u / c);
+            r = ia::fmac(a, c, b); CHECK(sane(r) && holds(r, fma(u, c, v)), "fmac [%g,%g]*%g+[%g,%g] = [%g,%g] (%g)", a.lo, a.hi, c, b.lo, b.hi, r.lo, r.hi, fma(u, c, v));
+            r = ia::sqr(a); CHECK(sane(r) && r.lo >= 0.0 && holds(r, u * u), "sqr [%g,%g] = [%g,%g] (%g)", a.lo, a.hi, r.lo, r.hi, u * u);
+            r = ia::abs_(a); CHECK(sane(r) && r.lo >= 0.0 && holds(r, fabs(u)), "abs [%g,%g] = [%g,%g]", a.lo, a.hi, r.lo, r.hi);
+            r = ia::neg(a); CHECK(sane(r) && holds(r, -u), "neg");
+            r = ia::min_(a, b); CHECK(sane(r) && holds(r, fmin(u, v)), "min");
+            r = ia::max_(a, b); CHECK(sane(r) && holds(r, fmax(u, v)), "max");
+            r = ia::dot3c(a, b, a, c, 0.5, -2.0); CHECK(sane(r) && holds(r, fma(u, -2.0, fma(v, 0.5, u * c))), "dot3c [%g,%g] [%g,%g] c=%g = [%g,%g]", a.lo, a.hi, b.lo, b.hi, c, r.lo, r.hi);
+            r = ia::len3(a, b, Ival{u, u}); CHECK(sane(r) && holds(r, sqrt((u * u + v * v) + u * u)), "len3 [%g,%g] [%g,%g] = [%g,%g]", a.lo, a.hi, b.lo, b.hi, r.lo, r.hi);
+        }
+    }
     // ---- interval product ----
     for (int it = 0; it < 100000; it++) {
         const Ival a{pick(-3, 3), 0}, b{pick(-3, 3), 0};
