@@ -124,14 +124,18 @@ __device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((flo
 
 template <int BLOCK>
 __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_sums, int &total) {
-    // wave64 inclusive scan by shuffles, then the wave totals through LDS
+    // wave64 inclusive scan in the vector ALU (data-parallel primitives: four shifts inside the rows of 16 lanes, then
+    // the row totals across), then the wave totals through LDS.  (Six `__shfl_up` steps -- ds_bpermute, an LDS round
+    // trip each -- used to make a scan cost 1.6 k cycles of a 256-thread workgroup; a lane that has no source, or whose
+    // row is masked out, adds the 0 of `old`.)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     if (lane == 63) wave_sums[wid] = inc;
     __syncthreads();
     int base = 0, tot = 0;

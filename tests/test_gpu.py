@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import fixtures
-from conftest import GOLDEN, value_tolerance
+from conftest import GOLDEN, ROOT, value_tolerance
 from sdf_amd import core
 
 pytestmark = pytest.mark.gpu
@@ -1169,3 +1169,16 @@ def test_float32_sampling_is_close_to_float64(name, samples, ns, eng):
     d1, _ = cKDTree(p64).query(p32)
     d2, _ = cKDTree(p32).query(p64)
     assert max(d1.max(), d2.max()) <= 1e-5 * extent * 4      # symmetric nearest-vertex distance (float32 coordinates: a few ulp of the extent)
+
+
+def test_block_scan_of_the_kernels_on_device(tmp_path):
+    """block_exclusive_scan (csrc/sdf_device.h: data-parallel-primitive shifts inside the wave, wave totals through LDS)
+    against a serial prefix sum, 1024 threads; built from tests/native/scan_check.hip with hipcc"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    exe = str(tmp_path / 'scan_check')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-Wno-unused-result', '-I', os.path.join(ROOT, 'sdf_amd', 'csrc'),
+                    '-o', exe, os.path.join(ROOT, 'tests', 'native', 'scan_check.hip')], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and 'bad=0' in r.stdout, r.stdout + r.stderr
