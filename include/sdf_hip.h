@@ -76,6 +76,10 @@ int sdf_ctx_set_cull(sdf_ctx *ctx, int enabled);
  * (sample + classify / number the triangles / emit), -1 = the library's choice by the tape's length (default; the
  * environment variable SDF_MESH_TWOPASS sets the initial state).  Results are identical either way. */
 int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
+/* Scheduling of the meshing pass: 1 (default; SDF_TAIL_ORDER sets the initial state) = the last few hundred surviving
+ * batches are handed to the workgroups by descending cost estimate instead of by position (shorter tail of the
+ * kernel), 0 = strictly in list order.  Results are identical either way. */
+int sdf_ctx_set_tail_order(sdf_ctx *ctx, int on);
 int sdf_ctx_synchronize(sdf_ctx *ctx);
 
 /* Upload an op tape produced by sdf_amd/tape.py (2 x uint32 per instruction, float64 constants).

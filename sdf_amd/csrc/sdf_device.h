@@ -94,7 +94,16 @@ struct MeshArgs {
     unsigned *cells;                    // 9 dwords per record
     unsigned *tlist;
     unsigned long long cells_cap, tlist_cap;
+    // The LAST `tail` work items of the shard are handed out by descending cost instead of by position: order[i] =
+    // k_cull's estimate for the i-th item of the tail (listed tasks x instructions); the workgroup that takes the
+    // r-th of them looks for the item of rank r.  The kernel ends when its slowest workgroup does, and a workgroup's
+    // last item decides how far behind the others it ends; with the expensive items first the stragglers get the
+    // cheap ones.  NULL / 0: in order.  tail <= workgroups - 1 keeps the look-back free of deadlock whatever the
+    // items do (see k_mesh).
+    const int *order;
+    int tail;
 };
+enum { MESH_TAIL_MAX = 255 };
 
 struct ItemDesc {
     unsigned ntri, ncells;
@@ -506,6 +515,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     if (tid < 256) ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
 
     const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
+    if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x] = wall_clock64();        // (timeline of the workgroup, 100 MHz)
     long long tprev = a.prof ? clock64() : 0;
 #define SDF_PROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     // position-dependent bookkeeping of work item w_ (thread 0)
@@ -590,10 +600,37 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     // 0.288 -> 0.300 ms.  Rejected.)
     for (;;) {
         SDF_FRESH();
-        if (tid == 0) bcast[0] = work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
+        if (tid == 0) { const int idx = (int)atomicAdd(&a.ctr->work_counter, 1u); bcast[0] = work_begin + idx; bcast[1] = idx; }
         __syncthreads();
-        const int w = bcast[0];
-        if (w >= work_end) break;
+        int w = bcast[0];
+        // Items are handed out in list order, so that the predecessors of a batch are always held by running
+        // workgroups -- except inside the tail, which goes by descending cost (MeshArgs::order): the r-th workgroup to
+        // arrive there takes the item of rank r (every thread ranks one item among the tail's <= 255 costs; ties by
+        // position).  That is safe: a batch publishes its COUNT before anything that can wait, so the look-back
+        // needs every earlier batch to be sampled, no more; a workgroup that waits (full FIFO, a batch too large to
+        // park) holds one item of the tail at most that others wait for, and the tail has fewer items than there are
+        // workgroups, hence some workgroup is always free to take the item everybody waits for.
+        {
+            const int n_work = work_end - work_begin, tail = min(a.tail, n_work), r = bcast[1] - (n_work - tail);
+            if (a.order && r >= 0 && r < tail) {   // (uniform)
+                int *cost = reinterpret_cast<int *>(list), *rnk = cost + 256;   // (the list region is idle here)
+                for (int i = tid; i < 256; i += BLOCK) { cost[i] = i < tail ? a.order[i] : -1; rnk[i] = 0; }
+                __syncthreads();
+                {   // item i = tid % 256 against a quarter (half) of the others, the partial ranks added up in LDS
+                    constexpr int PARTS = BLOCK / 256, SPAN = 256 / PARTS;
+                    const int i = tid & 255, j0 = (tid >> 8) * SPAN, ci = cost[i];
+                    int part = 0;
+                    for (int j = j0; j < j0 + SPAN; j++) { const int cj = cost[j]; part += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+                    if (part) atomicAdd(&rnk[i], part);
+                }
+                __syncthreads();
+                if (tid < tail && rnk[tid] == r) bcast[0] = work_end - tail + tid;
+                __syncthreads();
+                w = bcast[0];
+                __syncthreads();   // (the list region takes the batch's record next)
+            }
+        }
+        if (w >= work_end) { if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x + 1] = wall_clock64(); break; }
         const int b = a.worklist[w];
         // k_cull's record of the batch (cull_tasks) travels next to the axes: into the list region, idle until phase 3
         if (a.cull && tid < CULL_RECORD / 4) list[tid] = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[tid];
@@ -737,6 +774,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             return (unsigned)(~(ones | zeros)) & (c2 >= 32 ? 0xFFFFFFFFu : ((1u << c2) - 1u));
         };
         // ---- 2a. surface cells per row, their running count over the rows (the order of the soup) ----
+        long long tcnt = a.prof ? clock64() : 0;
+#define SDF_CNTPROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tcnt)); tcnt = tn; } } while (0)
         int ncells = 0, row_cell0[RPT];
         SDF_UNROLL
         for (int k = 0; k < RPT; k++) {
@@ -752,6 +791,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             row_cell0[k] = ncells + block_exclusive_scan<BLOCK>(__popc(mask), wave_sums, tot);
             ncells += tot;
         }
+        SDF_CNTPROF(12);
         // ---- 2b. ONE THREAD PER SURFACE CELL (up to MESH_CELL_CHUNKS * BLOCK of them).  The row's thread only
         // SCATTERS its cells -- (row, column, sign configuration) into a table at the cell's running index, a few
         // ALU instructions and one LDS write each, nothing to wait for; then thread s takes cell s: looks up its
@@ -780,6 +820,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 }
             }
             __syncthreads();
+            SDF_CNTPROF(13);
             per_cell = true;
             SDF_UNROLL
             for (int k = 0; k < MESH_CELL_CHUNKS; k++) {
@@ -808,6 +849,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (k * BLOCK < ncells) { coff[k] += block_exclusive_scan<BLOCK>(n, wave_sums, tot); total += tot; }   // (uniform)
                 cinfo[k] = info; cn[k] = n;
             }
+            SDF_CNTPROF(14);
             if (TWOPASS) {
                 list_ready = true;        // (no list in LDS: the entries go to the arena below)
             } else if (total <= a.list_cap) {
@@ -851,6 +893,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 total += tot;
             }
         }
+        SDF_CNTPROF(15);
+#undef SDF_CNTPROF
         // ---- the batch's count is public from here on; bookkeeping that needs no position ----
         if (tid < 64 && !TWOPASS) publish_count(a.status, w, work_begin, (unsigned long long)total);
         if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
@@ -1048,6 +1092,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     SDF_FRESH();
     place_parked(pq_count > 0 && tid < 64 ? lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin) : 0ull, true);
     SDF_PROF(5);
+    if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x + 2] = wall_clock64();
 #undef SDF_FRESH
 #undef SDF_PROF
 }

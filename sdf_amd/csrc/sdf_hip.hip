@@ -225,7 +225,8 @@ template <bool FULL, bool RARE, int CB = CULL_BLOCK>
 __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out, unsigned char *cull_smem, unsigned long long *prof) {
+                                                     unsigned char *__restrict__ out, unsigned char *cull_smem, unsigned long long *prof,
+                                                     int *__restrict__ order, int tail_max) {
     int *wave_sums = reinterpret_cast<int *>(cull_smem);                       // 64 B
     double *axes = reinterpret_cast<double *>(cull_smem + 64);                 // 3 * 33 doubles
     unsigned char *scratch = cull_smem + 896;                                  // CULL_SCRATCH bytes
@@ -263,8 +264,15 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     __syncthreads();
     for (int i = tid; i < CULL_RECORD / 4; i += CB)
         reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD)[i] = reinterpret_cast<const unsigned *>(scratch)[i];
+    // ---- every work item of the tail of the list leaves its cost estimate for k_mesh, which hands the tail out by
+    // descending cost (MeshArgs::order) ----
+    if (order && tid == 0) {
+        const int tail = min(tail_max, ctr->work_end - ctr->work_begin), tpos = w - (ctr->work_end - tail);
+        if (tpos >= 0) order[tpos] = (ntl < 0 ? 563 : ntl) * max(n_instr_w, 1);
+    }
     if (prof && tid == 0) {
         const unsigned *pacc = reinterpret_cast<const unsigned *>(scratch + CULL_COUNT + 80 + 1024);
+        atomicAdd(&prof[32 + (ntl < 0 ? 9 : min(ntl >> 6, 8))], 1ull);   // histogram of the listed tasks per work item, bins of 64
         atomicAdd(&prof[16], (unsigned long long)(tstart1 - tstart));
         atomicAdd(&prof[27], (unsigned long long)(t_b - tstart));
         atomicAdd(&prof[28], (unsigned long long)(t_axes - t_b));
@@ -280,27 +288,30 @@ template <bool FULL, bool RARE>
 __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out, unsigned long long *prof) {
+                                                     unsigned char *__restrict__ out, unsigned long long *prof,
+                                                     int *__restrict__ order, int tail_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<FULL, RARE>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof);
+    cull_body<FULL, RARE>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
 }
 // the variant for tapes without trigonometry and without the rarer leaves fits 80 VGPRs without spilling:
 // six waves per SIMD instead of five (the others would spill 64-160 bytes per lane at that budget)
 __global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out, unsigned long long *prof) {
+                                                     unsigned char *__restrict__ out, unsigned long long *prof,
+                                                     int *__restrict__ order, int tail_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof);
+    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
 }
 // (experiment: the same with two waves per workgroup -- twelve workgroups fit a CU, every work item of the 512^3
 // example is resident at once instead of in two rounds)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean128(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
-                                                     unsigned char *__restrict__ out, unsigned long long *prof) {
+                                                     unsigned char *__restrict__ out, unsigned long long *prof,
+                                                     int *__restrict__ order, int tail_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof);
+    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
 }
 
 // ordered compaction of the pending batches into the work list (single workgroup)
@@ -845,6 +856,7 @@ struct sdf_ctx {
     unsigned slot_seq = 0;
     int slot_streams = 1;             // SDF_SLOT_STREAMS=0: asynchronous calls stay on the context's stream (diagnostics)
     int cull_block = 256;             // SDF_CULL_BLOCK=128: the two-wave variant of k_cull_lean (tuning)
+    int tail_order = 1;               // SDF_TAIL_ORDER=0: k_mesh takes the whole work list in order
     int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
 };
 
@@ -867,7 +879,7 @@ struct sdf_mesh {
     sdf_ctx *ctx = nullptr;
     sdf_stats st = {};
     GridDesc g = {};
-    DevBuf axes, kinds, worklist, status, out, prune, tapes, cull;
+    DevBuf axes, kinds, worklist, status, out, prune, tapes, cull, order;
     DevBuf desc, cellrecs, trilist;   // two-pass meshing: per work item / per surface cell / per triangle (sdf_device.h ItemDesc)
     bool pruned = false;
     hipStream_t stream = nullptr;  // the stream the generating call ran on (the context's, or a call slot's lane)
@@ -987,6 +999,7 @@ static int ctx_init(sdf_ctx *c) {
     }
     if (const char *e = getenv("SDF_SLOT_STREAMS")) c->slot_streams = atoi(e);
     if (const char *e = getenv("SDF_CULL_BLOCK")) c->cull_block = atoi(e);
+    if (const char *e = getenv("SDF_TAIL_ORDER")) c->tail_order = atoi(e);
     if (const char *e = getenv("SDF_MESH_TWOPASS")) c->twopass = atoi(e);
     McTables t;
     memcpy(t.ntri, MC_NTRI, 256);
@@ -1002,7 +1015,7 @@ static int ctx_init(sdf_ctx *c) {
     if (const char *e = getenv("SDF_PRUNE_LIST_MIN")) c->prune_list_min = std::max(atoi(e), 0);
     if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
-    if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(256)) return 1; }
+    if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(512 + 4096 * 32)) return 1; }
     return 0;
 }
 
@@ -1044,6 +1057,11 @@ int sdf_ctx_set_cull(sdf_ctx *c, int enabled) {
     return 0;
 }
 
+int sdf_ctx_set_tail_order(sdf_ctx *c, int on) {
+    if (!c) return fail("sdf_ctx_set_tail_order: ctx is NULL");
+    c->tail_order = on ? 1 : 0;
+    return 0;
+}
 int sdf_ctx_set_twopass(sdf_ctx *c, int mode) {
     if (!c) return fail("sdf_ctx_set_twopass: ctx is NULL");
     c->twopass = mode < 0 ? -1 : (mode ? 1 : 0);
@@ -1497,9 +1515,13 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     }
     // second interval pass, per surviving batch: the groups of 4^3 cells the surface cannot be in are not sampled
     const bool culling = c->cull && intervals_ok && t->ia_complete;
+    // the tail of the work list is handed out by descending cost (MeshArgs::order, k_cull's estimates); fewer items
+    // than k_mesh has workgroups
+    const int tail_max = std::min<int>(MESH_TAIL_MAX, std::min(nb, c->n_cu) - 1);
+    const bool tail_order = culling && c->tail_order && tail_max >= 2;
     if (culling) {
-        if (c->prof.p) HIPCHK(hipMemsetAsync((unsigned char *)c->prof.p + 128, 0, 128, st));
-        if (m->cull.ensure((size_t)nb * CULL_RECORD)) return 1;
+        if (c->prof.p) HIPCHK(hipMemsetAsync((unsigned char *)c->prof.p + 128, 0, 384, st));
+        if (m->cull.ensure((size_t)nb * CULL_RECORD) || (tail_order && m->order.ensure(MESH_TAIL_MAX * sizeof(int)))) return 1;
         const int ia_np = (int)std::max(t->n_p, 1u), ia_nd = (int)std::max(t->n_d, 1u);
         auto kc = t->full ? (t->ia_rare ? k_cull<true, true> : k_cull<true, false>) : (t->ia_rare ? k_cull<false, true> : k_cull_lean);
         int cull_block = CULL_BLOCK;
@@ -1510,7 +1532,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
                            (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
-                           ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p, (unsigned long long *)c->prof.p);
+                           ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p, (unsigned long long *)c->prof.p,
+                           tail_order ? (int *)m->order.p : (int *)nullptr, tail_max);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(cs.e2, st));
@@ -1549,6 +1572,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         MeshArgs a;
         a.compact = 0; a.xf = nullptr; a.xf_cap = 0;
         a.twopass = 0; a.desc = nullptr; a.cells = nullptr; a.tlist = nullptr; a.cells_cap = a.tlist_cap = 0;
+        a.order = tail_order ? (const int *)m->order.p : nullptr; a.tail = tail_order ? tail_max : 0;
         if (compact) {
             const SlabLayout L(slab_items, cap_out);
             a.out = reinterpret_cast<double *>((unsigned char *)d_out + L.tris_off); a.out_cap = (unsigned long long)cap_out;
@@ -1641,12 +1665,28 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         HIPCHK(hipEventElapsedTime(&ms, own_start ? cs.e3 : cs.e2, cs.e4));
         m->st.ms_mesh = ms;
         if (c->prof.p) {
-            unsigned long long pc[32];
-            HIPCHK(hipMemcpy(pc, c->prof.p, 256, hipMemcpyDeviceToHost));
+            unsigned long long pc[64];
+            HIPCHK(hipMemcpy(pc, c->prof.p, 512, hipMemcpyDeviceToHost));
+            {   // timeline of the workgroups: when each ran out of work and when it was done, relative to the first start
+                std::vector<unsigned long long> tl((size_t)4 * grid);
+                HIPCHK(hipMemcpy(tl.data(), (unsigned char *)c->prof.p + 512, tl.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, t_end = 0;
+                double s_out = 0, s_done = 0, mn_out = 1e30, mx_out = 0;
+                for (int i = 0; i < grid; i++) t0 = std::min(t0, tl[4 * i]);
+                for (int i = 0; i < grid; i++) {
+                    const double o = (double)(tl[4 * i + 1] - t0) * 0.01, d = (double)(tl[4 * i + 2] - t0) * 0.01;   // us
+                    s_out += o; s_done += d; mn_out = std::min(mn_out, o); mx_out = std::max(mx_out, o); t_end = std::max(t_end, tl[4 * i + 2]);
+                }
+                fprintf(stderr, "[k_mesh prof] %d workgroups; out of work after min %.1f avg %.1f max %.1f us; done after avg %.1f, last %.1f us\n",
+                        grid, mn_out, s_out / grid, mx_out, s_done / grid, (double)(t_end - t0) * 0.01);
+            }
+            fprintf(stderr, "[k_cull prof] work items by listed tasks (of 563; bins of 64, last: not culled): %llu %llu %llu %llu %llu %llu %llu %llu %llu | %llu\n",
+                    pc[32], pc[33], pc[34], pc[35], pc[36], pc[37], pc[38], pc[39], pc[40], pc[41]);
             fprintf(stderr, "[k_cull prof] cycles of thread 0, summed over the workgroups: start %llu boxes %llu list %llu groups %llu (%llu passes, %llu groups) tasks %llu record %llu\n",
                     pc[16], pc[17], pc[18], pc[19], pc[23], pc[22], pc[20], pc[21]);
             fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu; start: work item %llu axes %llu (workgroups 1536..: %llu; max %llu) tape length %llu\n", pc[24], pc[25], pc[27], pc[28], pc[30], pc[31], pc[29]);
-            fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu\n", pc[8], pc[9], pc[10], pc[11]);
+            fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu; counting: rows %llu cell table %llu cells %llu list %llu\n",
+                    pc[8], pc[9], pc[10], pc[11], pc[12], pc[13], pc[14], pc[15]);
             fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked\n",
                     ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7]);
         }
@@ -2179,7 +2219,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
         m->out.p = nullptr; m->out.bytes = 0;
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
-    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->desc, &m->cellrecs, &m->trilist}) b->release();
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->order, &m->desc, &m->cellrecs, &m->trilist}) b->release();
     (void)hipFree(m->weld_pts); (void)hipFree(m->weld_inv);
     delete m;
     return 0;

@@ -53,6 +53,7 @@ ABI = {
     'sdf_ctx_set_prune': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_cull': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_twopass': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'sdf_ctx_set_tail_order': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_synchronize': (ctypes.c_int, [_vp]),
     'sdf_tape_create': (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _f64p, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
@@ -330,6 +331,10 @@ class Engine:
     def set_cull(self, enabled):
         """interval culling of cell groups inside a batch on / off (default on; results are identical)"""
         _check(self.lib, self.lib.sdf_ctx_set_cull(self.ctx, int(bool(enabled))))
+
+    def set_tail_order(self, on):
+        """hand the tail of the work list to the workgroups by descending cost (default) or in order; same results"""
+        _check(self.lib, self.lib.sdf_ctx_set_tail_order(self.ctx, int(bool(on))))
 
     def set_twopass(self, mode):
         """meshing scheme: 0 one kernel (look-back + parking), 1 three kernels (sample / number / emit), -1 the

@@ -1182,3 +1182,32 @@ def test_block_scan_of_the_kernels_on_device(tmp_path):
                     '-o', exe, os.path.join(ROOT, 'tests', 'native', 'scan_check.hip')], check=True, capture_output=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and 'bad=0' in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 24), ('ex_weave', 2 ** 22), ('ex_blobby', 2 ** 23), ('ex_pawn', 2 ** 23)])
+def test_tail_of_the_work_list_by_cost_or_in_order_same_soup(name, samples, ns, eng):
+    """k_mesh hands the last (workgroups - 1) surviving batches out by descending cost estimate (MeshArgs::order,
+    sdf_ctx_set_tail_order); in list order the soup, the per-batch offsets and the statistics must be the same, in both
+    meshing schemes, and small grids (fewer batches than workgroups) must take either path"""
+    f = fixtures.build(name, ns)
+    bounds = tuple(map(tuple, BOUNDS[name]))
+    res = {}
+    try:
+        for smp in (samples, 2 ** 16):
+            X, Y, Z, _ = core.grid_axes(bounds, samples=smp)
+            for mode in (0, 1):
+                eng.set_twopass(mode)
+                for on in (1, 0):
+                    eng.set_tail_order(on)
+                    m = eng.generate(f, X, Y, Z, 32, True)
+                    res[(smp, mode, on)] = (m.points(), m.kinds(), m.batch_offsets(), m.stats())
+                    m.close()
+    finally:
+        eng.set_twopass(-1)
+        eng.set_tail_order(1)
+    for (smp, mode, on), r in res.items():
+        ref = res[(smp, 0, 0)]
+        assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2]), (smp, mode, on)
+        for k in ('triangles', 'skipped', 'empty', 'nonempty', 'n_eval_voxels', 'n_ambiguous_cells', 'n_sampled_voxels', 'n_pruned_instrs'):
+            assert r[3][k] == ref[3][k], (smp, mode, on, k)
+    assert res[(samples, 0, 0)][3]['triangles'] > 1000
