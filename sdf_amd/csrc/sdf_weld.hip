@@ -93,8 +93,8 @@ int weld_device(hipStream_t stream, const double *pts, long long n, double **d_u
     WCHK(hipGetLastError());
     WCHK(hipStreamSynchronize(stream));
 done:
-    hipFree(k0); hipFree(k1); hipFree(p0); hipFree(p1); hipFree(tmp);
-    if (rc) { hipFree(*d_uniq); hipFree(*d_inv); *d_uniq = nullptr; *d_inv = nullptr; }
+    for (void *q : {(void *)k0, (void *)k1, (void *)p0, (void *)p1, (void *)tmp}) (void)hipFree(q);
+    if (rc) { (void)hipFree(*d_uniq); (void)hipFree(*d_inv); *d_uniq = nullptr; *d_inv = nullptr; }
     return rc;
 }
 
