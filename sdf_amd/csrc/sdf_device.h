@@ -774,8 +774,6 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             return (unsigned)(~(ones | zeros)) & (c2 >= 32 ? 0xFFFFFFFFu : ((1u << c2) - 1u));
         };
         // ---- 2a. surface cells per row, their running count over the rows (the order of the soup) ----
-        long long tcnt = a.prof ? clock64() : 0;
-#define SDF_CNTPROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tcnt)); tcnt = tn; } } while (0)
         int ncells = 0, row_cell0[RPT];
         SDF_UNROLL
         for (int k = 0; k < RPT; k++) {
@@ -791,7 +789,6 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             row_cell0[k] = ncells + block_exclusive_scan<BLOCK>(__popc(mask), wave_sums, tot);
             ncells += tot;
         }
-        SDF_CNTPROF(12);
         // ---- 2b. ONE THREAD PER SURFACE CELL (up to MESH_CELL_CHUNKS * BLOCK of them).  The row's thread only
         // SCATTERS its cells -- (row, column, sign configuration) into a table at the cell's running index, a few
         // ALU instructions and one LDS write each, nothing to wait for; then thread s takes cell s: looks up its
@@ -816,11 +813,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 while (m) {
                     const int i2 = __ffs((int)m) - 1;
                     m &= m - 1u;
-                    list[pos++] = (unsigned)r | ((unsigned)i2 << 10) | (cell_config(row_bits[k], i2) << 15);
+                    list[pos++] = (unsigned)r | ((unsigned)i2 << 10);   // (the cell's thread works out the configuration: below)
                 }
             }
             __syncthreads();
-            SDF_CNTPROF(13);
             per_cell = true;
             SDF_UNROLL
             for (int k = 0; k < MESH_CELL_CHUNKS; k++) {
@@ -830,7 +826,12 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (sidx < ncells) {
                     const unsigned ce = list[sidx];
                     const int r = (int)(ce & 1023u), i2 = (int)((ce >> 10) & 31u), i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
-                    const unsigned cfg = ce >> 15;
+                    // the sign configuration from the row's four sign strings, read again here: in the scatter above it
+                    // cost the thread of a row ~40 instructions per surface cell, one cell after the other -- 32 in a row
+                    // along a flat face -- while every other lane waited (3.6 k cycles per batch)
+                    unsigned long long rb[4];
+                    row_signs(i0, i1, rb);
+                    const unsigned cfg = cell_config(rb, i2);
                     const unsigned e = ntri_lds[cfg];
                     if (e & 128u) {   // ambiguous configuration: Lewiner's tests pick the tiling (rare)
                         double lv[8];
@@ -849,7 +850,6 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (k * BLOCK < ncells) { coff[k] += block_exclusive_scan<BLOCK>(n, wave_sums, tot); total += tot; }   // (uniform)
                 cinfo[k] = info; cn[k] = n;
             }
-            SDF_CNTPROF(14);
             if (TWOPASS) {
                 list_ready = true;        // (no list in LDS: the entries go to the arena below)
             } else if (total <= a.list_cap) {
@@ -893,8 +893,6 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 total += tot;
             }
         }
-        SDF_CNTPROF(15);
-#undef SDF_CNTPROF
         // ---- the batch's count is public from here on; bookkeeping that needs no position ----
         if (tid < 64 && !TWOPASS) publish_count(a.status, w, work_begin, (unsigned long long)total);
         if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup

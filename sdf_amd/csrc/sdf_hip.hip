@@ -1685,8 +1685,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             fprintf(stderr, "[k_cull prof] cycles of thread 0, summed over the workgroups: start %llu boxes %llu list %llu groups %llu (%llu passes, %llu groups) tasks %llu record %llu\n",
                     pc[16], pc[17], pc[18], pc[19], pc[23], pc[22], pc[20], pc[21]);
             fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu; start: work item %llu axes %llu (workgroups 1536..: %llu; max %llu) tape length %llu\n", pc[24], pc[25], pc[27], pc[28], pc[30], pc[31], pc[29]);
-            fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu; counting: rows %llu cell table %llu cells %llu list %llu\n",
-                    pc[8], pc[9], pc[10], pc[11], pc[12], pc[13], pc[14], pc[15]);
+            fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu\n", pc[8], pc[9], pc[10], pc[11]);
             fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked\n",
                     ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7]);
         }
