@@ -11,6 +11,7 @@ import fixtures
 ns = {k: getattr(s, k) for k in dir(s) if not k.startswith('_')}
 eng = engine.get_engine(0)
 on_only = '--on-only' in sys.argv
+BS = int(os.environ.get('MODELTIME_BS', '32'))
 jobs = [a for a in sys.argv[1:] if not a.startswith('--')] or ['example:27', 'gearlike:27', 'gearlike:30', 'blobby:27', 'blobby:30', 'weave:24', 'weave:27', 'knurling:24']
 for job in jobs:
     name, k = job.split(':')
@@ -21,7 +22,7 @@ for job in jobs:
         best = None
         for _ in range(3):
             t0 = time.perf_counter()
-            m = eng.generate(f, X, Y, Z, 32, True); st = m.stats(); m.close()
+            m = eng.generate(f, X, Y, Z, BS, True); st = m.stats(); m.close()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         print('%-9s 2^%s %dx%dx%d passes %d: wall %.2f ms, prepass %.3f mesh %.3f ms; batches %d work %d tris %d; sampled %.1f%% pruned %.1f%%'
