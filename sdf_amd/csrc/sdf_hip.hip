@@ -147,8 +147,10 @@ __global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__rest
     }
 }
 
-// reference sdf/core.py:28-43.  16 lanes per batch: lane 0 = centre, lanes 1..8 = corners in
-// itertools.product((x0,x1),(y0,y1),(z0,z1)) order.  kinds[b] = 0 (skipped) or 255 (pending).
+// reference sdf/core.py:28-43.  9 lanes per batch, 7 batches per wave (lane 63 idles): lane 0 of a batch = centre,
+// lanes 1..8 = corners in itertools.product((x0,x1),(y0,y1),(z0,z1)) order.  kinds[b] = 0 (skipped) or 255 (pending).
+// (16 lanes per batch, 7 of them idle, until r02p: the kernel is the tape at 9 points per batch and nothing else.)
+enum { SKIP_BATCHES_PER_BLOCK = 7 * (256 / 64) };
 // Workgroups >= pa.first_block run the interval pass of the same batches instead (sdf_prune.h).
 template <typename T, bool FULL, bool RARE>
 __device__ __forceinline__ void skip_body(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
@@ -159,8 +161,8 @@ __device__ __forceinline__ void skip_body(const uint32_t *__restrict__ code, con
         prune_block<FULL, RARE>(code, c64, rstart, lstart, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
         return;
     }
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = gid >> 4, l = gid & 15;
+    const int lane = threadIdx.x & 63, slot = min(lane / 9, 6), l = lane - 9 * slot;    // (lane 63: l = 9, idle)
+    const int b = ((int)blockIdx.x * (256 / 64) + (int)(threadIdx.x >> 6)) * 7 + slot;
     const bool live = b < nbatches && l < 9;
     int ox = 0, oy = 0, oz = 0, lx = 1, ly = 1, lz = 1;
     if (b < nbatches) batch_origin(g, b, ox, oy, oz, lx, ly, lz);
@@ -173,7 +175,7 @@ __device__ __forceinline__ void skip_body(const uint32_t *__restrict__ code, con
     if (l >= 1) { const int k = l - 1; px = (k & 4) ? x1 : x0; py = (k & 2) ? y1 : y0; pz = (k & 1) ? z1 : z0; }
     T v = T(0);
     if (live) v = run_tape1<T, FULL>(code, consts, (T)px, (T)py, (T)pz);
-    const int lane = threadIdx.x & 63, base = lane & ~15;
+    const int base = 9 * slot;
     const T vc = __shfl(v, base, 64);          // centre
     const T v1 = __shfl(v, base + 1, 64);      // values[0]
     const bool pos = v1 > T(0);
@@ -1474,7 +1476,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     pa.first_block = 0x7fffffff;
     // many batches: the interval pass runs behind k_compact, for the surviving batches only (k_prune_list)
     const bool prune_listed = pruning && sparse && nb >= c->prune_list_min;
-    unsigned skip_blocks = sparse ? (unsigned)(((long long)nb * 16 + 255) / 256) : 0u, prune_blocks = 0;
+    unsigned skip_blocks = sparse ? (unsigned)((nb + SKIP_BATCHES_PER_BLOCK - 1) / SKIP_BATCHES_PER_BLOCK) : 0u, prune_blocks = 0;
     size_t prune_lds = 0;
     if (pruning) {
         if (m->prune.ensure((size_t)nb * 64) || m->tapes.ensure((size_t)nb * tape_stride * 8)) return 1;
