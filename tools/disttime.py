@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fixed costs of the multi-GPU exchange path, measured on ONE GPU with a one-rank RCCL group (GPU box):
-    python tools/disttime.py [steps]
+    python tools/disttime.py [steps [log2 samples]]      (a tiny grid, e.g. 16, shows the host's share of a step)
 The same job as bench.py (example at 512^3) through sdf_amd.dist: mesh into a slab, all-gather (one rank: a copy),
 k_expand, one host synchronisation per step; one and two steps in flight."""
 import os, sys, time, socket
@@ -21,7 +21,8 @@ td.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda
 eng = engine.get_engine(0)
 f, _ = bench.build_model('example')
 tape = eng.tape_for(f)
-X, Y, Z, _ = core.grid_axes(bench.EXAMPLE_BOUNDS, samples=2 ** 27)
+LOG2 = int(sys.argv[2]) if len(sys.argv) > 2 else 27
+X, Y, Z, _ = core.grid_axes(bench.EXAMPLE_BOUNDS, samples=2 ** LOG2)
 dev = torch.device('cuda', 0)
 for chunks in (1, 2):
     for depth in (1, 2):
