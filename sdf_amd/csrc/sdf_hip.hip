@@ -241,12 +241,6 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     const int w = ctr->work_begin + (int)blockIdx.x;
     if (w >= ctr->work_end) return;
     const int b = __builtin_amdgcn_readfirstlane(worklist[w]);   // (uniform: the tape is then read with scalar loads)
-    auto now_drained = [&]() -> long long {   // (profiling: the clock once every outstanding load has arrived)
-        long long t;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(b) : "memory");
-        return t;
-    };
-    const long long t_b = prof ? now_drained() : 0;
     int ox, oy, oz, lx, ly, lz;
     batch_origin(g, b, ox, oy, oz, lx, ly, lz);
     for (int i = tid; i < 99; i += CB) {
@@ -255,10 +249,9 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
         else if (i - 66 < lz) axes[i] = g.Z[oz + i - 66];
     }
     __syncthreads();
-    const long long t_axes = prof ? now_drained() : 0;
     const uint32_t *wcode = code + (size_t)b * (size_t)tape_stride * 2;
     const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
-    long long tstart1 = 0;
+    long long tstart1 = 0;   // (profiling: the clock once the work item, its axes and the length of its tape have arrived)
     if (prof) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart1) : "s"(n_instr_w) : "memory");
     const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd, prof);
     const long long tw = prof ? clock64() : 0;
@@ -276,11 +269,6 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
         const unsigned *pacc = reinterpret_cast<const unsigned *>(scratch + CULL_COUNT + 80 + 1024);
         atomicAdd(&prof[32 + (ntl < 0 ? 9 : min(ntl >> 6, 8))], 1ull);   // histogram of the listed tasks per work item, bins of 64
         atomicAdd(&prof[16], (unsigned long long)(tstart1 - tstart));
-        atomicAdd(&prof[27], (unsigned long long)(t_b - tstart));
-        atomicAdd(&prof[28], (unsigned long long)(t_axes - t_b));
-        atomicAdd(&prof[29], (unsigned long long)(tstart1 - t_axes));
-        if (blockIdx.x >= 1536) atomicAdd(&prof[30], (unsigned long long)(t_axes - t_b));
-        atomicMax(&prof[31], (unsigned long long)(t_axes - t_b));
         atomicAdd(&prof[21], (unsigned long long)(clock64() - tw));
         for (int k = 1; k < 10; k++) if (k != 5) atomicAdd(&prof[16 + k], (unsigned long long)pacc[k]);
     }
@@ -1686,7 +1674,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                     pc[32], pc[33], pc[34], pc[35], pc[36], pc[37], pc[38], pc[39], pc[40], pc[41]);
             fprintf(stderr, "[k_cull prof] cycles of thread 0, summed over the workgroups: start %llu boxes %llu list %llu groups %llu (%llu passes, %llu groups) tasks %llu record %llu\n",
                     pc[16], pc[17], pc[18], pc[19], pc[23], pc[22], pc[20], pc[21]);
-            fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu; start: work item %llu axes %llu (workgroups 1536..: %llu; max %llu) tape length %llu\n", pc[24], pc[25], pc[27], pc[28], pc[30], pc[31], pc[29]);
+            fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu\n", pc[24], pc[25]);
             fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu\n", pc[8], pc[9], pc[10], pc[11]);
             fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked\n",
                     ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7]);
