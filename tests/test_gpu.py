@@ -1211,3 +1211,35 @@ def test_tail_of_the_work_list_by_cost_or_in_order_same_soup(name, samples, ns, 
         for k in ('triangles', 'skipped', 'empty', 'nonempty', 'n_eval_voxels', 'n_ambiguous_cells', 'n_sampled_voxels', 'n_pruned_instrs'):
             assert r[3][k] == ref[3][k], (smp, mode, on, k)
     assert res[(samples, 0, 0)][3]['triangles'] > 1000
+
+
+def test_no_parking_and_tail_by_cost_do_not_wait_for_each_other():
+    """With parking off (SDF_PARK=0) EVERY batch waits for its predecessors' counts before it emits -- the case the
+    bound `tail <= workgroups - 1` on the reordered tail of the work list is there for ("The end of the
+    kernel").  A fresh process (the switch is read when the context is created) meshes three grids in both orders of
+    the tail (at these sizes the tail is the whole work list); the soups must be the reference's (gen_* goldens) and the
+    process must come back."""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import sdf_amd, fixtures
+from sdf_amd import core, engine
+ns = {k: getattr(sdf_amd, k) for k in dir(sdf_amd) if not k.startswith('_')}
+eng = engine.get_engine(0)
+for name in ('gen_example_s22', 'gen_blobby_s20', 'gen_example_s17'):
+    d = np.load(os.path.join(%r, name + '.npz'))
+    f = fixtures.build(str(d['fixture']), ns)
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
+    for on in (1, 0):
+        eng.set_tail_order(on)
+        m = eng.generate(f, X, Y, Z, 32, True)
+        sha = hashlib.sha256(m.points().tobytes()).hexdigest()
+        m.close()
+        assert sha == bytes(d['sha256']).hex(), (name, on)
+print('ok')
+''' % (ROOT, ROOT, GOLDEN)
+    r = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, SDF_PARK='0'), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
