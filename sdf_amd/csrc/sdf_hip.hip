@@ -1,10 +1,16 @@
 // sdf_hip.hip -- kernels + C ABI of libsdf_hip.so (gfx950 only).
 //
-// Kernels
-//   k_eval_points / k_eval_grid   f(P): the tape interpreter alone
+// Kernels (one call of sdf_generate enqueues k_skip -> k_compact [-> k_prune_list] -> k_cull -> k_mesh
+// [-> k_scan_items -> k_emit2] on one stream, without a host round trip in between)
+//   k_eval_points / k_eval_grid   f(P): the tape interpreter alone; k_eval_points_ext: with user closures (L_EXTERN)
+//   k_estimate_bounds             the reference's `_estimate_bounds` loop (sdf/core.py:62-82) as one launch
 //   k_skip                        the reference's `_skip` predicate for every batch at once
-//                                 (reference sdf/core.py:28-43), 16 lanes per batch
-//   k_compact                     ordered work list of the surviving batches
+//                                 (reference sdf/core.py:28-43), 9 lanes per batch, 7 batches per wave; its surplus
+//                                 workgroups run the interval pruning pass of the same batches (sdf_prune.h)
+//   k_compact                     ordered work list of the surviving batches; clears the counters / look-back words
+//   k_prune_list                  the pruning pass for the survivors only (grids with many batches)
+//   k_cull / k_cull_lean          per surviving batch: the sampling tasks that have to be evaluated, by interval
+//                                 arithmetic over groups of 4^3 cells (cull_tasks, sdf_device.h)
 //   k_mesh (sdf_device.h)         THE hot kernel: one persistent workgroup per CU pulls batches
 //                                 from the work list; samples the (<=33)^3 tile through the tape
 //                                 interpreter (float64 -> float32 like skimage's cast) straight
@@ -13,7 +19,12 @@
 //                                 the earlier batches' counts and writes the float64 world-space
 //                                 triangles in reference order (reference `_worker`,
 //                                 sdf/core.py:45-60, and `points.extend`, :141)
-//   k_mc_rows / k_mc_emit         marching cubes of a caller-supplied volume (`_marching_cubes`)
+//   k_scan_items / k_emit2        two-pass meshing (long tapes): k_mesh stops at the classification, these number
+//                                 and write the triangles
+//   k_pack_slab / k_expand        multi-GPU exchange: a shard's soup as a fixed-capacity slab / the gathered slabs
+//                                 expanded into the ordered float64 soup
+//   k_mc_rows / k_mc_emit         marching cubes of a caller-supplied volume (`_marching_cubes`);
+//   k_cast_f32 / k_field_*        the same for the batches of a host-evaluated field (user closures)
 //   k_stl                         50-byte STL records (reference sdf/stl.py:4-24)
 #include <hip/hip_runtime.h>
 
