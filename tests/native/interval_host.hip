@@ -158,6 +158,25 @@ int main() {
         auto d2 = [](double ax, double ay, double bx, double by) { return std::fma(ay, by, ax * bx); };
         auto leaf = [&](uint32_t op, const double *c, double x, double y, double z) -> double {
             switch (op) {
+            // the common leaves (ia_leaf): corner-exact forms, checked without a tolerance
+            case OP_L_SPHERE: return l3(x - c[1], y - c[2], z - c[3]) - c[0];
+            case OP_L_PLANE: return fma(c[5] - z, c[2], fma(c[4] - y, c[1], (c[3] - x) * c[0]));
+            case OP_L_BOX: { const double qx = fabs(x - c[0]) - c[3], qy = fabs(y - c[1]) - c[4], qz = fabs(z - c[2]) - c[5];
+                return l3(smax(qx, 0), smax(qy, 0), smax(qz, 0)) + smin(smax(smax(qx, qy), qz), 0); }
+            case OP_L_ROUNDED_BOX: { const double qx = fabs(x) - c[0] + c[3], qy = fabs(y) - c[1] + c[3], qz = fabs(z) - c[2] + c[3];
+                return l3(smax(qx, 0), smax(qy, 0), smax(qz, 0)) + smin(smax(smax(qx, qy), qz), 0) - c[3]; }
+            case OP_L_TORUS: return l2(l2(x, y) - c[0], z) - c[1];
+            case OP_L_CYLINDER: return l2(x, y) - c[0];
+            case OP_L_ROUNDED_CYLINDER: { const double d0 = l2(x, y) - c[0] + c[1], d1 = fabs(z) - c[2] + c[1];
+                return smin(smax(d0, d1), 0) + l2(smax(d0, 0), smax(d1, 0)) - c[1]; }
+            case OP_L_CAPSULE: { const double pax = x - c[0], pay = y - c[1], paz = z - c[2];
+                const double h = sclip(fma(paz, c[5], fma(pay, c[4], pax * c[3])) / c[6], 0.0, 1.0);
+                return l3(pax - c[3] * h, pay - c[4] * h, paz - c[5] * h) - c[7]; }
+            case OP_L_OCTAHEDRON: return (((fabs(x) + fabs(y)) + fabs(z)) - c[0]) * c[1];
+            case OP_L_CIRCLE: return l2(x - c[1], y - c[2]) - c[0];
+            case OP_L_LINE: return fma(c[3] - y, c[1], (c[2] - x) * c[0]);
+            case OP_L_RECTANGLE: { const double qx = fabs(x - c[0]) - c[2], qy = fabs(y - c[1]) - c[3];
+                return l2(smax(qx, 0), smax(qy, 0)) + smin(smax(qx, qy), 0); }
             case OP_L_WIREFRAME_BOX: {
                 const double t2 = c[3];
                 const double px = fabs(x) - c[0] - t2, py = fabs(y) - c[1] - t2, pz = fabs(z) - c[2] - t2;
@@ -284,13 +303,22 @@ int main() {
             default: return 0.0;
             }
         };
-        const uint32_t ops[] = {OP_L_TEXTURE2D, OP_L_CAPPED_CONE, OP_L_PYRAMID, OP_L_POLYGON,OP_L_WIREFRAME_BOX, OP_L_CAPPED_CYLINDER, OP_L_ROUNDED_CONE, OP_L_ELLIPSOID, OP_L_TETRAHEDRON, OP_L_DODECAHEDRON,
+        const uint32_t ops[] = {OP_L_SPHERE, OP_L_PLANE, OP_L_BOX, OP_L_ROUNDED_BOX, OP_L_TORUS, OP_L_CYLINDER, OP_L_ROUNDED_CYLINDER, OP_L_CAPSULE,
+                                OP_L_OCTAHEDRON, OP_L_CIRCLE, OP_L_LINE, OP_L_RECTANGLE,
+                                OP_L_TEXTURE2D, OP_L_CAPPED_CONE, OP_L_PYRAMID, OP_L_POLYGON,OP_L_WIREFRAME_BOX, OP_L_CAPPED_CYLINDER, OP_L_ROUNDED_CONE, OP_L_ELLIPSOID, OP_L_TETRAHEDRON, OP_L_DODECAHEDRON,
                                 OP_L_ICOSAHEDRON, OP_L_ROUNDED_RECTANGLE, OP_L_EQUILATERAL_TRIANGLE, OP_L_HEXAGON, OP_L_ROUNDED_X, OP_L_VESICA};
         long decided = 0, boxes = 0;
         for (uint32_t op : ops) {
             for (int it = 0; it < 60000; it++) {
                 double c[14 + 24 * 20];
                 for (int k = 0; k < 16; k++) c[k] = pick(0.1, 1.2);
+                if (op == OP_L_PLANE || op == OP_L_LINE) for (int k = 0; k < 6; k++) c[k] = pick(-1.5, 1.5);            // normal, point
+                if (op == OP_L_SPHERE || op == OP_L_CIRCLE || op == OP_L_BOX || op == OP_L_RECTANGLE) for (int k = 1; k < 3; k++) c[k] = pick(-1, 1);   // (centres)
+                if (op == OP_L_CAPSULE) {                // a, ba, |ba|^2, radius (d3.py:167-176)
+                    for (int k = 0; k < 6; k++) c[k] = pick(-1, 1);
+                    c[6] = (c[3] * c[3] + c[4] * c[4]) + c[5] * c[5]; c[7] = pick(0.05, 0.5);
+                    if (!(c[6] > 1e-3)) continue;
+                }
                 if (op == OP_L_CAPPED_CYLINDER) {      // a, ba, baba, -, radius, baba / 2 (d3.py:184-204)
                     for (int k = 0; k < 6; k++) c[k] = pick(-1, 1);
                     c[6] = (c[3] * c[3] + c[4] * c[4]) + c[5] * c[5]; c[8] = pick(0.05, 0.6) * c[6]; c[9] = c[6] * 0.5;
