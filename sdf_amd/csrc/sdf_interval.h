@@ -273,8 +273,13 @@ struct IaShared {
     double *base;
     int n_p;
     int stride;     // threads that share the array
-    __device__ __forceinline__ double &ps(uint32_t slot, int k) { return base[(slot * 6 + k) * stride + threadIdx.x]; }
-    __device__ __forceinline__ double &ds(uint32_t slot, int k) { return base[(n_p * 6 + slot * 2 + k) * stride + threadIdx.x]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ __forceinline__ static int lane_slot() { return (int)threadIdx.x; }
+#else
+    static int lane_slot() { return 0; }      // (host build of the interval run: one box at a time, tests/native/interval_tape_host.hip)
+#endif
+    SDF_IA double &ps(uint32_t slot, int k) { return base[(slot * 6 + k) * stride + lane_slot()]; }
+    SDF_IA double &ds(uint32_t slot, int k) { return base[(n_p * 6 + slot * 2 + k) * stride + lane_slot()]; }
 };
 __host__ __device__ inline size_t prune_lds_bytes(int n_p, int n_d) { return (size_t)(6 * n_p + 2 * n_d) * PRUNE_BLOCK * 8; }
 
@@ -675,16 +680,24 @@ __device__ __forceinline__ uint32_t mask_word(const uint32_t *m, int idx) {
     return r;
 }
 
+SDF_IA void ia_keep_bit(uint32_t *m, int i) {   // (mask_set_bit, host-compilable)
+    for (int k = 0; k < 8; k++) if ((i >> 5) == k) m[k] |= 1u << (i & 31);
+}
+
 // One pass of the tape over the box (x, y, z); returns the interval of the model's value.  All
 // lanes of the wave run the same tape (uniform control flow).  With DECIDE the 8 lanes of a batch
 // agree on which operands to drop with a ballot and every one of them records it: masks[0..8) skip
 // bits, masks[8..16) forced bits (without DECIDE rstart / lstart / masks are not touched).
+// (Without DECIDE the run also compiles for the host: tests/test_interval_host.py runs whole tapes over random boxes
+// and checks the CPU checker's point values against the intervals.)
 template <bool DECIDE, bool FULL, bool RARE>
-__device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, const double *__restrict__ consts,
-                                            const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart, int n_instr,
-                                            Ival x, Ival y, Ival z, bool live, IaShared sh, int n_d, uint32_t *masks) {
+SDF_IA Ival ia_run_tape(const uint32_t *__restrict__ code, const double *__restrict__ consts,
+                        const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart, int n_instr,
+                        Ival x, Ival y, Ival z, bool live, IaShared sh, int n_d, uint32_t *masks) {
     using namespace ia;
+#if defined(__HIP_DEVICE_COMPILE__)
     const int lane = threadIdx.x & 63, gbase = lane & ~7;
+#endif
     Ival acc = pt(0.0);
     for (int i = 0; i < sh.n_p; i++)
         for (int k = 0; k < 6; k++) sh.ps(i, k) = 0.0;
@@ -717,6 +730,7 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
             }
             int rs = 0xFFFF, ls = 0xFFFF;
             if constexpr (DECIDE) { rs = rstart[ip]; ls = lstart[ip]; }
+#if defined(__HIP_DEVICE_COMPILE__)
             if (DECIDE && rs != 0xFFFF && ls != 0xFFFF && rs <= ip && ls <= rs) {
                 const int d = live ? ia_decide(post, left, right, c[-1]) : 3;     // dead lanes agree with everything
                 const unsigned long long b1 = __ballot(d == 1 || d == 3), b2 = __ballot(d == 2 || d == 3);
@@ -731,6 +745,7 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
                     mask_set_bit(masks + 8, ip);
                 }
             }
+#endif
             acc = ia_post(post, left, right, c[-1]);
             continue;
         }
@@ -757,8 +772,8 @@ __device__ __forceinline__ Ival ia_run_tape(const uint32_t *__restrict__ code, c
             x = maxc(qx, 0.0); y = maxc(qy, 0.0); break; }
         case OP_REVOLVE: { const Ival nx = subc(len2(x, y), c[0]); y = z; x = nx; z = pt(0.0); break; }
         case OP_SETZ0: z = pt(0.0); break;
-        case OP_SAVE_P: psave(sa); if constexpr (DECIDE) mask_set_bit(keep, ip); break;
-        case OP_LOAD_P: pload(sa); if constexpr (DECIDE) mask_set_bit(keep, ip); break;
+        case OP_SAVE_P: psave(sa); if constexpr (DECIDE) ia_keep_bit(keep, ip); break;
+        case OP_LOAD_P: pload(sa); if constexpr (DECIDE) ia_keep_bit(keep, ip); break;
         case OP_PUSH_D: dsave(sa, acc); break;
         case OP_NOP: break;
         case OP_NEG: acc = neg(acc); break;
