@@ -294,8 +294,8 @@ __global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
     cull_body<FULL, RARE>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
 }
-// the variant for tapes without trigonometry and without the rarer leaves fits 80 VGPRs without spilling:
-// six waves per SIMD instead of five (the others would spill 64-160 bytes per lane at that budget)
+// the variant for tapes without trigonometry and without the rarer leaves: 70 VGPRs without spilling, seven waves per
+// SIMD (the others take 99 - 104; holding them to five or six waves was measured in r02p: no faster)
 __global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
