@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 2
+#define SDF_ABI_VERSION 3
 
 #define SDF_PRECISION_F64 0 /* parity mode: float64 sampling like the reference's NumPy path */
 #define SDF_PRECISION_F32 1 /* fast mode: float32 sampling */

@@ -104,7 +104,7 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _lib_lock = threading.Lock()
