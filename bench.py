@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the sampling + meshing hot path.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; started plainly (`python bench.py
+--gpus N`) the script launches those N ranks itself (same launcher, 127.0.0.1) and rank 0's line comes out of it.
 
 Workload (BASELINE.json configs[1]): the canonical CSG example (reference examples/example.py:
 sphere & box - 3 cylinders) on the 512^3 grid the reference builds for samples=2**27 over its own
 estimated bounds, sparse=True, batch_size=32.  One "step" = one complete pass of the hot path:
-skip prepass -> work list -> fused sample+march kernel -> ordered gather to the float64 (3T,3)
-soup in HBM (and, for N>1, the RCCL all-gather of the rank soups).  The axes are the only input
-(3 x 512 float64); the output stays in HBM inside the timed region (the PCIe-inclusive rate is
-reported separately as `value_incl_d2h`).  float64 sampling = the reference's NumPy precision.
+skip prepass -> work list -> interval passes -> fused sample+march kernel writing the ordered float64 (3T,3)
+soup in HBM (N > 1: every rank meshes its share of the work list into a slab, ONE RCCL all-gather, expansion into
+the same ordered soup on every rank).  The axes are the only input (3 x 512 float64); the output stays in HBM
+inside the timed region (the PCIe-inclusive rate is reported separately as `value_incl_d2h`).  float64 sampling =
+the reference's NumPy precision.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (k_mesh),
-`cpu_baseline` = the reference's own CPU path (NumPy thread pool + skimage; live where the reference is
-installed, else the committed build-container run, see `kind`), `cpu_port` = the C oracle timed live on one host core.
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (k_mesh), `cpu_baseline` = the
+reference's own CPU path (NumPy thread pool + skimage; live where the reference is installed, else the committed
+build-container run, see `kind`), `cpu_port` = the C oracle timed live on one host core, `isolated_calls` = what ONE
+synchronous call costs (min / median / max over back-to-back calls with nothing else in flight: what a drop-in
+caller of f.generate() sees), `clocks`, `other_configs` = BASELINE configs 3 - 5 at their real sizes (a few steps each).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,6 +46,9 @@ REFERENCE_PYTHON = '/opt/conda/bin/python3.9'
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
+# BASELINE.json configs[2..4] at their real sizes: (model, log2 samples, triangles the reference / the golden runs give)
+OTHER_CONFIGS = [('gearlike', 30, 10204096), ('weave', 33, 53943912), ('blobby', 30, 4048520)]
+
 
 def build_model(name):
     import sdf_amd as s
@@ -55,7 +66,6 @@ def build_model(name):
 def reference_cpu_baseline(samples_log2):
     """the `cpu_baseline` object from the reference's own generate(): live (subprocess of the reference's
     interpreter, tools/time_reference.py) or, where the reference is not installed, the committed numbers"""
-    import subprocess
     script = os.path.join(ROOT, 'tools', 'time_reference.py')
     rec, kind = None, None
     if os.path.isdir(REFERENCE_DIR) and os.path.exists(REFERENCE_PYTHON) and not os.environ.get('SDF_BENCH_NO_LIVE_REFERENCE'):
@@ -81,6 +91,50 @@ def reference_cpu_baseline(samples_log2):
             'soup_sha256': best.get('soup_sha256')}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks (one per GPU) under
+    torch.distributed.run on this node and hand their output through; rank 0 prints the JSON line"""
+    import socket
+    import torch
+    if not os.environ.get('SDF_BENCH_ONE_DEVICE'):
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus:
+            raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible on this node' % (args.gpus, n))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % args.gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # (dmabuf IPC: RCCL across processes needs it on this driver)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def read_clocks():
+    """current shader / memory clocks from rocm-smi (best effort; None where the tool is missing).  The clock the
+    kernels actually ran at is measured by the kernels themselves (`sclk_mhz_in_kernel`)."""
+    try:
+        out = subprocess.run(['rocm-smi', '--showclocks', '--json'], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        pick = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if 'sclk' in kl and 'level' in kl:
+                pick['sclk'] = v
+            elif 'mclk' in kl and 'level' in kl:
+                pick['mclk'] = v
+            elif 'fclk' in kl and 'level' in kl:
+                pick['fclk'] = v
+        return pick or None
+    except Exception:
+        return None
+
+
+def stats3(v):
+    v = np.asarray(v, dtype=np.float64)
+    return {'min': round(float(v.min()), 4), 'median': round(float(np.median(v)), 4), 'max': round(float(v.max()), 4), 'n': int(len(v))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -91,21 +145,24 @@ def main():
     ap.add_argument('--precision', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-check', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE configs 3 - 5 section')
     ap.add_argument('--sync', action='store_true', help='one step in flight: every call synchronises before the next is submitted')
     ap.add_argument('--inflight', type=int, default=4, help='steps in flight on a single GPU (each on a lane of its own; at most 4)')
+    ap.add_argument('--chunks', type=int, default=None, help='N > 1: shards per rank and step (default 1: one all-gather per step)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world and world > 1:
+    if args.gpus > 1 and world == 1 and 'RANK' not in os.environ:
+        self_launch(args)
+    if args.gpus != world:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
 
     import torch
-    # debugging aids for boxes with ONE GPU: SDF_BENCH_ONE_DEVICE=1 puts every rank on device 0,
-    # SDF_BENCH_BACKEND=gloo exchanges through host memory (RCCL refuses two ranks on one device)
+    # debugging aids for boxes with ONE GPU: SDF_BENCH_ONE_DEVICE=1 puts every rank on device 0, SDF_BENCH_BACKEND=gloo
+    # exchanges through gloo (RCCL refuses two ranks on one device), SDF_BENCH_COMM_DEVICE=cuda keeps the slabs on the
+    # device all the same (the device side of the protocol between two real processes)
     backend = os.environ.get('SDF_BENCH_BACKEND', 'nccl')
     if os.environ.get('SDF_BENCH_ONE_DEVICE'):
         local_rank = 0
@@ -122,162 +179,201 @@ def main():
     from sdf_amd import core, engine, dist
     eng = engine.get_engine(local_rank)
     eng.precision = engine.PRECISION_F64 if args.precision == 'f64' else engine.PRECISION_F32
-    f, _ = build_model(args.model)
-    tape = eng.tape_for(f)
-    if args.model == 'example':
-        bounds = EXAMPLE_BOUNDS
-    else:
-        bounds = core._estimate_bounds(f)
-    X, Y, Z, step = core.grid_axes(bounds, samples=2 ** args.samples_log2)
-    grid_voxels = len(X) * len(Y) * len(Z)
     dev = torch.device('cuda', local_rank)
-    comm_dev = dev if backend == 'nccl' else torch.device('cpu')
+    comm_dev = dev if (backend == 'nccl' or os.environ.get('SDF_BENCH_COMM_DEVICE') == 'cuda') else torch.device('cpu')
+    stat_dev = dev if backend == 'nccl' else torch.device('cpu')      # (the few scalars the ranks exchange about the run itself)
+    clocks_idle = read_clocks() if rank == 0 else None
 
-    state = {}
+    def soup_sha(soup, tris):
+        """sha256 of the first `tris` triangles of a soup on the device (torch tensor), copied out in pieces"""
+        import hashlib
+        h = hashlib.sha256()
+        piece = 1 << 22
+        for t0 in range(0, tris, piece):
+            h.update(soup[9 * t0:9 * min(tris, t0 + piece)].cpu().numpy().tobytes())
+        return h.hexdigest()
 
-    DEPTH = 1 if args.sync else max(1, min(args.inflight, 4))   # steps in flight (single GPU): step i+1 is submitted before step i is collected
-    inflight = []
+    def measure(model, samples_log2, steps, warmup, depth, bounds=None):
+        """W untimed + K timed steps of one job; a step is complete when its counters (N > 1: the gathered slab
+        headers) are back on the host.  Returns timings, per-step kernel times, the last step's soup + statistics."""
+        f, _ = build_model(model)
+        tape = eng.tape_for(f)
+        if bounds is None:
+            bounds = EXAMPLE_BOUNDS if model == 'example' else core._estimate_bounds(f)
+        X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** samples_log2)
+        state = {'n': 0}
+        inflight, mesh_ms, exch_ms, dev_ms, sclk = [], [], [], [], []
 
-    def collect():
-        mesh, buf = inflight.pop(0)
-        mesh.wait()
-        t = mesh.n_triangles
-        if not mesh.emitted:               # (the soup did not fit: it was meshed again into library memory)
-            big = torch.empty(max(t + t // 8, 1) * 9, dtype=torch.float64, device=dev)
-            mesh.emit_device(big.data_ptr())
-            state['bufs'] = [big if b is buf else b for b in state['bufs']]      # (identity, not tensor ==)
-            buf = big
-        state['last_buf'] = buf
-        st = mesh.stats()
-        state['stats'] = st
-        state['tris'] = t
-        mesh_ms.append(st['ms_mesh'])
-        mesh.close()
+        def collect():
+            mesh, buf = inflight.pop(0)
+            mesh.wait()
+            t = mesh.n_triangles
+            if not mesh.emitted:               # (the soup did not fit: it was meshed again into library memory)
+                big = torch.empty(max(t + t // 8, 1) * 9, dtype=torch.float64, device=dev)
+                mesh.emit_device(big.data_ptr())
+                state['bufs'] = [big if b is buf else b for b in state['bufs']]      # (identity, not tensor ==)
+                buf = big
+            state['soup'] = buf
+            st = mesh.stats()
+            state['stats'], state['tris'] = st, t
+            mesh_ms.append(st['ms_mesh']); dev_ms.append(st['ms_mesh_device']); sclk.append(st['sclk_mhz'])
+            mesh.close()
 
-    def collect_dist():
-        soup, st = dist.collect_sharded(inflight.pop(0))
-        state['buf'] = soup
-        state['stats'] = st
-        state['tris'] = st['triangles']
-        mesh_ms.append(st['ms_mesh'])            # this rank: prepass + k_mesh of its shard, into the slab
-        exch_ms.append((st['ms_exchange'], st['ms_expand']))
+        def collect_dist():
+            soup, st = dist.collect_sharded(inflight.pop(0))
+            state['soup'], state['stats'], state['tris'] = soup, st, st['triangles']
+            mesh_ms.append(st['ms_mesh'])            # this rank: prepass + k_mesh of its shard, into the slab
+            exch_ms.append((st['ms_exchange'], st['ms_expand']))
 
-    def one_step():
-        if world == 1:
-            # every step writes its ordered float64 soup into a device buffer of its own (DEPTH of them
-            # alternate), sized from the previous steps (first: a guess); the step is complete when its
-            # counters are back on the host (collect)
-            bufs = state.setdefault('bufs', [torch.empty(9 * (1 << 22), dtype=torch.float64, device=dev) for _ in range(DEPTH)])
-            buf = bufs[state.get('n', 0) % DEPTH]
-            state['n'] = state.get('n', 0) + 1
-            while len(inflight) >= DEPTH:
-                collect()
-            inflight.append((eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9, wait=False), buf))
-        else:
-            # N > 1: two exchange steps in flight on lanes of their own: step i + 1's meshing runs under step i's
-            # all-gather; a step is complete when its gathered headers are back on the host (collect_dist)
-            while len(inflight) >= (1 if args.sync else 2):
-                collect_dist()
-            state['n'] = state.get('n', 0) + 1
-            inflight.append(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=comm_dev, lane=state['n'] % 2))
+        def one_step():
+            if world == 1:
+                # every step writes its ordered float64 soup into a device buffer of its own (`depth` of them
+                # alternate), sized from the previous steps (first: a guess)
+                bufs = state.setdefault('bufs', [torch.empty(9 * (1 << 22), dtype=torch.float64, device=dev) for _ in range(depth)])
+                buf = bufs[state['n'] % depth]
+                state['n'] += 1
+                while len(inflight) >= depth:
+                    collect()
+                inflight.append((eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9, wait=False), buf))
+            else:
+                # N > 1: steps in flight run on lanes of their own: step i + 1's meshing runs under step i's all-gather
+                while len(inflight) >= depth:
+                    collect_dist()
+                state['n'] += 1
+                inflight.append(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=comm_dev, lane=state['n'] % 2, chunks=args.chunks))
 
-    def sync():
-        while inflight:
-            collect() if world == 1 else collect_dist()
-        eng.synchronize()
-        torch.cuda.synchronize()
-        if td is not None:
-            td.barrier()
+        def sync():
+            while inflight:
+                collect() if world == 1 else collect_dist()
+            eng.synchronize()
             torch.cuda.synchronize()
+            if td is not None:
+                td.barrier()
+                torch.cuda.synchronize()
 
-    mesh_ms, exch_ms = [], []
-    if world == 1:          # set-up, not a step: every call lane allocates its staging on first use (hundreds of MB each)
-        for _ in range(DEPTH + 1):
+        if world == 1:          # set-up, not a step: every call lane allocates its staging on first use (hundreds of MB each)
+            for _ in range(depth + 1):
+                one_step()
+            sync()
+        for _ in range(warmup):
             one_step()
         sync()
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    del mesh_ms[:], exch_ms[:]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    sync()                                 # every one of the K steps is complete (collected) here
-    dt = time.perf_counter() - t0
-    assert len(mesh_ms) == args.steps
-    per_rank = None
-    if td is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        dt = float(tt.item())
-        # per-rank device times of the three stages of a step (means over the timed steps)
-        mine = torch.tensor([float(np.mean(mesh_ms)), float(np.mean([e[0] for e in exch_ms])), float(np.mean([e[1] for e in exch_ms]))],
-                            dtype=torch.float64, device=comm_dev)
-        allr = torch.empty(3 * world, dtype=torch.float64, device=comm_dev)
-        td.all_gather_into_tensor(allr, mine)
-        per_rank = allr.cpu().numpy().reshape(world, 3)
+        del mesh_ms[:], exch_ms[:], dev_ms[:], sclk[:]
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        sync()                                 # every one of the K steps is complete (collected) here
+        dt = time.perf_counter() - t0
+        assert len(mesh_ms) == steps
+        if td is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=stat_dev)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            dt = float(tt.item())
+        return {'f': f, 'tape': tape, 'X': X, 'Y': Y, 'Z': Z, 'dt': dt, 'mesh_ms': list(mesh_ms), 'exch_ms': list(exch_ms),
+                'dev_ms': list(dev_ms), 'sclk': list(sclk), 'state': state, 'grid_voxels': len(X) * len(Y) * len(Z)}
 
+    DEPTH = 1 if args.sync else (max(1, min(args.inflight, 4)) if world == 1 else 2)
+    res = measure(args.model, args.samples_log2, args.steps, args.warmup, DEPTH)
+    clocks_busy = read_clocks() if rank == 0 else None       # (right behind the timed region)
+    f, tape, X, Y, Z, dt, state = res['f'], res['tape'], res['X'], res['Y'], res['Z'], res['dt'], res['state']
+    grid_voxels = res['grid_voxels']
+    mesh_ms, exch_ms = res['mesh_ms'], res['exch_ms']
     st = state['stats']
     tris = int(state['tris'])
     ms_per_step = 1e3 * dt / args.steps
     value = grid_voxels * args.steps / dt
+    per_rank = None
+    if td is not None:
+        # per-rank device times of the three stages of a step (means over the timed steps)
+        mine = torch.tensor([float(np.mean(mesh_ms)), float(np.mean([e[0] for e in exch_ms])), float(np.mean([e[1] for e in exch_ms]))],
+                            dtype=torch.float64, device=stat_dev)
+        allr = torch.empty(3 * world, dtype=torch.float64, device=stat_dev)
+        td.all_gather_into_tensor(allr, mine)
+        per_rank = allr.cpu().numpy().reshape(world, 3)
 
-    # latency of ONE call (submit -> counters back on the host), nothing else in flight
-    latency_ms = None
+    # parity check inside the bench run: the sha256 of the soup the LAST TIMED STEP left on the device
+    # (copied out after the timed region) against the hash of the reference's own soup on this grid
+    check = soup_hash = None
+    if not args.no_check:
+        last = state.get('soup')
+        if last is not None and tris * 9 <= last.numel() and rank == 0:
+            soup_hash = soup_sha(last, tris)
+        if args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64' and rank == 0:
+            check = bool(soup_hash == EXAMPLE_S27_SHA256 and
+                         (st['batches'], st['skipped'], st['empty'], st['nonempty'], tris) == (4096, 2352, 120, 1624, 2945152))
+
+    # ---- ONE call at a time (single GPU): what a drop-in caller of generate() sees.  A warm-up burst, then >= 20
+    # synchronous calls back to back, nothing else in flight; per call: wall time submit -> counters on the host,
+    # k_mesh by HIP events and by the kernel's own clock, the prepass ----
+    iso = None
     if world == 1:
-        sync()
-        n_lat = max(1, min(args.steps, 20))
         buf = state['bufs'][0]
-        t1 = time.perf_counter()
-        lat_mesh_ms, lat_pre_ms = [], []
-        for _ in range(n_lat):
+        n_lat = max(20, min(args.steps, 50))
+        wall, k_ev, k_dev, pre, sclk = [], [], [], [], []
+        for i in range(5 + n_lat):
+            t1 = time.perf_counter()
             mesh = eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9)
-            lat_mesh_ms.append(mesh.stats()['ms_mesh'])
-            lat_pre_ms.append(mesh.stats()['ms_prepass'])
+            w = time.perf_counter() - t1
+            s1 = mesh.stats()
             mesh.close()
-        latency_ms = 1e3 * (time.perf_counter() - t1) / n_lat
+            if i >= 5:
+                wall.append(1e3 * w); k_ev.append(s1['ms_mesh']); k_dev.append(s1['ms_mesh_device']); pre.append(s1['ms_prepass']); sclk.append(s1['sclk_mhz'])
+        iso = {'wall_ms': stats3(wall), 'k_mesh_ms_hip_events': stats3(k_ev), 'k_mesh_ms_device_clock': stats3(k_dev),
+               'prepass_ms': stats3(pre), 'sclk_mhz_in_kernel': stats3(sclk),
+               'what': 'synchronous sdf_generate_to_device calls back to back after 5 warm-up calls, nothing else in flight'}
+    clocks_iso = read_clocks() if rank == 0 else None
 
     # PCIe-inclusive variant (single GPU): same step + D2H of the soup into the ndarray `generate` returns (a recycled pinned block)
     incl = None
     if world == 1:
-        sync()
         n_incl = max(1, min(args.steps, 5))
-        pts = None
         for i in range(2 + n_incl):          # (two untimed passes: the result blocks are pinned once, then recycled)
             if i == 2:
                 t1 = time.perf_counter()
             mesh = eng.generate(tape, X, Y, Z, 32, True)
-            pts = mesh.points()
+            mesh.points()
             mesh.close()
         incl = grid_voxels * n_incl / (time.perf_counter() - t1)
 
-    # parity check inside the bench run: the sha256 of the soup the LAST TIMED STEP left in its device buffer
-    # (copied out after the timed region) against the hash of the reference's own soup on this grid
-    check = None
-    soup_sha = None
-    if not args.no_check and rank == 0:
-        import hashlib
-        last = state.get('last_buf') if world == 1 else state.get('buf')   # the soup the last timed step left on the device
-        if last is not None and tris * 9 <= last.numel():
-            soup_sha = hashlib.sha256(last[:tris * 9].cpu().numpy().tobytes()).hexdigest()
-        if args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64':
-            check = bool(soup_sha == EXAMPLE_S27_SHA256 and
-                         (st['batches'], st['skipped'], st['empty'], st['nonempty'], tris) == (4096, 2352, 120, 1624, 2945152))
+    # ---- BASELINE configs 3 - 5 at their real sizes (every rank takes part; a few steps each) ----
+    others = []
+    if not args.no_other_configs and args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64':
+        for model, log2, want_tris in OTHER_CONFIGS:
+            try:
+                r = measure(model, log2, 3, 1, 1 if world == 1 else 2)
+                s2, t2 = r['state']['stats'], int(r['state']['tris'])
+                o = {'workload': '%s @ samples=2**%d -> %dx%dx%d grid' % (model, log2, len(r['X']), len(r['Y']), len(r['Z'])),
+                     'n_gpus': world, 'steps': 3, 'ms_per_step': round(1e3 * r['dt'] / 3, 4),
+                     'value': round(r['grid_voxels'] * 3 / r['dt'], 1), 'unit': 'voxels/s', 'triangles': t2,
+                     'triangles_per_sec': round(t2 * 3 / r['dt'], 1), 'batches': int(s2['batches']), 'skipped': int(s2['skipped']),
+                     'triangles_match_reference': bool(t2 == want_tris),
+                     'device_ms': ({'prepass': round(float(s2['ms_prepass']), 4), 'mesh': round(float(np.median(r['mesh_ms'])), 4)} if world == 1 else
+                                   {'mesh': round(float(np.mean(r['mesh_ms'])), 4), 'exchange': round(float(np.mean([e[0] for e in r['exch_ms']])), 4),
+                                    'expand': round(float(np.mean([e[1] for e in r['exch_ms']])), 4), 'slab_bytes': s2.get('slab_bytes')})}
+                gold = os.path.join(ROOT, 'tests', 'golden', 'full_c5_blobby_s30.npz')
+                if model == 'blobby' and rank == 0 and os.path.exists(gold) and not args.no_check:
+                    o['soup_sha256_equals_reference'] = bool(soup_sha(r['state']['soup'], t2) == bytes(np.load(gold)['sha256']).hex())
+                others.append(o)
+                del r
+            except Exception as e:          # (reported, never fatal for the headline line)
+                others.append({'workload': '%s @ samples=2**%d' % (model, log2), 'error': repr(e)[:300]})
+            if td is not None:
+                td.barrier()
 
     if rank != 0:
         if td is not None:
             td.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (k_mesh), from HIP events on the library's stream ----
-    # (single GPU: the kernel's duration is taken from the calls that ran ALONE -- the latency loop above; in the timed
-    # region two calls are in flight on lanes of their own and the events around k_mesh include its wait for the
-    # compute units the previous call's k_mesh still holds; that figure is reported as `mesh_pipelined`)
-    k_ms = float(np.mean(lat_mesh_ms)) if world == 1 else float(np.mean(mesh_ms))
+    # ---- roofline of the dominant kernel (k_mesh), from HIP events on the stream the kernel runs on ----
+    # single GPU: the MEDIAN over the isolated calls above (the kernel alone on the device); with several calls in flight
+    # the events around k_mesh also cover its wait for compute units the neighbouring calls hold: `pipelined`
+    k_ms = iso['k_mesh_ms_hip_events']['median'] if world == 1 else float(np.mean(mesh_ms))
     shard_tris = int(st.get('n_triangles', tris)) if world == 1 else int(max(st.get('per_rank_triangles', [tris])))
     # fused design: the kernel's only HBM product is the ordered float64 soup, 9 doubles = 72 B per
-    # triangle (SURVEY 8d counts 36 B for a float32 soup; the reference's soup is float64)
-    alg_bytes = 72.0 * shard_tris
+    # triangle (SURVEY 8d counts 36 B for a float32 soup; the reference's soup is float64); the ranks of an
+    # N-GPU job write the 36-byte slab form instead
+    alg_bytes = (72.0 if world == 1 else 36.0) * shard_tris
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     plain, special = tape.tape.flop_estimate()
     eval_vox = int(st['n_eval_voxels']) if world == 1 else int(st['n_eval_voxels'] // world)
@@ -307,10 +403,12 @@ def main():
         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
         'traffic_source': ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured '
                            'in this run)' % traffic_src) if traffic_src else None,
-        'kernel_ms_source': 'HIP events around k_mesh in calls that ran alone (the latency loop of this run); with several '
-                            'calls in flight the same events read %.4f ms because the kernel then shares the compute units '
-                            'with the neighbouring calls\' prepass' % float(np.mean(mesh_ms)) if world == 1 else 'HIP events',
+        'kernel_ms_source': ('median of the HIP-event times around k_mesh over the isolated synchronous calls of this run '
+                             '(`isolated_calls`: min / median / max, and the same kernel by its own device clock)') if world == 1
+                            else 'HIP events on the exchange lane: prepass + k_mesh of this rank\'s shard (mean over the timed steps)',
         'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': round(k_ms, 4),
+        'kernel_ms_pipelined': stats3(mesh_ms) if world == 1 else None,
+        'kernel_ms_device_clock_pipelined': stats3(res['dev_ms']) if world == 1 and res['dev_ms'] else None,
         'note': 'path is VALU/latency bound by construction (SURVEY 8d): see valu',
         'valu': {'eval_voxels_per_launch': eval_vox, 'interpreted_voxels_per_launch': sampled_vox,
                  'pruned_instr_fraction': round(st.get('n_pruned_instrs', 0) / st['n_batch_instrs'], 4) if st.get('n_batch_instrs') else None,
@@ -323,12 +421,13 @@ def main():
     # timed live when the reference and its interpreter exist on this box (the build container); the GPU boxes
     # have neither, there the committed numbers of the build-container run are reported with that provenance
     cpu_ref = None
-    if not args.no_cpu_baseline and args.model == 'example' and args.samples_log2 == 27:
+    # (both CPU baselines: on rank 0 of the single-GPU run only)
+    if not args.no_cpu_baseline and world == 1 and args.model == 'example' and args.samples_log2 == 27:
         cpu_ref = reference_cpu_baseline(args.samples_log2)
 
     # ---- CPU baseline 2: the C oracle (a port of the reference path), one core, same workload, always live ----
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         import oracle
         nb = st['batches']
         # bounded sample: ~10-30 s of single-core work
@@ -352,29 +451,35 @@ def main():
                                % (args.model, args.samples_log2, len(X), len(Y), len(Z)),
                    'batches': int(st['batches']), 'skipped': int(st['skipped']), 'empty': int(st['empty']),
                    'nonempty': int(st['nonempty']), 'triangles': tris,
-                   'parallelism': 'work-list shards x%d + RCCL all-gather' % world if world > 1 else 'single GPU'},
+                   'parallelism': 'work-list shards x%d + one RCCL all-gather of the slabs per step' % world if world > 1 else 'single GPU'},
         'triangles_per_sec': round(tris * args.steps / dt, 1),
         'eval_voxels_per_sec': round(int(st['n_eval_voxels']) * args.steps / dt, 1),
         'value_incl_d2h': round(incl, 1) if incl else None,
-        'steps_in_flight': DEPTH if world == 1 else (1 if args.sync else 2),
-        'latency_ms_per_call': round(latency_ms, 4) if latency_ms else None,
-        'device_ms': ({'prepass': round(float(np.mean(lat_pre_ms)), 4), 'mesh': round(k_ms, 4), 'mesh_pipelined': round(float(np.mean(mesh_ms)), 4),
+        'steps_in_flight': DEPTH,
+        'latency_ms_per_call': iso['wall_ms']['median'] if iso else None,
+        'isolated_calls': iso,
+        'clocks': {'idle_before': clocks_idle, 'after_timed_region': clocks_busy, 'after_isolated_calls': clocks_iso,
+                   'sclk_mhz_in_kernel_pipelined': stats3(res['sclk']) if res['sclk'] else None,
+                   'source': 'rocm-smi --showclocks; sclk_mhz_in_kernel: k_mesh workgroup 0, shader cycle counter / 100 MHz counter'},
+        'device_ms': ({'prepass': iso['prepass_ms']['median'], 'mesh': round(k_ms, 4), 'mesh_pipelined': round(float(np.median(mesh_ms)), 4),
                        'emit': round(st.get('ms_emit', 0.0), 4)} if world == 1 else
                       {'per_rank_mesh': [round(float(v), 4) for v in per_rank[:, 0]],          # prepass + k_mesh of the rank's shard
                        'per_rank_exchange': [round(float(v), 4) for v in per_rank[:, 1]],      # the all-gather of the slabs
                        'per_rank_expand': [round(float(v), 4) for v in per_rank[:, 2]]}),      # slabs -> float64 soup
         'exchange_ms': None if world == 1 else round(float(per_rank[:, 1].max()), 4),
         'exchange': None if world == 1 else {'payload': st.get('payload'), 'slab_bytes': st.get('slab_bytes'), 'chunks': st.get('chunks'),
-                                             'collectives_per_step': st.get('chunks'), 'host_syncs_per_step': 1},
+                                             'collectives_per_step': st.get('chunks'), 'host_syncs_per_step': 1,
+                                             'driver': st.get('exchange', 'torch.distributed (%s)' % backend)},
         'parity_check': check,
-        'parity': {'soup_sha256': soup_sha, 'reference_sha256': EXAMPLE_S27_SHA256 if check is not None else None,
+        'parity': {'soup_sha256': soup_hash, 'reference_sha256': EXAMPLE_S27_SHA256 if check is not None else None,
                    'what': 'sha256 of the float64 soup of the last timed step (copied from its device buffer after the '
                            'timed region) vs the unmodified reference on the same grid (tests/golden/full_c2_example_s27.npz)'},
         'roofline': roofline,
         'cpu_baseline': cpu_ref if cpu_ref is not None else cpu,
         'cpu_port': cpu,
+        'other_configs': others or None,
     }
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if td is not None:
         td.destroy_process_group()
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 3
+#define SDF_ABI_VERSION 4
 
 #define SDF_PRECISION_F64 0 /* parity mode: float64 sampling like the reference's NumPy path */
 #define SDF_PRECISION_F32 1 /* fast mode: float32 sampling */
@@ -54,6 +54,9 @@ typedef struct sdf_stats {
     int64_t n_batch_instrs;     /* (instructions per tape) x (batches of the shard): the total they come out of    */
     int64_t n_sampled_voxels;   /* of n_eval_voxels, the samples that went through the interpreter (the rest lie in
                                  * cell groups whose interval excludes the surface; in lots of 64)                 */
+    double ms_mesh_device;      /* the sample+march kernel by the device's own constant-rate counter: first workgroup's
+                                 * start to last workgroup's end (no HIP event, no host in the measurement)        */
+    double sclk_mhz;            /* shader clock that kernel ran at (its cycle counter against the constant one)    */
 } sdf_stats;
 
 int sdf_abi_version(void);
@@ -183,6 +186,52 @@ int sdf_generate_compact_async(sdf_tape *tape, const double *X, int nx, const do
                                void *d_slab, int64_t cap_items, int64_t cap_tris, sdf_mesh **out);
 int sdf_expand_slabs(sdf_ctx *ctx, const void *const *d_slabs, int n_slabs, int64_t cap_items, int64_t cap_tris,
                      void *d_out, int64_t cap_out_tris);
+/* The multi-GPU step inside the library: one process per GPU, RCCL (dlopen'ed: librccl.so.1) over xGMI.
+ *   sdf_comm_unique_id   rank 0 draws one 128-byte id per lane (ncclGetUniqueId) and hands them to the other ranks out
+ *                        of band (sdf_amd/dist.py: through the process group that launched the ranks)
+ *   sdf_comm_create      collective: every rank, same ids, its own rank.  A communicator has 1 or 2 LANES -- a lane is
+ *                        an RCCL communicator + streams + persistent slab / gathered-slab / soup buffers -- so that two
+ *                        steps can be in flight: step i + 1 meshes while step i's all-gather is on the links.
+ *   sdf_generate_sharded_async   enqueue one step on a lane: mesh this rank's share of the surviving-batch work list
+ *                        (contiguous, `chunks` shards per rank; from SDF_SKIP_SHARD_MIN = 32768 batches on the skip
+ *                        test itself is shared out too and its one-byte verdicts all-gathered) into slabs, ONE
+ *                        ncclAllGather per shard, sdf_expand_slabs' kernel, the gathered headers to pinned memory.
+ *                        Nothing waits on the host.  Every rank must submit the same steps in the same order.
+ *   sdf_exchange_wait    the step's ONE host synchronisation: reads the gathered headers; slabs that were too small
+ *                        are flagged there -- every rank sees the same headers and repeats the step with the
+ *                        capacities the headers ask for (first call of a job: a guess, later calls: what the last one
+ *                        needed).  *d_soup = the complete ordered float64 soup (9 doubles per triangle, reference
+ *                        order: sdf/core.py:141) in library memory on THIS rank's GPU, valid until the next step is
+ *                        submitted on the same lane; identical on every rank and to the single-GPU soup. */
+#define SDF_COMM_ID_BYTES 128
+typedef struct sdf_comm sdf_comm;
+typedef struct sdf_exchange sdf_exchange;
+typedef struct sdf_exchange_stats {
+    int64_t n_batches, n_skipped, n_empty, n_nonempty, n_triangles, n_grid_voxels, n_eval_voxels, n_ambiguous_cells,
+        n_sampled_voxels, n_pruned_instrs;      /* whole job (sums over the ranks' slabs)                             */
+    int64_t n_retries, chunks, world, slab_bytes;
+    double ms_mesh, ms_exchange, ms_expand, ms_total;   /* this rank, HIP events on the lane: prepass + meshing of its
+                                                 * shard(s) / until the last all-gather has landed / k_expand / all   */
+    int64_t per_rank_triangles[64];
+} sdf_exchange_stats;
+int sdf_comm_unique_id(void *out_id128);
+int sdf_comm_create(sdf_ctx *ctx, const void *ids, int n_lanes, int rank, int world, sdf_comm **out);
+int sdf_comm_destroy(sdf_comm *comm);
+int sdf_generate_sharded_async(sdf_comm *comm, sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z,
+                               int nz, int batch_size, int sparse, int precision, int chunks, int lane, sdf_exchange **out);
+int sdf_exchange_wait(sdf_exchange *x, void **d_soup, int64_t *n_tris);
+int sdf_exchange_stats_get(sdf_exchange *x, sdf_exchange_stats *out);
+int sdf_exchange_destroy(sdf_exchange *x);
+/* `_skip` (reference sdf/core.py:28-43) alone, for batches [b_begin, b_end) of the grid: d_kinds (device memory, one
+ * byte per batch of the WHOLE grid) receives 0 (skipped) / 255 (to be meshed) at those positions.  And `generate` for a
+ * grid whose verdicts are already there (every byte of d_kinds set): what the sharded step does between its ranks. */
+int sdf_skip_kinds(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int batch_size,
+                   int64_t b_begin, int64_t b_end, int precision, void *d_kinds);
+int sdf_generate_from_kinds(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
+                            int batch_size, int64_t shard_index, int64_t shard_count, int precision, const void *d_kinds,
+                            sdf_mesh **out);
+/* device -> host copy on the context's stream (for soups in library memory: sdf_exchange_wait) */
+int sdf_memcpy_to_host(sdf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int sdf_mesh_stats(sdf_mesh *mesh, sdf_stats *out);
 int64_t sdf_mesh_triangles(sdf_mesh *mesh);
 /* write the (3T,3) float64 world-space soup (reference order; `points * scale + offset`,

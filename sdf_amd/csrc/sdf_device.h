@@ -47,11 +47,16 @@ struct MeshCounters {   // zeroed before every k_mesh run
     unsigned long long total;         // triangles of this shard (written by the workgroup of the last work item / by k_scan_items)
     unsigned long long cell_cursor;   // two-pass meshing: surface-cell records / triangle-list entries handed out so far
     unsigned long long list_cursor;
+    // the kernel's own clock readings (k_mesh): when its first workgroup started (kept as the maximum of ~t so that a
+    // zeroed block means "none yet") and its last one ended, in ticks of the constant 100 MHz counter; and what
+    // workgroup 0 saw between its start and its end on both counters (shader cycles / 100 MHz ticks = the shader clock
+    // the kernel actually ran at)
+    unsigned long long t_first_inv, t_last, clk_cycles, clk_ticks;
     // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
     // and this shard's slice of it, so k_mesh can start without a host round trip
     int nwork, work_begin, work_end, pad_;
 };
-enum { MESH_COUNTERS_RESET_BYTES = 72 };   // the part of MeshCounters cleared before every k_mesh run
+enum { MESH_COUNTERS_RESET_BYTES = 104 };   // the part of MeshCounters cleared before every k_mesh run
 
 struct GridDesc {
     const double *X, *Y, *Z;   // device copies of the np.arange axes
@@ -516,6 +521,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
 
     const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
     if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x] = wall_clock64();        // (timeline of the workgroup, 100 MHz)
+    if (tid == 0) {   // the kernel's start on the device's own clock (sdf_stats.ms_mesh_device, sclk_mhz)
+        const unsigned long long tw = wall_clock64();
+        atomicMax(&a.ctr->t_first_inv, ~tw);
+        if (blockIdx.x == 0) { a.ctr->clk_cycles = (unsigned long long)clock64(); a.ctr->clk_ticks = tw; }
+    }
     long long tprev = a.prof ? clock64() : 0;
 #define SDF_PROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     // position-dependent bookkeeping of work item w_ (thread 0)
@@ -1091,6 +1101,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     place_parked(pq_count > 0 && tid < 64 ? lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin) : 0ull, true);
     SDF_PROF(5);
     if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x + 2] = wall_clock64();
+    if (tid == 0) {
+        const unsigned long long tw = wall_clock64();
+        atomicMax(&a.ctr->t_last, tw);
+        if (blockIdx.x == 0) { a.ctr->clk_cycles = (unsigned long long)clock64() - a.ctr->clk_cycles; a.ctr->clk_ticks = tw - a.ctr->clk_ticks; }
+    }
 #undef SDF_FRESH
 #undef SDF_PROF
 }

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -138,9 +139,13 @@ __global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__rest
             atomicAdd(&work[0], 1);
             unsigned spins = 0;
             while (__hip_atomic_load(&work[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * (it + 1) && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
+            // (a workgroup that gives up -- the four were not co-resident for seconds: other kernels held the compute
+            // units -- must not go on with a partial hit box: workgroup 0 reports it, the host falls back to its loop)
+            if (spins >= (1u << 26)) stop = 2;
             __threadfence();
         }
         __syncthreads();
+        if (stop == 2) { if (blockIdx.x == 0 && tid == 0) out[6] = 2.0; return; }
         if (tid < 6) box[tid] = __hip_atomic_load(&slot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (box[3] == 0) { if (blockIdx.x == 0 && tid == 0) out[6] = 1.0; return; }       // no probe within the threshold
@@ -167,13 +172,14 @@ template <typename T, bool FULL, bool RARE>
 __device__ __forceinline__ void skip_body(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
                                               int nbatches, unsigned char *__restrict__ kinds, const PruneArgs &pa,
                                               const double *__restrict__ c64, const uint16_t *__restrict__ rstart,
-                                              const uint16_t *__restrict__ lstart, double *prune_lds) {
+                                              const uint16_t *__restrict__ lstart, double *prune_lds, int skip_b0) {
     if ((int)blockIdx.x >= pa.first_block) {   // (uniform)
         prune_block<FULL, RARE>(code, c64, rstart, lstart, pa, g, nbatches, (int)blockIdx.x - pa.first_block, prune_lds);
         return;
     }
     const int lane = threadIdx.x & 63, slot = min(lane / 9, 6), l = lane - 9 * slot;    // (lane 63: l = 9, idle)
-    const int b = ((int)blockIdx.x * (256 / 64) + (int)(threadIdx.x >> 6)) * 7 + slot;
+    // (the skip test of batches [skip_b0, nbatches): a rank of a multi-GPU job tests its share only, sdf_skip_kinds)
+    const int b = skip_b0 + ((int)blockIdx.x * (256 / 64) + (int)(threadIdx.x >> 6)) * 7 + slot;
     const bool live = b < nbatches && l < 9;
     int ox = 0, oy = 0, oz = 0, lx = 1, ly = 1, lz = 1;
     if (b < nbatches) batch_origin(g, b, ox, oy, oz, lx, ly, lz);
@@ -206,16 +212,18 @@ __device__ __forceinline__ void skip_body(const uint32_t *__restrict__ code, con
 template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void k_skip(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
                                               int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa,
-                                              const double *__restrict__ c64, const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart) {
+                                              const double *__restrict__ c64, const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart,
+                                              int skip_b0) {
     extern __shared__ double prune_lds[];
-    skip_body<T, FULL, false>(code, consts, g, nbatches, kinds, pa, c64, rstart, lstart, prune_lds);
+    skip_body<T, FULL, false>(code, consts, g, nbatches, kinds, pa, c64, rstart, lstart, prune_lds, skip_b0);
 }
 template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void k_skip_rare(const uint32_t *__restrict__ code, const T *__restrict__ consts, GridDesc g,
                                                    int nbatches, unsigned char *__restrict__ kinds, PruneArgs pa,
-                                                   const double *__restrict__ c64, const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart) {
+                                                   const double *__restrict__ c64, const uint16_t *__restrict__ rstart, const uint16_t *__restrict__ lstart,
+                                                   int skip_b0) {
     extern __shared__ double prune_lds[];
-    skip_body<T, FULL, true>(code, consts, g, nbatches, kinds, pa, c64, rstart, lstart, prune_lds);
+    skip_body<T, FULL, true>(code, consts, g, nbatches, kinds, pa, c64, rstart, lstart, prune_lds, skip_b0);
 }
 
 // The interval pass of sdf_prune.h as a kernel of its own, over this shard's work list: for grids with many
@@ -751,6 +759,34 @@ static int fail(const std::string &m) { g_err = m; return 1; }
         if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
+// Waiting for the device WITHOUT going to sleep.  hipStreamSynchronize / hipEventSynchronize block on an interrupt
+// after a short active wait; on a virtualised host the wake-up costs milliseconds (BENCH_r02: a synchronous 512^3 call
+// took 2.2 ms on the driver's box against 0.4 ms of device work).  The calls of this library last 0.3 - 40 ms, so the
+// host polls the completion signal (hipStreamQuery / hipEventQuery read it directly) for up to g_spin_us microseconds
+// and only then falls back to the blocking wait.  SDF_WAIT_SPIN_US=0 restores the blocking behaviour.
+static long g_spin_us = [] { const char *e = getenv("SDF_WAIT_SPIN_US"); return e ? atol(e) : 100000L; }();
+template <typename Query, typename Block>
+static hipError_t spin_then_block(Query query, Block block) {
+    if (g_spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned n = 0;; n++) {
+            const hipError_t e = query();
+            if (e != hipErrorNotReady) return e;
+            if ((n & 63u) == 63u &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > g_spin_us)
+                break;
+            __builtin_ia32_pause();
+        }
+    }
+    return block();
+}
+static hipError_t stream_wait(hipStream_t s) {
+    return spin_then_block([&] { return hipStreamQuery(s); }, [&] { return hipStreamSynchronize(s); });
+}
+static hipError_t event_wait(hipEvent_t ev) {
+    return spin_then_block([&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); });
+}
+
 // Device allocations are recycled through a small per-device free list: hipMalloc / hipFree cost
 // tens of microseconds each (and hipFree synchronises), which at ~1 ms per generate call was 10 %
 // of the step when every mesh allocated and freed its seven buffers.
@@ -1023,8 +1059,8 @@ static int ctx_init(sdf_ctx *c) {
 int sdf_ctx_destroy(sdf_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    for (auto &cs : c->slots) { if (cs.stream) (void)hipStreamSynchronize(cs.stream); cs.park.release(); }
+    (void)stream_wait(c->stream);
+    for (auto &cs : c->slots) { if (cs.stream) (void)stream_wait(cs.stream); cs.park.release(); }
     for (DevBuf *b : {&c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof, &c->park, &c->ext, &c->field_vals,
                       &c->field_vol, &c->field_tiles})
         b->release();
@@ -1072,8 +1108,8 @@ int sdf_ctx_set_twopass(sdf_ctx *c, int mode) {
 int sdf_ctx_synchronize(sdf_ctx *c) {
     if (!c) return fail("sdf_ctx_synchronize: ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (auto &cs : c->slots) if (cs.stream) HIPCHK(hipStreamSynchronize(cs.stream));
+    HIPCHK(stream_wait(c->stream));
+    for (auto &cs : c->slots) if (cs.stream) HIPCHK(stream_wait(cs.stream));
     return 0;
 }
 
@@ -1136,7 +1172,7 @@ int sdf_tape_set_prune_info(sdf_tape *t, const uint16_t *rstart, const uint16_t 
 int sdf_tape_destroy(sdf_tape *t) {
     if (!t) return 0;
     (void)hipSetDevice(t->ctx->device);
-    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)stream_wait(t->ctx->stream);
     if (t->d_code) (void)hipFree(t->d_code);
     if (t->d_c64) (void)hipFree(t->d_c64);
     if (t->d_c32) (void)hipFree(t->d_c32);
@@ -1197,7 +1233,7 @@ int sdf_eval_points_host(sdf_tape *t, const double *h_pts, int64_t n, int dim, d
     HIPCHK(hipMemcpyAsync(c->scratch_in.p, h_pts, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream));
     if (sdf_eval_points(t, c->scratch_in.p, n, dim, c->scratch_out.p, precision)) return 1;
     HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     return 0;
 }
 
@@ -1220,7 +1256,7 @@ int sdf_eval_grid_host(sdf_tape *t, const double *X, int nx, const double *Y, in
                 nx, ny, nz, (double *)c->scratch_out.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     return 0;
 }
 
@@ -1237,7 +1273,8 @@ int sdf_estimate_bounds(sdf_tape *t, double *h_out6, int precision) {
     HIPCHK(hipGetLastError());
     double h[7];
     HIPCHK(hipMemcpyAsync(h, c->scratch_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
+    if (h[6] == 2.0) return fail("sdf_estimate_bounds: the probe workgroups did not meet at their barrier (device busy): use the host loop");
     if (h[6] != 0.0) return fail("zero-size array to reduction operation maximum which has no identity");   // (NumPy's words, reference sdf/core.py:80)
     memcpy(h_out6, h, 48);
     return 0;
@@ -1262,7 +1299,7 @@ int sdf_eval_extern_points_host(sdf_tape *t, const double *h_pts, int64_t n, int
                 (double *)c->ext.p, 1, (double *)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_ext_pts, c->ext.p, ext_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     return 0;
 }
 
@@ -1285,7 +1322,7 @@ int sdf_eval_points_extern_host(sdf_tape *t, const double *h_pts, int64_t n, int
                 (double *)c->ext.p, 0, (double *)c->scratch_out.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     return 0;
 }
 
@@ -1305,13 +1342,13 @@ int sdf_marching_cubes(sdf_ctx *c, const void *d_volume, int n0, int n1, int n2,
     HIPCHK(hipGetLastError());
     unsigned long long total = 0;
     HIPCHK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     *n_tris = (int64_t)total;
     if (total && d_out && cap > 0) {
         hipLaunchKernelGGL(k_mc_emit, dim3(grid), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)d_volume, n0, n1, n2,
                            (const unsigned long long *)c->rows_off.p, (float *)d_out, (unsigned long long)cap);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(stream_wait(c->stream));
     }
     return 0;
 }
@@ -1330,7 +1367,7 @@ int sdf_marching_cubes_host(sdf_ctx *c, const float *h_vol, int n0, int n1, int 
     const int64_t ncopy = std::min<int64_t>(*n_tris, cap);
     if (ncopy > 0 && h_out) {
         HIPCHK(hipMemcpyAsync(h_out, c->scratch_out.p, (size_t)ncopy * 36, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(stream_wait(c->stream));
     }
     return 0;
 }
@@ -1372,6 +1409,24 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     return 0;
 }
 
+// the skip test (`_skip`, reference sdf/core.py:28-43) of batches [b0, b1) alone, enqueued on `st`: d_kinds[b] = 0 (skipped) or
+// 255 (pending) for those batches; the axes are on the device already (X, then Y, then Z)
+static int enqueue_skip(sdf_tape *t, const double *d_axes, int nx, int ny, int nz, int bs, int b0, int b1, int precision,
+                        unsigned char *d_kinds, hipStream_t st) {
+    if (b1 <= b0) return 0;
+    GridDesc g = {};
+    g.X = d_axes; g.Y = d_axes + nx; g.Z = d_axes + nx + ny;
+    g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
+    g.nbx = (nx + bs - 1) / bs; g.nby = (ny + bs - 1) / bs; g.nbz = (nz + bs - 1) / bs;
+    PruneArgs pa = {};
+    pa.first_block = 0x7fffffff;     // (no interval pass in this launch)
+    const unsigned blocks = (unsigned)((b1 - b0 + SKIP_BATCHES_PER_BLOCK - 1) / SKIP_BATCHES_PER_BLOCK);
+    LAUNCH_TAPE_ON(st, k_skip, dim3(blocks), dim3(256), 0, t, precision, g, b1, d_kinds, pa, (const double *)t->d_c64,
+                   (const uint16_t *)t->d_rstart, (const uint16_t *)t->d_lstart, b0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // the per-call statistics from the counters the meshing pass left (end of sdf_generate / sdf_mesh_wait)
 extern "C" int sdf_mesh_wait(sdf_mesh *m, int *emitted);
 
@@ -1385,6 +1440,9 @@ static void finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb
     m->st.n_eval_voxels = (int64_t)h.n_eval; m->st.n_ambiguous_cells = (int64_t)h.n_ambiguous;
     m->st.n_pruned_instrs = pruning ? (int64_t)h.n_pruned : 0;
     m->st.n_sampled_voxels = (int64_t)h.n_sampled;
+    // the kernel's own clock readings: 100 MHz ticks between the first workgroup's start and the last one's end
+    m->st.ms_mesh_device = (h.t_first_inv && h.t_last > ~h.t_first_inv) ? (double)(h.t_last - ~h.t_first_inv) * 1e-5 : 0.0;
+    m->st.sclk_mhz = h.clk_ticks ? (double)h.clk_cycles / (double)h.clk_ticks * 100.0 : 0.0;
     m->pruned = pruning;
     m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
@@ -1394,8 +1452,12 @@ static void finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb
 
 static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
                          int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out,
-                         bool async_mode = false, int64_t slab_items = -1) {
+                         bool async_mode = false, int64_t slab_items = -1, hipStream_t lane_stream = nullptr,
+                         const unsigned char *d_kinds_in = nullptr) {
     // slab_items >= 0: compact mode (sdf_generate_compact_async) -- d_out is a SLAB of capacity (slab_items, cap_out)
+    // lane_stream: the stream the whole call is enqueued on (the exchange steps of sdf_comm run on lanes of their own)
+    // d_kinds_in: the skip test's verdict for every batch is already on the device (0 skipped / 255 pending, n_batches
+    // bytes: sdf_skip_kinds, possibly all-gathered from the ranks that each tested a share): k_skip is not run
     sdf_ctx *c = t->ctx;
     const bool compact = slab_items >= 0;
     // a free call slot; when all are held by calls in flight, the oldest of them is COLLECTED first (its counters
@@ -1408,7 +1470,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         slot = (int)(c->slot_seq % SDF_CALL_SLOTS);
         CallSlot &held = c->slots[slot];
         if (held.owner && held.owner->pend.active) { if (sdf_mesh_wait(held.owner, nullptr)) return 1; }
-        else { HIPCHK(hipEventSynchronize(held.done)); }
+        else { HIPCHK(event_wait(held.done)); }
         held.busy = false; held.owner = nullptr;
     }
     c->slot_seq = (unsigned)slot + 1u;
@@ -1419,8 +1481,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     // the kernels of the other.  Everything a call touches is its own (per-mesh buffers, per-slot staging / events /
     // park slots), so the streams need no ordering among themselves.  An adopted caller stream is never left.
     const bool own_lane = async_mode && !compact && c->stream == c->own_stream && c->slot_streams;
-    hipStream_t st = own_lane ? cs.stream : c->stream;
-    m->stream = own_lane ? st : nullptr;
+    hipStream_t st = lane_stream ? lane_stream : (own_lane ? cs.stream : c->stream);
+    m->stream = (own_lane || lane_stream) ? st : nullptr;
     char *stage = (char *)c->h_stage + (size_t)slot * SDF_STAGE_BYTES;
     GridDesc &g = m->g;
     g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
@@ -1475,7 +1537,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     pa.first_block = 0x7fffffff;
     // many batches: the interval pass runs behind k_compact, for the surviving batches only (k_prune_list)
     const bool prune_listed = pruning && sparse && nb >= c->prune_list_min;
-    unsigned skip_blocks = sparse ? (unsigned)((nb + SKIP_BATCHES_PER_BLOCK - 1) / SKIP_BATCHES_PER_BLOCK) : 0u, prune_blocks = 0;
+    unsigned skip_blocks = (sparse && !d_kinds_in) ? (unsigned)((nb + SKIP_BATCHES_PER_BLOCK - 1) / SKIP_BATCHES_PER_BLOCK) : 0u, prune_blocks = 0;
     size_t prune_lds = 0;
     if (pruning) {
         if (m->prune.ensure((size_t)nb * 64) || m->tapes.ensure((size_t)nb * tape_stride * 8)) return 1;
@@ -1496,11 +1558,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         }
         const size_t skip_lds = prune_blocks ? prune_lds : 0;
         if (t->ia_rare) LAUNCH_TAPE_ON(st, k_skip_rare, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa,
-                                       (const double *)t->d_c64, (const uint16_t *)t->d_rstart, (const uint16_t *)t->d_lstart);
+                                       (const double *)t->d_c64, (const uint16_t *)t->d_rstart, (const uint16_t *)t->d_lstart, 0);
         else LAUNCH_TAPE_ON(st, k_skip, dim3(skip_blocks + prune_blocks), dim3(256), skip_lds, t, precision, g, nb, (unsigned char *)m->kinds.p, pa,
-                            (const double *)t->d_c64, (const uint16_t *)t->d_rstart, (const uint16_t *)t->d_lstart);
+                            (const double *)t->d_c64, (const uint16_t *)t->d_rstart, (const uint16_t *)t->d_lstart, 0);
     }
     if (!sparse) HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, st));
+    else if (d_kinds_in) HIPCHK(hipMemcpyAsync(m->kinds.p, d_kinds_in, (size_t)nb, hipMemcpyDeviceToDevice, st));   // (k_mesh writes its verdicts into the mesh's own copy)
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
                        (MeshCounters *)m->counters.p, (unsigned long long *)m->status.p, (long long)shard_index,
                        (long long)shard_count);
@@ -1519,7 +1582,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     // the tail of the work list is handed out by descending cost (MeshArgs::order, k_cull's estimates); fewer items
     // than k_mesh has workgroups
     const int tail_max = std::min<int>(MESH_TAIL_MAX, std::min(nb, c->n_cu) - 1);
-    const bool tail_order = culling && c->tail_order && tail_max >= 2;
+    // (not for calls in flight next to others: the argument that a reordered tail cannot stall -- fewer tail items than
+    // workgroups -- counts RESIDENT workgroups, and a k_mesh that shares the device with another call's k_mesh may have
+    // fewer of them for a while; the neighbours fill the tail of such a call anyway)
+    const bool tail_order = culling && c->tail_order && tail_max >= 2 && !async_mode;
     if (culling) {
         if (c->prof.p) HIPCHK(hipMemsetAsync((unsigned char *)c->prof.p + 128, 0, 384, st));
         if (m->cull.ensure((size_t)nb * CULL_RECORD) || (tail_order && m->order.ensure(MESH_TAIL_MAX * sizeof(int)))) return 1;
@@ -1559,7 +1625,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         } else {
             quiet = false;
             HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stream_wait(st));
             const unsigned long long nshard0 = (unsigned long long)std::max(h.work_end - h.work_begin, 1);
             cap = std::max<unsigned long long>(4096ull * nshard0, 1ull << 16);
             // a guess, not a need (the overflow re-run finds the exact size): never more than half the free memory
@@ -1661,7 +1727,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             pd.axes.assign(X, X + nx); pd.axes.insert(pd.axes.end(), Y, Y + ny); pd.axes.insert(pd.axes.end(), Z, Z + nz);
             return 0;
         }
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stream_wait(st));
         h = *hp;
         HIPCHK(hipEventElapsedTime(&ms, own_start ? cs.e3 : cs.e2, cs.e4));
         m->st.ms_mesh = ms;
@@ -1714,7 +1780,7 @@ int sdf_mesh_destroy(sdf_mesh *m);
 
 static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
                           int sparse, int64_t shard_index, int64_t shard_count, int precision, void *d_out, int64_t cap_out,
-                          sdf_mesh **out, bool async_mode = false, int64_t slab_items = -1) {
+                          sdf_mesh **out, bool async_mode = false, int64_t slab_items = -1, const unsigned char *d_kinds_in = nullptr) {
     if (!t || !X || !Y || !Z || !out) return fail("sdf_generate: NULL argument");
     *out = nullptr;
     if (t->n_extern) return fail("sdf_generate: the tape reads user closures (L_EXTERN): mesh it with sdf_generate_field");
@@ -1726,7 +1792,7 @@ static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y,
     HIPCHK(hipSetDevice(c->device));
     sdf_mesh *m = new sdf_mesh();
     m->ctx = c;
-    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out, async_mode, slab_items)) {
+    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out, async_mode, slab_items, nullptr, d_kinds_in)) {
         const std::string keep = g_err;
         sdf_mesh_destroy(m);
         g_err = keep;
@@ -1749,6 +1815,12 @@ int sdf_generate_to_device(sdf_tape *t, const double *X, int nx, const double *Y
     if (generate_entry(t, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_tris, out)) return 1;
     if (emitted) *emitted = ((*out)->emitted_to == d_out || (*out)->st.n_triangles == 0) ? 1 : 0;
     return 0;
+}
+
+int sdf_generate_from_kinds(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
+                            int64_t shard_index, int64_t shard_count, int precision, const void *d_kinds, sdf_mesh **out) {
+    if (!d_kinds) return fail("sdf_generate_from_kinds: d_kinds is NULL");
+    return generate_entry(t, X, nx, Y, ny, Z, nz, bs, 1, shard_index, shard_count, precision, nullptr, 0, out, false, -1, (const unsigned char *)d_kinds);
 }
 
 int sdf_generate_to_device_async(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
@@ -1877,7 +1949,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
                            (unsigned long long *)c->rows_off.p, d_total);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(offs.data(), c->rows_off.p, (nslots + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(stream_wait(c->stream));
         const unsigned long long chunk_total = offs[nslots];
         for (int j = 0; j < nt; j++) {
             const unsigned long long cnt = offs[(size_t)(j + 1) * 1024] - offs[(size_t)j * 1024];
@@ -1889,7 +1961,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
                 DevBuf bigger;
                 if (bigger.ensure(std::max<size_t>((size_t)(total + chunk_total) * 72 * 2, (size_t)1 << 22))) return 1;
                 if (total) HIPCHK(hipMemcpyAsync(bigger.p, m->out.p, (size_t)total * 72, hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));
+                HIPCHK(stream_wait(c->stream));
                 m->out.release();
                 m->out = bigger;
             }
@@ -1897,7 +1969,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
                                (const FieldTile *)c->field_tiles.p, (const unsigned long long *)c->rows_off.p, (double *)m->out.p, total,
                                (unsigned long long)(m->out.bytes / 72));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(c->stream));   // (the chunk's buffers are refilled next)
+            HIPCHK(stream_wait(c->stream));   // (the chunk's buffers are refilled next)
             total += chunk_total;
         }
     }
@@ -1906,7 +1978,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
     if (m->kinds.ensure((size_t)nb)) return 1;
     // (work items of other shards stay 255 = "other shard", like sdf_generate)
     HIPCHK(hipMemcpyAsync(m->kinds.p, kinds.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     *out = m;
     m = nullptr;
     return 0;
@@ -1946,7 +2018,7 @@ int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
         sdf_ctx *c = m->ctx;
         HIPCHK(hipSetDevice(c->device));
         CallSlot &cs = c->slots[pd.slot];
-        HIPCHK(hipEventSynchronize(cs.done));
+        HIPCHK(event_wait(cs.done));
         pd.active = false;
         const MeshCounters h = *(const MeshCounters *)((char *)c->h_stage + (size_t)pd.slot * SDF_STAGE_BYTES + SDF_STAGE_BYTES - 256);
         float ms = 0, ms_pre = 0, ms_tot = 0;
@@ -2008,7 +2080,7 @@ int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     HIPCHK(hipMemcpyAsync(d_out, mesh_soup(m), (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[4], c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     m->st.ms_emit = ms;
@@ -2021,7 +2093,7 @@ int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
 // workgroups: the same 7.5 ms.  One copy it stays.)
 static int copy_to_host(sdf_ctx *c, void *h_dst, const void *d_src, size_t bytes) {
     HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     return 0;
 }
 
@@ -2040,7 +2112,7 @@ int sdf_mesh_emit_host_range(sdf_mesh *m, int64_t first_tri, int64_t n_tris, dou
     if (n_tris == 0) return 0;
     HIPCHK(hipSetDevice(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, (const char *)mesh_soup(m) + (size_t)first_tri * 72, (size_t)n_tris * 72, hipMemcpyDeviceToHost, m->ctx->stream));
-    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(stream_wait(m->ctx->stream));
     return 0;
 }
 
@@ -2059,7 +2131,7 @@ int sdf_mesh_batch_offsets(sdf_mesh *m, int64_t *h_out) {
     std::vector<unsigned long long> stw((size_t)nw);
     HIPCHK(hipMemcpyAsync(wl.data(), (const int *)m->worklist.p + m->work_begin, (size_t)nw * 4, hipMemcpyDeviceToHost, m->ctx->stream));
     HIPCHK(hipMemcpyAsync(stw.data(), (const unsigned long long *)m->status.p + m->work_begin, (size_t)nw * 8, hipMemcpyDeviceToHost, m->ctx->stream));
-    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(stream_wait(m->ctx->stream));
     // h_out[b + 1] = triangles of batch b for now; the running sum follows
     unsigned long long prev = 0;
     for (int i = 0; i < nw; i++) {
@@ -2110,7 +2182,7 @@ int sdf_mesh_weld_fetch(sdf_mesh *m, double *h_points, int64_t *h_cells) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(h_points, m->weld_pts, (size_t)m->weld_n * 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(h_cells, m->weld_inv, (size_t)m->st.n_triangles * 24, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_wait(c->stream));
     return 0;
 }
 
@@ -2188,7 +2260,7 @@ int sdf_mesh_kinds(sdf_mesh *m, uint8_t *h_out) {
     if (m->st.n_batches == 0) return 0;
     HIPCHK(hipSetDevice(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, m->kinds.p, (size_t)m->st.n_batches, hipMemcpyDeviceToHost, m->ctx->stream));
-    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(stream_wait(m->ctx->stream));
     for (int64_t i = 0; i < m->st.n_batches; i++) if (h_out[i] == 255) h_out[i] = 3;
     return 0;
 }
@@ -2201,7 +2273,7 @@ int sdf_mesh_prune_masks(sdf_mesh *m, uint32_t *h_out) {
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, m->prune.p, n * 64, hipMemcpyDeviceToHost, m->ctx->stream));
-    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(stream_wait(m->ctx->stream));
     return 0;
 }
 
@@ -2209,8 +2281,8 @@ int sdf_mesh_destroy(sdf_mesh *m) {
     if (!m) return 0;
     sdf_ctx *c = m->ctx;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    if (m->stream) (void)hipStreamSynchronize(m->stream);        // (a call slot's lane)
+    (void)stream_wait(c->stream);
+    if (m->stream) (void)stream_wait(m->stream);        // (a call slot's lane)
     if (m->pend.active) { c->slots[m->pend.slot].busy = false; c->slots[m->pend.slot].owner = nullptr; m->pend.active = false; }   // (abandoned; the stream is idle now)
     if (m->out.p) {   // keep one soup buffer around for the next call
         if (c->arena_pool.empty()) c->arena_pool.push_back(m->out);
@@ -2226,3 +2298,5 @@ int sdf_mesh_destroy(sdf_mesh *m) {
 }
 
 }  // extern "C"
+
+#include "sdf_comm.inc"

@@ -36,10 +36,10 @@ import weakref
 import numpy as np
 
 HEADER_WORDS = 16          # int64 words at the head of a slab (include/sdf_hip.h)
+MAX_SLABS = 64             # slabs one sdf_expand_slabs call takes
 H_TRIS, H_ITEMS, H_OVERFLOW, H_EMPTY, H_NONEMPTY, H_EVAL, H_AMBIGUOUS, H_SAMPLED, H_PRUNED, H_WORK = range(10)
 
 _HINTS = weakref.WeakKeyDictionary()      # tape object -> {job key: (cap_items, cap_tris, total_tris)}
-_HINTS_BY_ID = {}                         # the same for objects that cannot be weakly referenced
 _STREAMS = {}                             # device index -> {lane: the torch stream exchange steps of that lane run on}
 
 
@@ -70,10 +70,13 @@ def shard_bounds(n_work, r, world):
 
 
 def _hints_for(tape):
+    """capacity hints of the jobs run with this tape object; they live exactly as long as the object (a model that
+    cannot be weakly referenced gets none: ids are recycled, a table keyed by id() would hand a new model the
+    capacities of a dead one)"""
     try:
         return _HINTS.setdefault(tape, {})
     except TypeError:
-        return _HINTS_BY_ID.setdefault(id(tape), {})
+        return {}
 
 
 class HostCodec:
@@ -153,24 +156,112 @@ def _job(eng, tape, X, Y, Z, batch_size, sparse, device, group, chunks):
     if device is None:
         backend = td.get_backend(group)
         device = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-    externs = getattr(getattr(tape, 'tape', None), 'externs', None)
-    codec = DeviceCodec(eng) if (device.type == 'cuda' and hasattr(eng, 'generate_compact') and not externs) else HostCodec(eng)
+    # (an SDF / Tape with closures handed over directly has to be lowered before its externs can be seen)
+    lowered = eng.tape_for(tape) if hasattr(eng, 'tape_for') else tape
+    externs = getattr(getattr(lowered, 'tape', None), 'externs', None)
     if chunks is None:
         chunks = int(os.environ.get('SDF_DIST_CHUNKS', '1'))
-    C = max(1, min(int(chunks), 64 // max(world, 1)))
+    C = max(1, min(int(chunks), MAX_SLABS // max(world, 1)))
+    # sdf_expand_slabs takes at most MAX_SLABS slabs per call: a larger world ships the float64 soup through host memory
+    on_device = device.type == 'cuda' and hasattr(eng, 'generate_compact') and not externs and world * C <= MAX_SLABS
+    codec = DeviceCodec(eng) if on_device else HostCodec(eng)
     s = int(batch_size)
     nb = (-(-len(X) // s)) * (-(-len(Y) // s)) * (-(-len(Z) // s))
     key = (len(X), len(Y), len(Z), s, bool(sparse), world, C, type(codec).__name__)
     return device, world, C, nb, codec, key
 
 
+def _all_gather(td, g, mine, group, world, sb, async_op):
+    """ONE collective: the equal-sized slabs of all ranks into g, in rank order.  (RCCL and gloo on host tensors take
+    the single-buffer form; a backend that refuses it for these tensors -- gloo with device tensors in some builds --
+    gets the list form over views of the same buffer.)"""
+    try:
+        return td.all_gather_into_tensor(g, mine, group=group, async_op=async_op)
+    except (RuntimeError, NotImplementedError):
+        return td.all_gather([g[r * sb:(r + 1) * sb] for r in range(world)], mine, group=group, async_op=async_op)
+
+
+# ---- the native path: RCCL called from inside the library (csrc/sdf_comm.inc) ----
+_COMMS = {}      # (engine id, group id) -> engine.Comm
+
+
+class NativeStep:
+    """one exchange step in flight inside the library (engine.Exchange); same life cycle as ShardedStep"""
+    __slots__ = ('comm', 'xch', 'lane', 'device', 'result')
+
+
+def _native_comm(eng, td, group):
+    """the library's communicator for this process group (created once, collectively: rank 0 draws the RCCL ids,
+    the group that launched the ranks carries them to the others)"""
+    key = (id(eng), id(group) if group is not None else 0)
+    comm = _COMMS.get(key)
+    if comm is None:
+        from . import engine as _engine
+        r, world = td.get_rank(group), td.get_world_size(group)
+        ids = [_engine.Comm.unique_ids(eng.lib, 2) if r == 0 else None]
+        src = td.get_global_rank(group, 0) if group is not None else 0
+        td.broadcast_object_list(ids, src=src, group=group)
+        comm = _COMMS[key] = _engine.Comm(eng, ids[0], r, world)
+        comm._lane_owner = {}
+    return comm
+
+
+def shutdown_native():
+    """destroy the library's communicators of this process (collective, like their creation)"""
+    for comm in list(_COMMS.values()):
+        comm.close()
+    _COMMS.clear()
+
+
+def _native_ok(eng, td, tape, device, group):
+    if os.environ.get('SDF_DIST_NATIVE', '1') == '0' or device.type != 'cuda' or not hasattr(eng, 'lib'):
+        return False
+    if td.get_backend(group) != 'nccl' or td.get_world_size(group) > MAX_SLABS:
+        return False
+    lowered = eng.tape_for(tape)
+    return not getattr(lowered.tape, 'externs', None)
+
+
+def _native_finish(step):
+    import torch
+    if step.result is None:
+        soup, st = step.xch.wait()
+        t = torch.as_tensor(soup, device=step.device) if soup.n_triangles else torch.empty(0, dtype=torch.float64, device=step.device)
+        step.result = (t, st, soup)
+        if step.comm._lane_owner.get(step.lane) is step:
+            del step.comm._lane_owner[step.lane]
+    return step.result
+
+
 def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=None, chunks=None, lane=0, _caps=None, _attempt=0):
     """enqueue one exchange step -- mesh this rank's shard(s) into slabs, all-gather, expand -- and return without
     waiting for any of it; `collect_sharded` finishes the step.  Steps submitted on different `lane`s (0 / 1) run on
-    streams of their own, so step i + 1's meshing overlaps step i's collective."""
+    streams of their own, so step i + 1's meshing overlaps step i's collective.
+
+    On GPUs under the "nccl" backend the step runs INSIDE the library (csrc/sdf_comm.inc: ncclAllGather called from
+    there, persistent buffers, no interpreter between submit and collect; SDF_DIST_NATIVE=0 keeps the torch.distributed
+    path below, which is also what every other backend / engine uses).  The soup of a native step lives in library
+    memory and stays valid until the next step is submitted on the same lane."""
     import contextlib
     import torch
     td = _dist()
+    if td is None:
+        raise RuntimeError('torch.distributed is not initialised')
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if td.get_backend(group) == 'nccl' else torch.device('cpu')
+    if _native_ok(eng, td, tape, device, group):
+        comm = _native_comm(eng, td, group)
+        if chunks is None:
+            chunks = int(os.environ.get('SDF_DIST_CHUNKS', '1'))
+        held = comm._lane_owner.get(lane)
+        if held is not None:                 # the lane's buffers are about to be reused: finish that step, keep its soup
+            t, st, _ = _native_finish(held)
+            held.result = (t.clone(), st, None)
+        step = NativeStep()
+        step.comm, step.lane, step.device, step.result = comm, lane, device, None
+        step.xch = comm.submit(tape, X, Y, Z, batch_size, sparse, chunks=chunks, lane=lane)
+        comm._lane_owner[lane] = step
+        return step
     device, world, C, nb, codec, key = _job(eng, tape, X, Y, Z, batch_size, sparse, device, group, chunks)
     r = td.get_rank(group)
     on_gpu = device.type == 'cuda'
@@ -181,9 +272,17 @@ def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=No
         cap_items, cap_tris, total_hint = hints[key]
     else:                       # first call: a shard is a contiguous piece of the work list, at most 1/(world*C) of ALL batches
         cap_items = -(-nb // (world * C)) + 1
-        # (triangles: a guess, 4096 per batch -- 2.4 x what the BASELINE models produce -- within 8 GB of gathered
-        # slabs; a slab that is too small is flagged in its header and the step repeated)
-        cap_tris = max(min(4096 * cap_items, (8 << 30) // (72 * world * C)), 1 << 16)
+        # (triangles: a guess, 4096 per batch of the shard -- 2.4 x what the surviving batches of the BASELINE models
+        # produce, and most batches do not survive -- within 8 GB resp. a quarter of the free device memory for gathered
+        # slabs (36 B) plus the expanded soup (72 B) together; a slab that is too small is flagged in its header, the
+        # headers carry the exact need, and the step is repeated once with that)
+        budget = (8 << 30)
+        if on_gpu:
+            try:
+                budget = min(budget, torch.cuda.mem_get_info(device)[0] // 4)
+            except Exception:
+                pass
+        cap_tris = max(min(4096 * cap_items, budget // (108 * world * C)), 1 << 16)
         total_hint = 0
 
     st = ShardedStep()
@@ -220,7 +319,7 @@ def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=No
                 if ev and j == C - 1:
                     ev[1].record()
                 # one collective per shard; with several shards the gather of shard j overlaps the meshing of shard j + 1
-                works.append(td.all_gather_into_tensor(g, mine, group=group, async_op=C > 1))
+                works.append(_all_gather(td, g, mine, group, world, sb, C > 1))
                 gathered.append((g, mine))
             for w in works:
                 if w is not None and C > 1:
@@ -246,6 +345,9 @@ def collect_sharded(st):
     (soup: flat float64 torch tensor of 9*T values in reference order, merged stats dict)"""
     import contextlib
     import torch
+    if isinstance(st, NativeStep):
+        soup, merged, _ = _native_finish(st)
+        return soup, merged
     on_gpu = st.device.type == 'cuda'
     cap_items, cap_tris, _ = st.caps
     with (torch.cuda.stream(st.stream) if on_gpu else contextlib.nullcontext()):

@@ -29,6 +29,15 @@ _u32p = ctypes.POINTER(ctypes.c_uint32)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
+class SdfExchangeStats(ctypes.Structure):
+    """mirror of `sdf_exchange_stats` in include/sdf_hip.h"""
+    _fields_ = [(k, ctypes.c_int64) for k in ('n_batches', 'n_skipped', 'n_empty', 'n_nonempty', 'n_triangles', 'n_grid_voxels',
+                                               'n_eval_voxels', 'n_ambiguous_cells', 'n_sampled_voxels', 'n_pruned_instrs',
+                                               'n_retries', 'chunks', 'world', 'slab_bytes')] + \
+               [(k, ctypes.c_double) for k in ('ms_mesh', 'ms_exchange', 'ms_expand', 'ms_total')] + \
+               [('per_rank_triangles', ctypes.c_int64 * 64)]
+
+
 class SdfStats(ctypes.Structure):
     """mirror of `sdf_stats` in include/sdf_hip.h"""
     _fields_ = [
@@ -38,7 +47,7 @@ class SdfStats(ctypes.Structure):
         ('n_retries', _c_i64),
         ('ms_prepass', ctypes.c_double), ('ms_mesh', ctypes.c_double), ('ms_emit', ctypes.c_double),
         ('ms_total', ctypes.c_double), ('n_pruned_instrs', _c_i64), ('n_batch_instrs', _c_i64),
-        ('n_sampled_voxels', _c_i64),
+        ('n_sampled_voxels', _c_i64), ('ms_mesh_device', ctypes.c_double), ('sclk_mhz', ctypes.c_double),
     ]
 
 
@@ -89,6 +98,20 @@ ABI = {
                                                   ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _vp, _c_i64,
                                                   _c_i64, ctypes.POINTER(_vp)]),
     'sdf_expand_slabs': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int, _c_i64, _c_i64, _vp, _c_i64]),
+    'sdf_comm_unique_id': (ctypes.c_int, [_vp]),
+    'sdf_comm_create': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    'sdf_comm_destroy': (ctypes.c_int, [_vp]),
+    'sdf_generate_sharded_async': (ctypes.c_int, [_vp, _vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.POINTER(_vp)]),
+    'sdf_exchange_wait': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_c_i64)]),
+    'sdf_exchange_stats_get': (ctypes.c_int, [_vp, ctypes.POINTER(SdfExchangeStats)]),
+    'sdf_exchange_destroy': (ctypes.c_int, [_vp]),
+    'sdf_skip_kinds': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int, ctypes.c_int, _c_i64,
+                                      _c_i64, ctypes.c_int, _vp]),
+    'sdf_generate_from_kinds': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int, ctypes.c_int,
+                                               _c_i64, _c_i64, ctypes.c_int, _vp, ctypes.POINTER(_vp)]),
+    'sdf_memcpy_to_host': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     'sdf_mesh_stats': (ctypes.c_int, [_vp, ctypes.POINTER(SdfStats)]),
     'sdf_mesh_triangles': (_c_i64, [_vp]),
     'sdf_mesh_emit_device': (ctypes.c_int, [_vp, _vp]),
@@ -104,7 +127,7 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -305,6 +328,91 @@ class Mesh:
         self._fin()
 
 
+COMM_ID_BYTES = 128          # SDF_COMM_ID_BYTES
+
+
+class DeviceSoup:
+    """a float64 soup in LIBRARY memory on the device (9 doubles per triangle): the result of an exchange step.  It
+    exposes `__cuda_array_interface__` (zero-copy view for torch / cupy: `torch.as_tensor(soup, device=...)`) and can
+    copy itself to the host.  Valid until the next step is submitted on the same lane of its communicator."""
+
+    def __init__(self, eng, ptr, n_tris, keep=None):
+        self.engine, self.ptr, self.n_triangles, self._keep = eng, int(ptr or 0), int(n_tris), keep
+
+    @property
+    def __cuda_array_interface__(self):
+        return {'shape': (9 * self.n_triangles,), 'typestr': '<f8', 'data': (self.ptr, False), 'version': 2, 'strides': None}
+
+    def to_host(self, first_tri=0, n_tris=None):
+        """(3n, 3) float64 ndarray of triangles [first_tri, first_tri + n_tris)"""
+        n = self.n_triangles - first_tri if n_tris is None else int(n_tris)
+        out = pinned_empty(self.engine.lib, (3 * n, 3), np.float64)
+        if n:
+            _check(self.engine.lib, self.engine.lib.sdf_memcpy_to_host(self.engine.ctx, out.ctypes.data_as(_vp),
+                                                                       _vp(self.ptr + 72 * int(first_tri)), 72 * n))
+        return out
+
+
+class Exchange:
+    """one sharded step in flight (`sdf_exchange*`)"""
+
+    def __init__(self, comm, handle, tape):
+        self.comm, self.handle, self._tape = comm, handle, tape
+        self._fin = weakref.finalize(self, comm.engine.lib.sdf_exchange_destroy, handle)
+
+    def wait(self):
+        """the step's one host synchronisation -> (DeviceSoup, stats dict)"""
+        lib = self.comm.engine.lib
+        p, n = _vp(), _c_i64(0)
+        _check(lib, lib.sdf_exchange_wait(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        st = SdfExchangeStats()
+        _check(lib, lib.sdf_exchange_stats_get(self.handle, ctypes.byref(st)))
+        d = {k: getattr(st, k) for k, _ in SdfExchangeStats._fields_ if k != 'per_rank_triangles'}
+        d['per_rank_triangles'] = [int(v) for v in st.per_rank_triangles[:st.world]]
+        d.update(batches=st.n_batches, skipped=st.n_skipped, empty=st.n_empty, nonempty=st.n_nonempty, triangles=st.n_triangles,
+                 payload='f32 local + per-batch transform', exchange='rccl (native)')
+        return DeviceSoup(self.comm.engine, p.value, n.value, keep=self), d
+
+    def close(self):
+        self._fin()
+
+
+class Comm:
+    """the ranks of one multi-GPU job (`sdf_comm*`): RCCL communicators + persistent exchange buffers, 1 or 2 lanes.
+    Creation is collective: every rank calls it with the ids rank 0 drew (`Comm.unique_ids`)."""
+
+    @staticmethod
+    def unique_ids(lib, n_lanes=2):
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES * n_lanes)
+        for l in range(n_lanes):
+            _check(lib, lib.sdf_comm_unique_id(ctypes.cast(ctypes.byref(buf, COMM_ID_BYTES * l), _vp)))
+        return buf.raw
+
+    def __init__(self, eng, ids, rank, world):
+        self.engine, self.rank, self.world = eng, int(rank), int(world)
+        self.n_lanes = len(ids) // COMM_ID_BYTES
+        self.handle = _vp()
+        raw = ctypes.create_string_buffer(bytes(ids), len(ids))
+        _check(eng.lib, eng.lib.sdf_comm_create(eng.ctx, ctypes.cast(raw, _vp), self.n_lanes, self.rank, self.world,
+                                                ctypes.byref(self.handle)))
+        self._fin = weakref.finalize(self, eng.lib.sdf_comm_destroy, self.handle)
+
+    def submit(self, sdf, X, Y, Z, batch_size=32, sparse=True, chunks=1, lane=0):
+        eng = self.engine
+        dt = eng.tape_for(sdf)
+        if dt.tape.externs:
+            raise ValueError('a model with user closures is sharded through the host protocol (sdf_amd.dist with HostCodec)')
+        X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
+        h = _vp()
+        _check(eng.lib, eng.lib.sdf_generate_sharded_async(self.handle, dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y),
+                                                           _dp(Z, _f64p), len(Z), int(batch_size), 1 if sparse else 0,
+                                                           eng.precision, int(chunks), int(lane), ctypes.byref(h)))
+        return Exchange(self, h, dt)
+
+    def close(self):
+        self._fin()
+
+
 class Engine:
     """one HIP context (`sdf_ctx*`) on one device"""
 
@@ -405,6 +513,8 @@ class Engine:
             msg = (lib.sdf_last_error() or b'').decode()
             if msg.startswith('zero-size array'):
                 raise ValueError(msg)                       # what np.argwhere(...).max(axis=0) raises in the reference
+            if 'barrier' in msg:
+                return None                                 # (the caller runs the reference's loop around eval_grid)
             raise SdfHipError(msg)
         return (tuple(out[:3]), tuple(out[3:]))
 
@@ -479,6 +589,26 @@ class Engine:
         m.emitted = bool(emitted.value)
         return m
 
+
+    def skip_kinds(self, sdf, X, Y, Z, batch_size, b_begin, b_end, kinds_ptr):
+        """`_skip` for batches [b_begin, b_end): 0 / 255 into the caller's device buffer (one byte per batch of the grid)"""
+        dt = self.tape_for(sdf)
+        X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
+        _check(self.lib, self.lib.sdf_skip_kinds(dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y), _dp(Z, _f64p), len(Z),
+                                                 int(batch_size), int(b_begin), int(b_end), self.precision, _vp(kinds_ptr)))
+
+    def generate_from_kinds(self, sdf, X, Y, Z, batch_size, kinds_ptr, shard=(0, 1)):
+        """`generate` (sparse) with the skip test's verdicts already on the device (skip_kinds)"""
+        dt = self.tape_for(sdf)
+        X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, Y, Z))
+        h = _vp()
+        _check(self.lib, self.lib.sdf_generate_from_kinds(dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y), _dp(Z, _f64p), len(Z),
+                                                          int(batch_size), int(shard[0]), int(shard[1]), self.precision,
+                                                          _vp(kinds_ptr), ctypes.byref(h)))
+        m = Mesh(self, h)
+        m._tape = dt
+        m.emitted = False
+        return m
 
     # -- the multi-GPU exchange unit (sdf_amd/dist.py) --
     SLAB_HEADER = ('n_tris', 'n_items', 'overflow', 'n_empty', 'n_nonempty', 'n_eval_voxels', 'n_ambiguous_cells',

@@ -337,13 +337,21 @@ def test_generate_to_device_matches_host_path(ns, eng):
     m.close()
 
 
-def test_sharded_generate_over_rccl_single_rank(ns, eng):
-    """the multi-GPU code path (sdf_amd/dist.py: device-resident soup, RCCL all-gather) with a
-    one-rank `nccl` process group: must reproduce the plain path bit for bit"""
+@pytest.mark.parametrize('driver', ['native', 'native-sharded-skip', 'torch'])
+def test_sharded_generate_over_rccl_single_rank(driver, ns, eng, monkeypatch):
+    """the multi-GPU code path with a one-rank `nccl` process group must reproduce the plain path bit for bit:
+    `native` = the exchange step inside the library (csrc/sdf_comm.inc: ncclAllGather through the dlopen'ed librccl,
+    persistent buffers, the default under nccl); `native-sharded-skip` = the same with the skip test shared out and its
+    verdicts all-gathered (SDF_SKIP_SHARD_MIN: every grid takes that path); `torch` = sdf_amd/dist.py's protocol through
+    torch.distributed (SDF_DIST_NATIVE=0: what other backends and engines use)"""
     import socket
     import torch
     import torch.distributed as td
     from sdf_amd import dist
+    monkeypatch.setenv('SDF_DIST_NATIVE', '0' if driver == 'torch' else '1')
+    if driver == 'native-sharded-skip':
+        monkeypatch.setenv('SDF_SKIP_SHARD_MIN', '0')
+    dist.shutdown_native()
     f = fixtures.build('ex_example', ns)
     d = np.load(os.path.join(GOLDEN, 'gen_example_s17.npz'))
     X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
@@ -365,6 +373,7 @@ def test_sharded_generate_over_rccl_single_rank(ns, eng):
             torch.cuda.synchronize()
             got = soup.cpu().numpy().reshape(-1, 3)
             assert st['triangles'] == len(want) // 3 and st['chunks'] == chunks and st['payload'].startswith('f32')
+            assert ('native' in st.get('exchange', '')) == (driver != 'torch')
             assert np.array_equal(got, want)
             assert st['ms_mesh'] > 0 and st['ms_exchange'] >= 0 and st['ms_expand'] > 0
             assert (st['batches'], st['skipped'] + st['empty'] + st['nonempty']) == (len(ref_kinds), len(ref_kinds))
@@ -383,7 +392,63 @@ def test_sharded_generate_over_rccl_single_rank(ns, eng):
         pts = f.generate(bounds=tuple(map(tuple, d['bounds'])), step=d['step'].tolist(), verbose=False)
         assert np.array_equal(pts, want)          # core.generate takes the sharded route when dist is up
     finally:
+        dist.shutdown_native()
         td.destroy_process_group()
+
+
+def test_skip_test_in_pieces_and_generate_from_its_verdicts(ns, eng):
+    """what the ranks of a sharded step do between them (csrc/sdf_comm.inc): each runs `_skip` for a share of the
+    batches (sdf_skip_kinds), the one-byte verdicts are gathered, and every rank meshes its share of the work list
+    from them (sdf_generate_from_kinds).  Here one device plays the three ranks: the assembled verdicts must equal the
+    plain call's classification and the soups must be the plain call's, whole and in shards"""
+    import torch
+    for name, samples in (('ex_example', 2 ** 22), ('ex_gearlike', 2 ** 21), ('ex_blobby', 2 ** 24)):
+        f = fixtures.build(name, ns)
+        X, Y, Z, _ = core.grid_axes(tuple(map(tuple, BOUNDS[name])), samples=samples)
+        m = eng.generate(f, X, Y, Z)
+        want, kinds = m.points(), m.kinds()
+        m.close()
+        nb = len(kinds)
+        world = 3
+        piece = -(-nb // world)
+        buf = torch.full((piece * world,), 77, dtype=torch.uint8, device='cuda:0')
+        torch.cuda.synchronize()
+        for r in (2, 0, 1):
+            eng.skip_kinds(f, X, Y, Z, 32, min(nb, piece * r), min(nb, piece * (r + 1)), buf.data_ptr())
+        got = buf.cpu().numpy()
+        assert (got[nb:] == 77).all()                                      # nothing outside the grid's batches
+        assert np.array_equal(got[:nb] != 0, kinds != 0) and set(np.unique(got[:nb])) <= {0, 255}
+        m = eng.generate_from_kinds(f, X, Y, Z, 32, buf.data_ptr())
+        assert np.array_equal(m.points(), want) and np.array_equal(m.kinds(), kinds)
+        m.close()
+        assert np.array_equal(buf.cpu().numpy(), got)                      # the caller's verdicts are read, never written
+        parts = []
+        for i in range(world):
+            m = eng.generate_from_kinds(f, X, Y, Z, 32, buf.data_ptr(), shard=(i, world))
+            parts.append(m.points())
+            m.close()
+        assert np.array_equal(np.concatenate(parts), want)
+
+
+def test_bench_two_ranks_on_one_device_exchange_slabs_between_processes(tmp_path):
+    """`python bench.py --gpus 2` the way the driver starts it (no launcher around it: bench.py starts its ranks
+    itself), both ranks on THIS device, gloo as the transport (RCCL refuses two ranks on one GPU), the slabs kept in
+    device memory: two real processes run sdf_amd.dist's device side -- sdf_generate_compact_async into a slab, the
+    all-gather, sdf_expand_slabs on the step's own stream -- and rank 0's line must carry the reference's soup hash"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SDF_BENCH_ONE_DEVICE='1', SDF_BENCH_BACKEND='gloo', SDF_BENCH_COMM_DEVICE='cuda')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-other-configs'], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['parity_check'] is True
+    assert rec['config']['triangles'] == 2945152 and rec['exchange']['payload'].startswith('f32')
+    assert len(rec['device_ms']['per_rank_mesh']) == 2 and rec['value'] > 0
 
 
 EDGE_GRIDS = [
@@ -1003,7 +1068,7 @@ def test_interval_passes_identity_and_oracle_for_every_fixture(name, ns, oracle_
 # ---- the multi-GPU exchange unit on ONE device: N "ranks" mesh their shards into slabs of one buffer (what the
 # all-gather would assemble), k_expand turns them into the soup ----
 
-@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 22), ('ex_gearlike', 2 ** 21), ('ex_blobby', 2 ** 24)])
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 22), ('ex_gearlike', 2 ** 21), ('ex_blobby', 2 ** 24), ('ex_weave', 2 ** 22)])
 def test_slab_exchange_emulated_ranks(name, samples, ns, eng):
     import torch
     f = fixtures.build(name, ns)

@@ -134,8 +134,9 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.sdf_abi_version() == engine.ABI_VERSION
-    # struct layout of sdf_stats: 11 int64 + 4 double + 3 int64
-    assert ctypes.sizeof(engine.SdfStats) == 18 * 8
+    # struct layout of sdf_stats: 11 int64 + 4 double + 3 int64 + 2 double; sdf_exchange_stats: 14 int64 + 4 double + 64 int64
+    assert ctypes.sizeof(engine.SdfStats) == 20 * 8
+    assert ctypes.sizeof(engine.SdfExchangeStats) == (14 + 4 + 64) * 8
 
 
 def test_no_cpu_fallback_without_device(ns):
@@ -219,3 +220,37 @@ def test_long_tapes_carry_no_prune_info_and_big_pools_fail_cleanly(ns):
     lw.emit('L_SPHERE', consts=(1.0, 0.0, 0.0, 0.0))            # still addressable
     with pytest.raises(ValueError):
         lw.emit('L_SPHERE', consts=(1.0, 0.0, 0.0, 0.0))
+
+
+def test_bound_method_closures_keep_their_own_instance():
+    """two bound methods of one function on different instances are two closures (a bound method's __dict__ is the
+    function's: a node cached there evaluated the first instance's closure for both)"""
+    from sdf_amd import ir
+
+    class Ball:
+        def __init__(self, r):
+            self.r = r
+
+        def f(self, p):
+            return np.linalg.norm(p, axis=1) - self.r
+
+    a, b = Ball(1.0), Ball(2.0)
+    na, nb = ir.extern_node(a.f), ir.extern_node(b.f)
+    assert na is not nb and na.meta['fn'].__self__ is a and nb.meta['fn'].__self__ is b
+    assert ir.extern_node(a.f) is na and ir.extern_node(b.f) is nb      # one node per (instance, function)
+    P = np.array([[3.0, 0.0, 0.0]])
+    assert na.meta['fn'](P)[0] == 2.0 and nb.meta['fn'](P)[0] == 1.0
+
+    class Slotted:
+        __slots__ = ('r',)
+
+        def f(self, p):
+            return np.linalg.norm(p, axis=1) - self.r
+
+    s1, s2 = Slotted(), Slotted()
+    s1.r, s2.r = 1.0, 2.0
+    assert ir.extern_node(s1.f).meta['fn'].__self__ is s1 and ir.extern_node(s2.f).meta['fn'].__self__ is s2
+
+    def plain(p):
+        return p[:, 0]
+    assert ir.extern_node(plain) is ir.extern_node(plain)
