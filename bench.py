@@ -111,20 +111,14 @@ def self_launch(args):
 
 
 def read_clocks():
-    """current shader / memory clocks from rocm-smi (best effort; None where the tool is missing).  The clock the
-    kernels actually ran at is measured by the kernels themselves (`sclk_mhz_in_kernel`)."""
+    """current shader / memory / fabric clocks in MHz from `rocm-smi --showclocks` (best effort; None where the tool is
+    missing).  The clock the kernels actually ran at is measured by the kernels themselves (`sclk_mhz_in_kernel`)."""
+    import re
     try:
-        out = subprocess.run(['rocm-smi', '--showclocks', '--json'], capture_output=True, text=True, timeout=20).stdout
-        card = next(iter(json.loads(out).values()))
+        out = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=20).stdout
         pick = {}
-        for k, v in card.items():
-            kl = k.lower()
-            if 'sclk' in kl and 'level' in kl:
-                pick['sclk'] = v
-            elif 'mclk' in kl and 'level' in kl:
-                pick['mclk'] = v
-            elif 'fclk' in kl and 'level' in kl:
-                pick['fclk'] = v
+        for name, mhz in re.findall(r'GPU\[0\]\s*:\s*(\w+) clock level:[^(]*\((\d+)Mhz\)', out):
+            pick[name + '_mhz'] = int(mhz)
         return pick or None
     except Exception:
         return None

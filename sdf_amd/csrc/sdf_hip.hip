@@ -780,6 +780,14 @@ static hipError_t spin_then_block(Query query, Block block) {
     }
     return block();
 }
+// Entering the library: select the context's device and DROP whatever error another library left in this thread's
+// "last error" slot (hipGetLastError is sticky per thread: a failed probe inside RCCL or torch -- seen after
+// destroy_process_group: "invalid device ordinal" -- would otherwise be reported by our next launch check)
+static hipError_t set_device(int device) {
+    const hipError_t e = hipSetDevice(device);
+    (void)hipGetLastError();
+    return e;
+}
 static hipError_t stream_wait(hipStream_t s) {
     return spin_then_block([&] { return hipStreamQuery(s); }, [&] { return hipStreamSynchronize(s); });
 }
@@ -1005,7 +1013,7 @@ int sdf_ctx_create(int device, sdf_ctx **out) {
     int n = 0;
     HIPCHK(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail("sdf_ctx_create: no such device");
-    HIPCHK(hipSetDevice(device));
+    HIPCHK(set_device(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
@@ -1107,7 +1115,7 @@ int sdf_ctx_set_twopass(sdf_ctx *c, int mode) {
 
 int sdf_ctx_synchronize(sdf_ctx *c) {
     if (!c) return fail("sdf_ctx_synchronize: ctx is NULL");
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     HIPCHK(stream_wait(c->stream));
     for (auto &cs : c->slots) if (cs.stream) HIPCHK(stream_wait(cs.stream));
     return 0;
@@ -1117,7 +1125,7 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
                     uint32_t n_p, uint32_t n_d, sdf_tape **out) {
     if (!c || !code || !consts || !out) return fail("sdf_tape_create: NULL argument");
     if (validate_tape(code, n_words, n_consts, n_p, n_d)) return 1;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     sdf_tape *t = new sdf_tape();
     struct Guard { sdf_tape *t; ~Guard() { if (t) { const std::string keep = g_err; sdf_tape_destroy(t); g_err = keep; } } } guard{t};
     t->ctx = c; t->n_words = n_words; t->n_consts = n_consts;
@@ -1161,7 +1169,7 @@ int sdf_tape_set_prune_info(sdf_tape *t, const uint16_t *rstart, const uint16_t 
         const bool none = rstart[i] == 0xFFFF || lstart[i] == 0xFFFF;
         if (!none && !(lstart[i] <= rstart[i] && rstart[i] <= i)) return fail("sdf_tape_set_prune_info: operand range out of order");
     }
-    HIPCHK(hipSetDevice(t->ctx->device));
+    HIPCHK(set_device(t->ctx->device));
     if (!t->d_rstart) HIPCHK(hipMalloc((void **)&t->d_rstart, n_instr * 2));
     if (!t->d_lstart) HIPCHK(hipMalloc((void **)&t->d_lstart, n_instr * 2));
     HIPCHK(hipMemcpy(t->d_rstart, rstart, n_instr * 2, hipMemcpyHostToDevice));
@@ -1215,7 +1223,7 @@ int sdf_eval_points(sdf_tape *t, const void *d_pts, int64_t n, int dim, void *d_
     if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_points: bad precision");
     if (t->n_extern) return fail("sdf_eval_points: the tape reads user closures (L_EXTERN): use sdf_eval_extern_points_host / sdf_eval_points_extern_host");
     if (n <= 0) return 0;
-    HIPCHK(hipSetDevice(t->ctx->device));
+    HIPCHK(set_device(t->ctx->device));
     const unsigned grid = (unsigned)((n + 255) / 256);
     LAUNCH_TAPE(k_eval_points, dim3(grid), dim3(256), 0, t, precision, (const double *)d_pts, (long long)n, dim, (double *)d_out);
     HIPCHK(hipGetLastError());
@@ -1228,7 +1236,7 @@ int sdf_eval_points_host(sdf_tape *t, const double *h_pts, int64_t n, int dim, d
     if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_eval_points_host: bad precision");
     if (n <= 0) return 0;
     sdf_ctx *c = t->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     if (c->scratch_in.ensure((size_t)n * dim * 8) || c->scratch_out.ensure((size_t)n * 8)) return 1;
     HIPCHK(hipMemcpyAsync(c->scratch_in.p, h_pts, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream));
     if (sdf_eval_points(t, c->scratch_in.p, n, dim, c->scratch_out.p, precision)) return 1;
@@ -1244,7 +1252,7 @@ int sdf_eval_grid_host(sdf_tape *t, const double *X, int nx, const double *Y, in
     if (t->n_extern) return fail("sdf_eval_grid_host: the tape reads user closures (L_EXTERN): evaluate it with the *_extern_* entry points");
     if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
     sdf_ctx *c = t->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     const size_t n = (size_t)nx * ny * nz;
     if (c->scratch_in.ensure((size_t)(nx + ny + nz) * 8) || c->scratch_out.ensure(n * 8)) return 1;
     double *dX = (double *)c->scratch_in.p, *dY = dX + nx, *dZ = dY + ny;
@@ -1265,7 +1273,7 @@ int sdf_estimate_bounds(sdf_tape *t, double *h_out6, int precision) {
     if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_estimate_bounds: bad precision");
     if (t->n_extern) return fail("sdf_estimate_bounds: the tape reads user closures (L_EXTERN): probe it through the *_extern_* entry points");
     sdf_ctx *c = t->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     if (c->scratch_out.ensure(2048)) return 1;
     int *work = reinterpret_cast<int *>((char *)c->scratch_out.p + 64);
     HIPCHK(hipMemsetAsync(work, 0, (1 + 6 * 32) * sizeof(int), c->stream));
@@ -1290,7 +1298,7 @@ int sdf_eval_extern_points_host(sdf_tape *t, const double *h_pts, int64_t n, int
     if (!t->n_extern) return fail("sdf_eval_extern_points_host: the tape has no user closures");
     if (n <= 0) return 0;
     sdf_ctx *c = t->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     const size_t ext_bytes = (size_t)t->n_extern * (size_t)n * 24;
     if (c->scratch_in.ensure((size_t)n * dim * 8) || c->ext.ensure(ext_bytes)) return 1;
     HIPCHK(hipMemcpyAsync(c->scratch_in.p, h_pts, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream));
@@ -1312,7 +1320,7 @@ int sdf_eval_points_extern_host(sdf_tape *t, const double *h_pts, int64_t n, int
     if (!t->n_extern) return fail("sdf_eval_points_extern_host: the tape has no user closures");
     if (n <= 0) return 0;
     sdf_ctx *c = t->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     const size_t ext_bytes = (size_t)t->n_extern * (size_t)n * 8;
     if (c->scratch_in.ensure((size_t)n * dim * 8) || c->scratch_out.ensure((size_t)n * 8) || c->ext.ensure(ext_bytes)) return 1;
     HIPCHK(hipMemcpyAsync(c->scratch_in.p, h_pts, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream));
@@ -1331,7 +1339,7 @@ int sdf_marching_cubes(sdf_ctx *c, const void *d_volume, int n0, int n1, int n2,
     *n_tris = 0;
     if (n0 < 2 || n1 < 2 || n2 < 2) return 0;   // skimage: "Input array must be at least 2x2x2" -> empty batch
     if (!d_volume) return fail("sdf_marching_cubes: volume is NULL");
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     const long long nrows = (long long)(n0 - 1) * (n1 - 1);
     if (c->rows.ensure((size_t)nrows * 4) || c->rows_off.ensure((size_t)(nrows + 1) * 8)) return 1;
     unsigned long long *d_total = (unsigned long long *)c->rows_off.p + nrows;
@@ -1358,7 +1366,7 @@ int sdf_marching_cubes_host(sdf_ctx *c, const float *h_vol, int n0, int n1, int 
     *n_tris = 0;
     if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
     if (!h_vol) return fail("sdf_marching_cubes_host: volume is NULL");
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     const size_t n = (size_t)n0 * n1 * n2;
     if (c->scratch_in.ensure(n * 4)) return 1;
     if (cap > 0 && c->scratch_out.ensure((size_t)cap * 36)) return 1;
@@ -1789,7 +1797,7 @@ static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y,
     if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_generate: bad precision");
     if (nx < 0 || ny < 0 || nz < 0) return fail("sdf_generate: negative axis length");
     sdf_ctx *c = t->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     sdf_mesh *m = new sdf_mesh();
     m->ctx = c;
     if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out, async_mode, slab_items, nullptr, d_kinds_in)) {
@@ -1843,7 +1851,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
     if (bs < 1 || bs > 32) return fail("sdf_generate_field: batch_size must be in 1..32");
     if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sdf_generate_field: bad shard");
     if (nx < 0 || ny < 0 || nz < 0) return fail("sdf_generate_field: negative axis length");
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     sdf_mesh *m = new sdf_mesh();
     m->ctx = c;
     void *h_pts = nullptr, *h_vals = nullptr;
@@ -2001,7 +2009,7 @@ int sdf_expand_slabs(sdf_ctx *c, const void *const *d_slabs, int n_slabs, int64_
     if (n_slabs < 1 || n_slabs > 64) return fail("sdf_expand_slabs: 1..64 slabs");
     if (cap_items < 0 || cap_tris < 0 || cap_out < 0) return fail("sdf_expand_slabs: negative capacity");
     if (cap_items == 0 || cap_out == 0) return 0;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     SlabPtrs ptrs = {};
     for (int i = 0; i < n_slabs; i++) { if (!d_slabs[i]) return fail("sdf_expand_slabs: NULL slab"); ptrs.p[i] = (const unsigned char *)d_slabs[i]; }
     const unsigned gx = (unsigned)std::min<int64_t>(cap_items, 8192);
@@ -2016,7 +2024,7 @@ int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
     sdf_mesh::Pending &pd = m->pend;
     if (pd.active) {
         sdf_ctx *c = m->ctx;
-        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(set_device(c->device));
         CallSlot &cs = c->slots[pd.slot];
         HIPCHK(event_wait(cs.done));
         pd.active = false;
@@ -2076,7 +2084,7 @@ int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
     MESH_READY(m);
     sdf_ctx *c = m->ctx;
     if (m->st.n_triangles == 0 || d_out == mesh_soup(m)) return 0;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     HIPCHK(hipMemcpyAsync(d_out, mesh_soup(m), (size_t)m->st.n_triangles * 72, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[4], c->stream));
@@ -2101,7 +2109,7 @@ int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_emit_host: NULL argument");
     MESH_READY(m);
     if (m->st.n_triangles == 0) return 0;
-    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(set_device(m->ctx->device));
     return copy_to_host(m->ctx, h_out, mesh_soup(m), (size_t)m->st.n_triangles * 72);
 }
 
@@ -2110,7 +2118,7 @@ int sdf_mesh_emit_host_range(sdf_mesh *m, int64_t first_tri, int64_t n_tris, dou
     MESH_READY(m);
     if (first_tri < 0 || n_tris < 0 || first_tri + n_tris > m->st.n_triangles) return fail("sdf_mesh_emit_host_range: range outside the soup");
     if (n_tris == 0) return 0;
-    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(set_device(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, (const char *)mesh_soup(m) + (size_t)first_tri * 72, (size_t)n_tris * 72, hipMemcpyDeviceToHost, m->ctx->stream));
     HIPCHK(stream_wait(m->ctx->stream));
     return 0;
@@ -2126,7 +2134,7 @@ int sdf_mesh_batch_offsets(sdf_mesh *m, int64_t *h_out) {
     const int nw = m->work_end - m->work_begin;
     if (nb == 0 || nw <= 0) return 0;
     if (!m->status.p || !m->worklist.p) return fail("sdf_mesh_batch_offsets: this mesh was not produced by sdf_generate");
-    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(set_device(m->ctx->device));
     std::vector<int> wl((size_t)nw);
     std::vector<unsigned long long> stw((size_t)nw);
     HIPCHK(hipMemcpyAsync(wl.data(), (const int *)m->worklist.p + m->work_begin, (size_t)nw * 4, hipMemcpyDeviceToHost, m->ctx->stream));
@@ -2151,7 +2159,7 @@ int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
     const long long nt = m->st.n_triangles;
     if (nt == 0) return 0;
     sdf_ctx *c = m->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     if (c->scratch_out.ensure((size_t)nt * 50)) return 1;
     hipLaunchKernelGGL(k_stl, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, (const double *)mesh_soup(m), nt,
                        (unsigned short *)c->scratch_out.p);
@@ -2163,7 +2171,7 @@ int sdf_mesh_weld(sdf_mesh *m, int64_t *n_unique) {
     if (!m || !n_unique) return fail("sdf_mesh_weld: NULL argument");
     MESH_READY(m);
     sdf_ctx *c = m->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     if (m->weld_n < 0) {
         long long nu = 0;
         const int rc = sdfk::weld_device(c->stream, (const double *)mesh_soup(m), 3ll * (long long)m->st.n_triangles, &m->weld_pts, &m->weld_inv, &nu);
@@ -2179,7 +2187,7 @@ int sdf_mesh_weld_fetch(sdf_mesh *m, double *h_points, int64_t *h_cells) {
     if (m->weld_n < 0) return fail("sdf_mesh_weld_fetch: call sdf_mesh_weld first");
     if (m->weld_n == 0) return 0;
     sdf_ctx *c = m->ctx;
-    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(set_device(c->device));
     HIPCHK(hipMemcpyAsync(h_points, m->weld_pts, (size_t)m->weld_n * 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(h_cells, m->weld_inv, (size_t)m->st.n_triangles * 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(stream_wait(c->stream));
@@ -2258,7 +2266,7 @@ int sdf_mesh_kinds(sdf_mesh *m, uint8_t *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_kinds: NULL argument");
     MESH_READY(m);
     if (m->st.n_batches == 0) return 0;
-    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(set_device(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, m->kinds.p, (size_t)m->st.n_batches, hipMemcpyDeviceToHost, m->ctx->stream));
     HIPCHK(stream_wait(m->ctx->stream));
     for (int64_t i = 0; i < m->st.n_batches; i++) if (h_out[i] == 255) h_out[i] = 3;
@@ -2271,7 +2279,7 @@ int sdf_mesh_prune_masks(sdf_mesh *m, uint32_t *h_out) {
     if (!m->pruned) return fail("sdf_mesh_prune_masks: this mesh was generated without the interval prepass");
     const size_t n = (size_t)m->st.n_batches;
     if (n == 0) return 0;
-    HIPCHK(hipSetDevice(m->ctx->device));
+    HIPCHK(set_device(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, m->prune.p, n * 64, hipMemcpyDeviceToHost, m->ctx->stream));
     HIPCHK(stream_wait(m->ctx->stream));
     return 0;

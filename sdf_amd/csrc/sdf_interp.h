@@ -55,8 +55,52 @@ SDF_OUTLINE double o_fmod(double x, double y) { return fmod(x, y); }
 SDF_OUTLINE float o_fmod(float x, float y) { return fmodf(x, y); }
 SDF_OUTLINE double o_pow2(double x) { return pow(2.0, x); }
 SDF_OUTLINE float o_pow2(float x) { return powf(2.0f, x); }
-SDF_OUTLINE void o_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 SDF_OUTLINE void o_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
+struct SinCos64 { double s, c; };    // (returned in registers: out-parameters of an outlined function live in scratch memory)
+SDF_OUTLINE SinCos64 o_sincos64(double x) { SinCos64 r; sincos(x, &r.s, &r.c); return r; }
+
+// sin and cos of a float64 angle, INLINE and branch-free: what `circular_array` runs twice per child evaluation
+// (reference sdf/d3.py:379-392 -- weave at 2^33: 36 of them per sample before pruning), and twist / bend.  The ocml
+// sincos is ~200 instructions behind a call; around the call the compiler has to park the interpreter's machine state
+// (72 VGPRs for two samples with four saved points) in the half of the register file the calling convention preserves,
+// and the rest went to scratch -- the 4-slot kernels spilled 88 - 226 registers because of it.
+// Reduction: k = rint(x * 2/pi), r + lo = x - k * pi/2 with pi/2 in three 53-bit pieces: the first product is exact
+// in the fma and its difference exactly representable, the second step keeps its rounding and product errors
+// (TwoSum + fma), the third piece goes into the tail.  Kernels: the fdlibm / FreeBSD msun polynomials (__kernel_sin,
+// __kernel_cos with tail) on |r| <= pi/4.  Measured against an 80-bit reference over 2e7 arguments in [-4e5, 4e5] incl.
+// neighbourhoods of multiples of pi/2: max error 0.79 ulp (glibc: 0.56); 2.3 % of the results differ from glibc's in
+// the last bit -- the same class of difference as ocml vs glibc, which the parity tolerances for libm models cover
+// (DESIGN.md section 5).  |x| >= 1e6, NaN and infinities take the ocml path (a wave-uniform branch never taken by
+// angles that come out of atan2 / np_mod).
+SDF_DEV void sincos64(double x, double &sn, double &cs) {
+    const double P1 = 1.5707963267948966, P2 = 6.123233995736766e-17, P3 = -1.4973849048591698e-33;
+    const double q = rint(x * 0.6366197723675814);
+    const double r0 = fma(-q, P1, x);
+    const double p2 = q * P2, b = -p2;
+    const double r = r0 + b;
+    const double bb = r - r0;
+    double lo = (r0 - (r - bb)) + (b - bb);      // TwoSum: the rounding error of r0 - p2
+    lo = lo - fma(q, P2, -p2);                   // the product's own error, exact
+    lo = fma(-q, P3, lo);
+    const double z = r * r, v = z * r;
+    const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                 -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double s = r - ((z * (0.5 * lo - v * rs) - lo) - v * -1.66666666666666324348e-01);
+    const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                          2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + (z * rc - r * lo));
+    const int n = (int)q;
+    double ss = (n & 1) ? c : s, cc = (n & 1) ? s : c;
+    ss = (n & 2) ? -ss : ss;
+    cc = ((n + 1) & 2) ? -cc : cc;
+    const bool big = !(fabs(x) < 1e6);
+    if (__builtin_expect(__ballot(big) != 0ull, 0)) {        // (wave-uniform)
+        const SinCos64 o = o_sincos64(x);
+        ss = big ? o.s : ss; cc = big ? o.c : cc;
+    }
+    sn = ss; cs = cc;
+}
 SDF_DEV double m_sin(double x) { return o_sin(x); }
 SDF_DEV float m_sin(float x) { return o_sin(x); }
 SDF_DEV double m_cos(double x) { return o_cos(x); }
@@ -96,10 +140,12 @@ SDF_VEC_MAP1(m_rint, m_rint(x))
 SDF_VEC_MAP1(m_sin, m_sin(x))
 SDF_VEC_MAP1(m_cos, m_cos(x))
 SDF_VEC_MAP1(m_pow2, m_pow2(x))
-// sin and cos of the same angle share the argument reduction (ocml sincos returns the same values
-// as its sin and cos)
-template <typename T, int N> SDF_DEV void m_sincos(const Vec<T, N> &a, Vec<T, N> &s, Vec<T, N> &c) {
+// sin and cos of the same angle share the argument reduction (float64: sincos64 above; float32: ocml)
+template <int N> SDF_DEV void m_sincos(const Vec<float, N> &a, Vec<float, N> &s, Vec<float, N> &c) {
     SDF_UNROLL for (int i = 0; i < N; i++) o_sincos(a.v[i], &s.v[i], &c.v[i]);
+}
+template <int N> SDF_DEV void m_sincos(const Vec<double, N> &a, Vec<double, N> &s, Vec<double, N> &c) {
+    SDF_UNROLL for (int i = 0; i < N; i++) sincos64(a.v[i], s.v[i], c.v[i]);
 }
 SDF_VEC_MAP1(np_sign, s_sign(x))
 SDF_VEC_MAP2(m_atan2, m_atan2(x, y))
@@ -631,7 +677,16 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             x = np_max(qx, T(0)); y = np_max(qy, T(0)); z = np_max(qz, T(0)); goto next; }
         L_BEND_LINEAR: {  // d3.py:435-445
             V tt = np_clip(dot3(x - c[0], y - c[1], z - c[2], c[3], c[4], c[5]) / c[6], T(0), T(1));
-            tt = ease_apply<T, FULL, NS>((int)c[10], tt);
+            // (the curves the example models bend with -- ease.linear is bend_linear's default, weave.py passes
+            // ease.in_out_quad -- without going through ease_apply's 34-way switch: in the trig-capable kernels that is
+            // an out-of-line function, and a call here parks the whole machine state, see sincos64)
+            const int eid = (int)c[10];
+            if (eid == EASE_in_out_quad) {
+                const V u = T(2) * tt - T(1), a = T(2) * tt * tt, b = T(-0.5) * (u * (u - T(2)) - T(1));
+                tt = vsel(tt < T(0.5), a, b);
+            } else if (eid != EASE_linear) {
+                tt = ease_apply<T, FULL, NS>(eid, tt);
+            }
             x = x + tt * c[7]; y = y + tt * c[8]; z = z + tt * c[9]; goto next; }
         L_REP_PREP: {  // dn.py:80-112: cell index of p
             const int dim = (int)c[0];

@@ -43,7 +43,7 @@
 namespace sdfk {
 
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void ia_sincos(double x, double *s, double *c) { o_sincos(x, s, c); }   // (outlined ocml bodies, sdf_interp.h)
+__device__ __forceinline__ void ia_sincos(double x, double *s, double *c) { sincos64(x, *s, *c); }   // (the interpreter's own, sdf_interp.h: inline, no call)
 __device__ __forceinline__ double ia_atan2(double y, double x) { return o_atan2(y, x); }
 #else
 inline void ia_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
