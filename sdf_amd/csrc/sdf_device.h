@@ -193,6 +193,9 @@ __device__ __forceinline__ unsigned cell_config(const unsigned long long *rb, in
     return cfg;
 }
 
+#ifndef SDF_FAST_VERTEX
+#define SDF_FAST_VERTEX 1
+#endif
 // One marching-cubes vertex on edge e of the cell at (i0,i1,i2); v points at the cell's corner 0
 // in a volume with strides (s0, s1, 1).  skimage's placement: with w = 1/(eps+|v|),
 // t = w_hi / (w_lo + w_hi), evaluated in float64 on the float32 samples, stored as float32.
@@ -205,11 +208,33 @@ __device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0
     const int base = o0 * s0 + o1 * s1 + o2;
     const double vlo = (double)v[base], vhi = (double)v[base + stride];
     const double eps = 2.220446049250313e-16;
-    const double wlo = 1.0 / (eps + fabs(vlo)), whi = 1.0 / (eps + fabs(vhi));
-    const double t = whi / (wlo + whi);
-    double p0 = (double)(i0 + o0), p1 = (double)(i1 + o1), p2 = (double)(i2 + o2);
-    if (axis == 0) p0 = (double)i0 + t; else if (axis == 1) p1 = (double)i1 + t; else p2 = (double)i2 + t;
-    o[0] = (float)p0; o[1] = (float)p1; o[2] = (float)p2;
+    const double a = eps + fabs(vlo), b = eps + fabs(vhi);
+    const double ibase = (double)(axis == 0 ? i0 : (axis == 1 ? i1 : i2));
+    float pf;
+#if SDF_FAST_VERTEX
+    // skimage's t = whi / (wlo + whi) with wlo = 1 / a, whi = 1 / b is a / (a + b) up to its three roundings (<= 5e-16
+    // absolute, t <= 1), and only float32(i + t) is kept.  ONE division by reciprocal + Newton steps instead of three
+    // correctly rounded ones (33 of the ~115 instructions of a vertex); the candidate q = i + t' is within 1e-14 of the
+    // reference's float64 sum, so wherever float32(q - D) == float32(q + D) for D = 2^-44 = 5.7e-14 -- rounding is
+    // monotone -- that float IS the reference's.  Otherwise (a float32 rounding boundary inside the 1e-13 window:
+    // ~1e-6 of the vertices; NaN / infinite samples) the three divisions run.  Bit-identical by construction.
+    const double sab = a + b;
+    double r = __builtin_amdgcn_rcp(sab);
+    r = fma(fma(-sab, r, 1.0), r, r);
+    r = fma(fma(-sab, r, 1.0), r, r);
+    double tq = a * r;
+    tq = fma(fma(-sab, tq, a), r, tq);
+    const double q = ibase + tq;
+    const float f_lo = (float)(q - 0x1p-44), f_hi = (float)(q + 0x1p-44);
+    pf = f_lo;
+    if (__builtin_expect(!(f_lo == f_hi), 0))
+#endif
+    {
+        const double wlo = 1.0 / a, whi = 1.0 / b;
+        const double t = whi / (wlo + whi);
+        pf = (float)(ibase + t);
+    }
+    o[0] = axis == 0 ? pf : (float)(i0 + o0); o[1] = axis == 1 ? pf : (float)(i1 + o1); o[2] = axis == 2 ? pf : (float)(i2 + o2);
 }
 
 // ---- ordered allocation: exclusive prefix of the triangle counts over the work list -----------

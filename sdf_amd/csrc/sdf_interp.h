@@ -72,7 +72,7 @@ SDF_OUTLINE SinCos64 o_sincos64(double x) { SinCos64 r; sincos(x, &r.s, &r.c); r
 // the last bit -- the same class of difference as ocml vs glibc, which the parity tolerances for libm models cover
 // (DESIGN.md section 5).  |x| >= 1e6, NaN and infinities take the ocml path (a wave-uniform branch never taken by
 // angles that come out of atan2 / np_mod).
-SDF_DEV void sincos64(double x, double &sn, double &cs) {
+SDF_DEV void sincos64_dd(double x, double x_lo, double &sn, double &cs) {      // sin / cos of x + x_lo
     const double P1 = 1.5707963267948966, P2 = 6.123233995736766e-17, P3 = -1.4973849048591698e-33;
     const double q = rint(x * 0.6366197723675814);
     const double r0 = fma(-q, P1, x);
@@ -81,7 +81,7 @@ SDF_DEV void sincos64(double x, double &sn, double &cs) {
     const double bb = r - r0;
     double lo = (r0 - (r - bb)) + (b - bb);      // TwoSum: the rounding error of r0 - p2
     lo = lo - fma(q, P2, -p2);                   // the product's own error, exact
-    lo = fma(-q, P3, lo);
+    lo = fma(-q, P3, lo) + x_lo;
     const double z = r * r, v = z * r;
     const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
                                  -1.98412698298579493134e-04), 8.33333333332248946124e-03);
@@ -100,6 +100,37 @@ SDF_DEV void sincos64(double x, double &sn, double &cs) {
         ss = big ? o.s : ss; cc = big ? o.c : cc;
     }
     sn = ss; cs = cc;
+}
+SDF_DEV void sincos64(double x, double &sn, double &cs) { sincos64_dd(x, 0.0, sn, cs); }
+
+// atan2 in float64, INLINE and branch-free, ONE division: with a = min(|x|, |y|), b = max(|x|, |y|), t = a / b in [0, 1]
+// is reduced like fdlibm's atan -- t < 7/16: atan(t); t < 11/16: atan(1/2) + atan((2t - 1) / (2 + t)); else
+// atan(1) + atan((t - 1) / (t + 1)) -- but the quotients are formed from a and b directly ((2a - b) / (2b + a),
+// (a - b) / (a + b): both numerators are exact by Sterbenz' lemma in their ranges), then fdlibm's degree-11
+// polynomial and hi / lo constants; pi/2 - u for |y| > |x|, pi - u for x < 0 (sign bit: atan2(+0, -0) = pi), the sign
+// of y.  Max error 1.48 ulp against an 80-bit reference over 3e7 points (ocml: 104 VALU instructions behind a call).
+SDF_DEV double atan2_64(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const bool swap = ay > ax;
+    const double a = swap ? ax : ay, b = swap ? ay : ax;
+    const bool id1 = !(16.0 * a < 7.0 * b), id2 = !(16.0 * a < 11.0 * b);
+    double num = id1 ? 2.0 * a - b : a, den = id1 ? 2.0 * b + a : b;
+    double hi = id1 ? 4.63647609000806093515e-01 : 0.0, lo = id1 ? 2.26987774529616870924e-17 : 0.0;
+    num = id2 ? a - b : num; den = id2 ? a + b : den;
+    hi = id2 ? 7.85398163397448278999e-01 : hi; lo = id2 ? 3.06161699786838301793e-17 : lo;
+    double q = num / den;
+    q = b == 0.0 ? 0.0 : q;                                   // atan2(+-0, +-0)
+    const bool both_inf = a == __builtin_inf();
+    q = both_inf ? 0.0 : q; hi = both_inf ? 7.85398163397448278999e-01 : hi; lo = both_inf ? 3.06161699786838301793e-17 : lo;
+    const double z = q * q, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                      w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                      w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    double u = hi - ((q * (s1 + s2) - lo) - q);               // atan(a / b) in [0, pi/4]
+    u = swap ? 1.57079632679489655800e+00 - (u - 6.12323399573676603587e-17) : u;
+    u = __builtin_signbit(x) ? 3.1415926535897931160e+00 - (u - 1.2246467991473531772e-16) : u;
+    return copysign(u, y);
 }
 SDF_DEV double m_sin(double x) { return o_sin(x); }
 SDF_DEV float m_sin(float x) { return o_sin(x); }
@@ -774,13 +805,55 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             V nx = c[0] + c[3] * tt + c[6] * d, ny = c[1] + c[4] * tt + c[7] * d;
             late_bind(nx, ny);
             x = nx; y = ny; } goto next;
-        L_CIRC_PREP: if constexpr (FULL) {  // d3.py:379-392: PS[sa] = (d, a, z)
-            PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); } goto next;
+        // circular_array (d3.py:379-392): d = hypot(x, y), a = arctan2(y, x) % da, then the child at
+        // (cos(a - delta) * d, sin(a - delta) * d, z) for delta = da and delta = 0.  In float64 the same two points are
+        // reached by ROTATING (x, y): with k = floor(arctan2(y, x) / da) -- the exact floor, i.e. the sector NumPy's floored
+        // modulo puts the point in -- (cos(a - delta) d, sin(a - delta) d) is (x, y) turned by -(k da + delta).  CIRC_PREP
+        // needs the angle only for k (one inline atan2, an exact remainder test, sin / cos of k * da carried with its
+        // rounding error) and no hypot / fmod; CIRC_SET is four products with the host's cos / sin of delta (c[1], c[2];
+        // delta = 0: the saved point itself).  Against the reference's own expression order (glibc) the coordinates differ
+        // by <= 4 ulp of d (3e7 random and near-boundary points; the ocml / glibc form differed by as much), the
+        // sector agrees except within ~1e-16 rad of a boundary, where any two libm's disagree.  c[1] (PREP) / c[3] (SET)
+        // say whether the lowering found 0 < da < 7 (else, and in float32, the polar form below).
+        L_CIRC_PREP: if constexpr (FULL) {
+            bool polar = true;
+            if constexpr (sizeof(T) == 8) {
+                if (c[1] != T(0)) {   // (uniform)
+                    polar = false;
+                    const double da = c[0];
+                    V xr, yr;
+                    SDF_UNROLL
+                    for (int i = 0; i < NS; i++) {
+                        const double a = atan2_64(y.v[i], x.v[i]);
+                        double k = floor(a / da);
+                        const double rem = fma(-k, da, a);                 // (its sign is exact: the fma rounds once)
+                        k = rem < 0.0 ? k - 1.0 : (rem >= da ? k + 1.0 : k);
+                        const double th = k * da;
+                        double sn, cs;
+                        sincos64_dd(th, fma(k, da, -th), sn, cs);
+                        xr.v[i] = x.v[i] * cs + y.v[i] * sn;
+                        yr.v[i] = y.v[i] * cs - x.v[i] * sn;
+                    }
+                    PSET(sa, xr, yr, z);
+                }
+            }
+            if (polar) PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); } goto next;
         L_CIRC_SET: if constexpr (FULL) {   // p = (cos(a - delta) * d, sin(a - delta) * d, z)
-            V d, a0, z0; PGET(sa, d, a0, z0);
-            const V ang = a0 - c[0];
-            V sn, cs; m_sincos(ang, sn, cs);
-            x = cs * d; y = sn * d; z = z0; } goto next;
+            bool polar = true;
+            if constexpr (sizeof(T) == 8) {
+                if (c[3] != T(0)) {   // (uniform)
+                    polar = false;
+                    V xr, yr, z0; PGET(sa, xr, yr, z0);
+                    if (c[0] == T(0)) { x = xr; y = yr; }
+                    else { V nx = xr * c[1] + yr * c[2], ny = yr * c[1] - xr * c[2]; late_bind(nx, ny); x = nx; y = ny; }
+                    z = z0;
+                }
+            }
+            if (polar) {
+                V d, a0, z0; PGET(sa, d, a0, z0);
+                const V ang = a0 - c[0];
+                V sn, cs; m_sincos(ang, sn, cs);
+                x = cs * d; y = sn * d; z = z0; } } goto next;
         L_TRANS_RAD_PRE: if constexpr (FULL) {  // d3.py:472-481
             const V r = m_hypot(x, y);
             DSET(sa, ease_apply<T, FULL, NS>((int)c[2], np_clip((r - c[0]) / c[1], T(0), T(1)))); } goto next;

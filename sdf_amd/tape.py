@@ -311,12 +311,16 @@ class _Lowering:
             return d
         if op == 'circular_array':
             s = self.palloc()
-            self.emit('CIRC_PREP', a=s, consts=n.params)
+            # (behind da / delta: what the float64 interpreter's rotation form needs -- cos / sin of delta and whether
+            # 0 < da < 7 holds, csrc/sdf_interp.h L_CIRC_PREP; the interval forms and the float32 path read c[0] only)
+            da = float(n.params[0])
+            rot = 1.0 if 0.0 < da < 7.0 else 0.0
+            self.emit('CIRC_PREP', a=s, consts=[da, rot])
             self.chain.append(self.here())
-            self.emit('CIRC_SET', a=s, consts=[n.params[0]])
+            self.emit('CIRC_SET', a=s, consts=[da, float(np.cos(da)), float(np.sin(da)), rot])
             self.value(n.children[0], dim)
             rs = self.here()
-            self.emit('CIRC_SET', a=s, consts=[0.0])
+            self.emit('CIRC_SET', a=s, consts=[0.0, 1.0, 0.0, rot])
             self.value(n.children[0], dim, 'UNION', _rs=rs)
             self.chain.pop()
             self.pfree()
