@@ -63,6 +63,13 @@ int sdf_abi_version(void);
 const char *sdf_last_error(void);
 int sdf_device_count(void); /* <= 0 when no HIP device is usable */
 
+/* free / total device memory (hipMemGetInfo) */
+int sdf_device_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
+/* TEST HOOK: the nth device / pinned-host allocation the library makes from now on fails once (0: off).  The tests
+ * walk it through sdf_ctx_create / sdf_tape_create / sdf_generate and check that every error path returns what it
+ * had taken (tests/test_gpu.py::test_failed_allocations_leak_nothing). */
+int sdf_test_fail_alloc(int nth);
+
 int sdf_ctx_create(int device, sdf_ctx **out);
 int sdf_ctx_destroy(sdf_ctx *ctx);
 /* adopt a caller-owned hipStream_t (e.g. torch's current stream); NULL returns to the own stream */

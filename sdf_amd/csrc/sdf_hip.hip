@@ -293,14 +293,14 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     }
 }
 
-template <bool FULL, bool RARE>
-__global__ __launch_bounds__(CULL_BLOCK) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
+template <bool FULL, bool RARE, int CB = CULL_BLOCK>
+__global__ __launch_bounds__(CB) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
                                                      int *__restrict__ order, int tail_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<FULL, RARE>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
+    cull_body<FULL, RARE, CB>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
 }
 // the variant for tapes without trigonometry and without the rarer leaves: 70 VGPRs without spilling, seven waves per
 // SIMD (the others take 99 - 104; holding them to five or six waves was measured in r02p: no faster)
@@ -795,6 +795,14 @@ static hipError_t event_wait(hipEvent_t ev) {
     return spin_then_block([&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); });
 }
 
+// Every allocation of this translation unit goes through these two, so that the tests can make the n-th one fail
+// (sdf_test_fail_alloc) and check that every error path hands back what it had taken.
+static int g_fail_alloc_in = 0;      // > 0: the g_fail_alloc_in-th allocation from now fails once
+static bool g_alloc_hook_hit = false;
+static bool alloc_fails_now() { g_alloc_hook_hit = g_fail_alloc_in > 0 && --g_fail_alloc_in == 0; return g_alloc_hook_hit; }
+static hipError_t dev_malloc(void **p, size_t bytes) { if (alloc_fails_now()) { *p = nullptr; return hipErrorOutOfMemory; } return hipMalloc(p, bytes); }
+static hipError_t host_malloc(void **p, size_t bytes) { if (alloc_fails_now()) { *p = nullptr; return hipErrorOutOfMemory; } return hipHostMalloc(p, bytes, hipHostMallocDefault); }
+
 // Device allocations are recycled through a small per-device free list: hipMalloc / hipFree cost
 // tens of microseconds each (and hipFree synchronises), which at ~1 ms per generate call was 10 %
 // of the step when every mesh allocated and freed its seven buffers.
@@ -847,10 +855,10 @@ struct DevBuf {
         want = (want + 255) & ~(size_t)255;
         size_t got = 0;
         if (void *q = g_pool.take(want, dev, &got)) { p = q; bytes = got; device = dev; return 0; }
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {   // give the cached blocks back to the driver and retry once
+        hipError_t e = dev_malloc(&p, want);
+        if (e != hipSuccess && !g_alloc_hook_hit) {   // give the cached blocks back to the driver and retry once
             g_pool.drop_device(dev);
-            e = hipMalloc(&p, want);
+            e = dev_malloc(&p, want);
         }
         if (e != hipSuccess) { p = nullptr; return fail(std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
         bytes = want; device = dev;
@@ -900,7 +908,7 @@ struct sdf_ctx {
     CallSlot slots[SDF_CALL_SLOTS];
     unsigned slot_seq = 0;
     int slot_streams = 1;             // SDF_SLOT_STREAMS=0: asynchronous calls stay on the context's stream (diagnostics)
-    int cull_block = 256;             // SDF_CULL_BLOCK=128: the two-wave variant of k_cull_lean (tuning)
+    int cull_block = 0;               // SDF_CULL_BLOCK=64 / 128 / 256: threads per work item of k_cull (0: the default of the variant)
     int tail_order = 1;               // SDF_TAIL_ORDER=0: k_mesh takes the whole work list in order
     int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
 };
@@ -1008,6 +1016,15 @@ int sdf_device_count(void) {
     return n;
 }
 
+int sdf_test_fail_alloc(int nth) { g_fail_alloc_in = nth > 0 ? nth : 0; return 0; }
+
+int sdf_device_mem_info(int device, size_t *free_bytes, size_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return fail("sdf_device_mem_info: NULL argument");
+    HIPCHK(set_device(device));
+    HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
+    return 0;
+}
+
 int sdf_ctx_create(int device, sdf_ctx **out) {
     if (!out) return fail("sdf_ctx_create: out is NULL");
     int n = 0;
@@ -1036,7 +1053,7 @@ static int ctx_init(sdf_ctx *c) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipHostMalloc(&c->h_stage, (size_t)SDF_CALL_SLOTS * SDF_STAGE_BYTES, hipHostMallocDefault));
+    HIPCHK(host_malloc(&c->h_stage, (size_t)SDF_CALL_SLOTS * SDF_STAGE_BYTES));
     for (auto &cs : c->slots) {
         HIPCHK(hipEventCreate(&cs.e0)); HIPCHK(hipEventCreate(&cs.e2)); HIPCHK(hipEventCreate(&cs.e3)); HIPCHK(hipEventCreate(&cs.e4));
         HIPCHK(hipEventCreateWithFlags(&cs.done, hipEventDisableTiming));
@@ -1151,9 +1168,9 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     for (size_t i = 0; i < c64.size(); i++) c32[i] = (float)c64[i];
     std::vector<uint32_t> pcode(code, code + n_words);   // + one more END: the interpreter looks one instruction ahead
     pcode.push_back(code[n_words - 2]); pcode.push_back(code[n_words - 1]);
-    HIPCHK(hipMalloc((void **)&t->d_code, pcode.size() * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **)&t->d_c64, c64.size() * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&t->d_c32, c32.size() * sizeof(float)));
+    HIPCHK(dev_malloc((void **)&t->d_code, pcode.size() * sizeof(uint32_t)));
+    HIPCHK(dev_malloc((void **)&t->d_c64, c64.size() * sizeof(double)));
+    HIPCHK(dev_malloc((void **)&t->d_c32, c32.size() * sizeof(float)));
     HIPCHK(hipMemcpy(t->d_code, pcode.data(), pcode.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t->d_c64, c64.data(), c64.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t->d_c32, c32.data(), c32.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1170,8 +1187,8 @@ int sdf_tape_set_prune_info(sdf_tape *t, const uint16_t *rstart, const uint16_t 
         if (!none && !(lstart[i] <= rstart[i] && rstart[i] <= i)) return fail("sdf_tape_set_prune_info: operand range out of order");
     }
     HIPCHK(set_device(t->ctx->device));
-    if (!t->d_rstart) HIPCHK(hipMalloc((void **)&t->d_rstart, n_instr * 2));
-    if (!t->d_lstart) HIPCHK(hipMalloc((void **)&t->d_lstart, n_instr * 2));
+    if (!t->d_rstart) HIPCHK(dev_malloc((void **)&t->d_rstart, n_instr * 2));
+    if (!t->d_lstart) HIPCHK(dev_malloc((void **)&t->d_lstart, n_instr * 2));
     HIPCHK(hipMemcpy(t->d_rstart, rstart, n_instr * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t->d_lstart, lstart, n_instr * 2, hipMemcpyHostToDevice));
     return 0;
@@ -1544,7 +1561,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     PruneArgs pa = {};
     pa.first_block = 0x7fffffff;
     // many batches: the interval pass runs behind k_compact, for the surviving batches only (k_prune_list)
-    const bool prune_listed = pruning && sparse && nb >= c->prune_list_min;
+    // (a rank of a multi-GPU job prunes its own share of the work list only, whatever the grid's size)
+    const bool prune_listed = pruning && sparse && (nb >= c->prune_list_min || shard_count > 1);
     unsigned skip_blocks = (sparse && !d_kinds_in) ? (unsigned)((nb + SKIP_BATCHES_PER_BLOCK - 1) / SKIP_BATCHES_PER_BLOCK) : 0u, prune_blocks = 0;
     size_t prune_lds = 0;
     if (pruning) {
@@ -1601,6 +1619,14 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         auto kc = t->full ? (t->ia_rare ? k_cull<true, true> : k_cull<true, false>) : (t->ia_rare ? k_cull<false, true> : k_cull_lean);
         int cull_block = CULL_BLOCK;
         if (c->cull_block == 128 && kc == k_cull_lean) { kc = k_cull_lean128; cull_block = 128; }
+        // (the trig-capable variant with one or two waves per work item: the first level of the pass -- 64 boxes -- keeps
+        // ONE wave of a workgroup busy whatever its size, so smaller workgroups mean more work items per compute unit)
+        // measured (r03f, prepass of weave 2^33 / 2^27, gearlike 2^30, knurling 2^27, ms): 256 threads 8.95 / 1.52 / 0.325 /
+        // 0.364; 128: 6.61 / 1.35 / 0.276 / 0.361; 64: 6.05 / 1.44 / 0.298 / 0.442 -- two waves are the default here
+        if (t->full && !t->ia_rare && c->cull_block != 256) {
+            cull_block = c->cull_block == 64 ? 64 : 128;
+            kc = cull_block == 64 ? k_cull<true, false, 64> : k_cull<true, false, 128>;
+        }
         const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

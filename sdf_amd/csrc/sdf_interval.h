@@ -44,7 +44,7 @@ namespace sdfk {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void ia_sincos(double x, double *s, double *c) { sincos64(x, *s, *c); }   // (the interpreter's own, sdf_interp.h: inline, no call)
-__device__ __forceinline__ double ia_atan2(double y, double x) { return o_atan2(y, x); }
+__device__ __forceinline__ double ia_atan2(double y, double x) { return atan2_64(y, x); }   // (inline, 1.5 ulp: the callers widen by 1e-12)
 #else
 inline void ia_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
 inline double ia_atan2(double y, double x) { return atan2(y, x); }

@@ -56,6 +56,8 @@ ABI = {
     'sdf_abi_version': (ctypes.c_int, []),
     'sdf_last_error': (ctypes.c_char_p, []),
     'sdf_device_count': (ctypes.c_int, []),
+    'sdf_device_mem_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    'sdf_test_fail_alloc': (ctypes.c_int, [ctypes.c_int]),
     'sdf_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     'sdf_ctx_destroy': (ctypes.c_int, [_vp]),
     'sdf_ctx_set_stream': (ctypes.c_int, [_vp, _vp]),

@@ -1308,3 +1308,87 @@ print('ok')
 ''' % (ROOT, ROOT, GOLDEN)
     r = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, SDF_PARK='0'), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+def test_failed_allocations_leak_nothing():
+    """Error paths hand back what they took: the library's test hook (sdf_test_fail_alloc) makes the n-th allocation
+    fail inside sdf_ctx_create, sdf_tape_create / sdf_tape_set_prune_info and sdf_generate in turn; every call must
+    fail with the allocator's message (never crash), the context must stay usable, and once tape and context are
+    destroyed the device's free memory (hipMemGetInfo) is back where it was.  A fresh process: the hook and the
+    library's buffer pools are process-wide."""
+    import subprocess
+    import sys
+    script = r'''
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import sdf_amd, fixtures
+from sdf_amd import core, engine, tape
+lib = engine.load_library()
+def free():
+    f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert lib.sdf_device_mem_info(0, ctypes.byref(f), ctypes.byref(t)) == 0
+    return f.value
+def err():
+    return (lib.sdf_last_error() or b'').decode()
+h = ctypes.c_void_p()
+assert lib.sdf_ctx_create(0, ctypes.byref(h)) == 0 and lib.sdf_ctx_destroy(h) == 0      # (the runtime's own lazy allocations)
+base = free()
+n_ctx = 0
+for n in range(1, 10):                                   # ---- sdf_ctx_create ----
+    lib.sdf_test_fail_alloc(n)
+    h = ctypes.c_void_p()
+    rc = lib.sdf_ctx_create(0, ctypes.byref(h))
+    lib.sdf_test_fail_alloc(0)
+    if rc == 0:
+        assert lib.sdf_ctx_destroy(h) == 0
+        break
+    n_ctx += 1
+    assert 'emory' in err(), err()
+    assert h.value is None and abs(free() - base) <= (8 << 20), (n, free(), base)
+assert n_ctx >= 2, n_ctx
+ns = {k: getattr(sdf_amd, k) for k in dir(sdf_amd) if not k.startswith('_')}
+f = fixtures.build('ex_example', ns)
+t = tape.lower(f)
+eng = engine.Engine(0)
+n_tape = 0
+for n in range(1, 10):                                   # ---- the tape (sdf_tape_create, sdf_tape_set_prune_info) ----
+    lib.sdf_test_fail_alloc(n)
+    try:
+        dt = engine.DeviceTape(eng, t)
+        lib.sdf_test_fail_alloc(0)
+        break
+    except engine.SdfHipError as e:
+        lib.sdf_test_fail_alloc(0)
+        n_tape += 1
+        assert 'emory' in str(e), e
+assert n_tape >= 4, n_tape
+X, Y, Z, _ = core.grid_axes(((-0.85, -0.85, -0.85), (0.85, 0.85, 0.85)), samples=2 ** 20)
+m = eng.generate(dt, X, Y, Z); want = m.points().copy(); m.close()
+n_gen = 0
+for n in range(1, 40):                                   # ---- sdf_generate: a fresh context has every buffer to allocate ----
+    eng2 = engine.Engine(0)
+    dt2 = engine.DeviceTape(eng2, t)
+    lib.sdf_test_fail_alloc(n)
+    try:
+        m = eng2.generate(dt2, X, Y, Z)
+        lib.sdf_test_fail_alloc(0)
+        assert np.array_equal(m.points(), want)
+        m.close(); done = True
+    except engine.SdfHipError as e:
+        lib.sdf_test_fail_alloc(0)
+        n_gen += 1; done = False
+        assert 'emory' in str(e), e
+        m = eng2.generate(dt2, X, Y, Z)                  # the context is still good
+        assert np.array_equal(m.points(), want)
+        m.close()
+    dt2._fin(); eng2._fin()
+    if done:
+        break
+assert n_gen >= 5, n_gen
+dt._fin(); eng._fin()
+assert abs(free() - base) <= (8 << 20), (free(), base)
+print('ok', n_ctx, n_tape, n_gen)
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-2000:] + r.stderr[-3000:]

@@ -28,6 +28,12 @@ MODELS = {
     'smooth_x4': 'union(' + ', '.join('sphere(%g, (%g, 0, 0))' % (1 - 0.05 * i, 0.3 * i) for i in range(4)) + ', k=0.2)',
     'example': '(sphere(1) & box(1.5)) - (cylinder(0.5).orient(X) | cylinder(0.5).orient(Y) | cylinder(0.5).orient(Z))',
     'circ_array': 'cylinder(0.1).translate((0.8, 0, 0)).circular_array(12)',
+    # the weave model's chain, one construct at a time (each rung adds what the name says)
+    'rbox': 'rounded_box([1.2, 0.5, 0.25], 0.1)',
+    'rbox_t': 'rounded_box([1.2, 0.5, 0.25], 0.1).translate((0.5, 0, 0.0625))',
+    'rbox_tb': 'rounded_box([1.2, 0.5, 0.25], 0.1).translate((0.5, 0, 0.0625)).bend_linear(X * 0.25, X * 0.75, Z * -0.1875, ease.in_out_quad)',
+    'rbox_tbc': 'rounded_box([1.2, 0.5, 0.25], 0.1).translate((0.5, 0, 0.0625)).bend_linear(X * 0.25, X * 0.75, Z * -0.1875, ease.in_out_quad).circular_array(3, 0)',
+    'rbox_tbcr': 'rounded_box([1.2, 0.5, 0.25], 0.1).translate((0.5, 0, 0.0625)).bend_linear(X * 0.25, X * 0.75, Z * -0.1875, ease.in_out_quad).circular_array(3, 0).repeat((0.9, 1.8, 0), padding=1)',
     'twist': 'box((0.6, 0.6, 1.8)).twist(1.5)',
     'gearlike': """(sphere(2) & slab(z0=-0.5, z1=0.5).k(0.1)) - cylinder(1).k(0.1) - cylinder(0.25).circular_array(16, 2).k(0.1)""",
     'blobby': """union(*[sphere(0.4, (0.6 * ((i * 7) % 5 - 2) / 2, 0.6 * ((i * 3) % 5 - 2) / 2, 0.6 * ((i * 5) % 5 - 2) / 2)) for i in range(7)], k=0.3)""",
@@ -54,10 +60,13 @@ print('RESULT', t.n_instr, st['n_eval_voxels'], st['ms_mesh'], st['triangles'])
 
 def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else 'f64'
-    env = dict(os.environ, SDF_MESH_PROF='1')
+    env = dict(os.environ, SDF_MESH_PROF='1', SDF_CULL='0', SDF_PRUNE='0')     # every sample through the whole tape
+    only = [a for a in sys.argv[2:]]
     print('%-14s %6s %10s %10s %12s %12s' % ('model', 'instr', 'ms_mesh', 'tris', 'cyc/sample', 'd(cyc)/instr'))
     base = None
     for name, expr in MODELS.items():
+        if only and name not in only and name != 'sphere':
+            continue
         p = subprocess.run([sys.executable, '-c', CHILD % dict(root=ROOT, expr=expr, prec=prec)], env=env,
                            capture_output=True, text=True)
         m = re.findall(r'sample (\d+) count (\d+) list (\d+) emit (\d+)', p.stderr)
