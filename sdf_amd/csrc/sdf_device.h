@@ -99,6 +99,7 @@ struct MeshArgs {
     unsigned *cells;                    // 9 dwords per record
     unsigned *tlist;
     unsigned long long cells_cap, tlist_cap;
+    const int *block_item;              // k_scan_items' index for k_emit2: the work item of triangle 256 b (or NULL)
     // The LAST `tail` work items of the shard are handed out by descending cost instead of by position: order[i] =
     // k_cull's estimate for the i-th item of the tail (listed tasks x instructions); the workgroup that takes the
     // r-th of them looks for the item of rank r.  The kernel ends when its slowest workgroup does, and a workgroup's

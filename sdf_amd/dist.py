@@ -183,6 +183,7 @@ def _all_gather(td, g, mine, group, world, sb, async_op):
 
 # ---- the native path: RCCL called from inside the library (csrc/sdf_comm.inc) ----
 _COMMS = {}      # (engine id, group id) -> engine.Comm
+_NATIVE_BROKEN = []   # why the native path was given up in this process (empty: it was not)
 
 
 class NativeStep:
@@ -249,8 +250,15 @@ def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=No
         raise RuntimeError('torch.distributed is not initialised')
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if td.get_backend(group) == 'nccl' else torch.device('cpu')
-    if _native_ok(eng, td, tape, device, group):
-        comm = _native_comm(eng, td, group)
+    comm = None
+    if _native_ok(eng, td, tape, device, group) and not _NATIVE_BROKEN:
+        try:
+            comm = _native_comm(eng, td, group)
+        except Exception as e:       # (librccl not loadable, communicator refused: every rank fails alike and takes the torch path)
+            import sys
+            sys.stderr.write('sdf_amd.dist: native RCCL exchange unavailable (%s); using torch.distributed\n' % (e,))
+            _NATIVE_BROKEN.append(repr(e))
+    if comm is not None:
         if chunks is None:
             chunks = int(os.environ.get('SDF_DIST_CHUNKS', '1'))
         held = comm._lane_owner.get(lane)
