@@ -430,15 +430,25 @@ def test_skip_test_in_pieces_and_generate_from_its_verdicts(ns, eng):
         assert np.array_equal(np.concatenate(parts), want)
 
 
-def test_bench_two_ranks_on_one_device_exchange_slabs_between_processes(tmp_path):
+@pytest.mark.parametrize('driver', ['torch-gloo', 'native-mock-rccl'])
+def test_bench_two_ranks_on_one_device_exchange_slabs_between_processes(driver, tmp_path):
     """`python bench.py --gpus 2` the way the driver starts it (no launcher around it: bench.py starts its ranks
-    itself), both ranks on THIS device, gloo as the transport (RCCL refuses two ranks on one GPU), the slabs kept in
-    device memory: two real processes run sdf_amd.dist's device side -- sdf_generate_compact_async into a slab, the
-    all-gather, sdf_expand_slabs on the step's own stream -- and rank 0's line must carry the reference's soup hash"""
+    itself), both ranks on THIS device (RCCL refuses two ranks on one GPU, so torch's own collectives go over gloo), the
+    slabs kept in device memory.  `torch-gloo`: two real processes run sdf_amd.dist's device side --
+    sdf_generate_compact_async into a slab, the all-gather, sdf_expand_slabs on the step's own stream; `native-mock-rccl`:
+    the step inside the library (csrc/sdf_comm.inc, what N > 1 runs under nccl) with tests/native/mock_rccl.cpp standing
+    in for librccl.  Rank 0's line must carry the reference's soup hash."""
     import json
+    import shutil
     import subprocess
     import sys
     env = dict(os.environ, SDF_BENCH_ONE_DEVICE='1', SDF_BENCH_BACKEND='gloo', SDF_BENCH_COMM_DEVICE='cuda')
+    if driver == 'native-mock-rccl':
+        hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+        mock = str(tmp_path / 'mock_rccl.so')
+        subprocess.run([hipcc, '-shared', '-fPIC', '-O2', '-o', mock, os.path.join(ROOT, 'tests', 'native', 'mock_rccl.cpp')],
+                       check=True, capture_output=True, timeout=300)
+        env.update(SDF_DIST_NATIVE='force', SDF_RCCL_LIB=mock)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
@@ -448,6 +458,7 @@ def test_bench_two_ranks_on_one_device_exchange_slabs_between_processes(tmp_path
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['parity_check'] is True
     assert rec['config']['triangles'] == 2945152 and rec['exchange']['payload'].startswith('f32')
+    assert ('native' in rec['exchange']['driver']) == (driver == 'native-mock-rccl')
     assert len(rec['device_ms']['per_rank_mesh']) == 2 and rec['value'] > 0
 
 
@@ -1433,3 +1444,89 @@ def test_circular_array_at_and_around_sector_boundaries(count, ns, oracle_lib, e
         ok = np.isfinite(o)
         assert np.array_equal(np.isfinite(v), ok)
         assert np.all(np.abs(v[ok] - o[ok]) <= value_tolerance(o[ok], P[ok])), float(np.max(np.abs(v[ok] - o[ok]) / value_tolerance(o[ok], P[ok])))
+
+
+def _native_exchange_worker(rank, world, port, q, mock, skip_shard, first_cap):
+    import hashlib
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SDF_RCCL_LIB=mock, SDF_DIST_NATIVE='force')
+    if skip_shard:
+        os.environ['SDF_SKIP_SHARD_MIN'] = '0'
+    if first_cap:
+        os.environ['SDF_COMM_FIRST_CAP_TRIS'] = str(first_cap)
+    try:
+        import torch
+        import torch.distributed as td
+        torch.cuda.set_device(0)
+        td.init_process_group('gloo', rank=rank, world_size=world)
+        import sdf_amd
+        from sdf_amd import dist, engine
+        ns = {k: getattr(sdf_amd, k) for k in dir(sdf_amd) if not k.startswith('_')}
+        eng = engine.get_engine(0)
+        dev = torch.device('cuda', 0)
+        out = []
+        for name, samples in (('ex_example', 2 ** 22), ('ex_weave', 2 ** 21), ('ex_blobby', 2 ** 24)):
+            f = fixtures.build(name, ns)
+            X, Y, Z, _ = core.grid_axes(tuple(map(tuple, BOUNDS[name])), samples=samples)
+            m = eng.generate(f, X, Y, Z)
+            want, wst = m.points(), m.stats()
+            m.close()
+            for chunks in (1, 1, 2):              # (the second call runs on the capacities the first one learned)
+                soup, st = dist.generate_sharded_device(eng, f, X, Y, Z, 32, True, device=dev, chunks=chunks)
+                got = soup.cpu().numpy().reshape(-1, 3)
+                assert 'native' in st['exchange'] and st['world'] == world and st['chunks'] == chunks
+                assert st['triangles'] == len(want) // 3 == sum(st['per_rank_triangles'])
+                assert np.array_equal(got, want), (name, chunks)
+                assert (st['skipped'], st['empty'], st['nonempty'], st['n_eval_voxels']) == (wst['skipped'], wst['empty'], wst['nonempty'], wst['n_eval_voxels'])
+                out.append((name, chunks, st['n_retries'], st['per_rank_triangles']))
+            # two steps in flight on the two lanes, collected in order
+            a = dist.submit_sharded(eng, f, X, Y, Z, 32, True, device=dev, lane=0)
+            b = dist.submit_sharded(eng, f, X, Y, Z, 32, True, device=dev, lane=1)
+            for step in (a, b):
+                soup, st = dist.collect_sharded(step)
+                assert np.array_equal(soup.cpu().numpy().reshape(-1, 3), want)
+        dist.shutdown_native()
+        td.destroy_process_group()
+        q.put((rank, 'ok', out))
+    except BaseException:
+        import traceback
+        q.put((rank, 'ERROR', traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize('world,skip_shard,first_cap', [(2, False, 0), (3, True, 0), (2, True, 700)],
+                         ids=['2-ranks', '3-ranks-sharded-skip', '2-ranks-sharded-skip-tiny-first-capacity'])
+def test_native_exchange_between_processes_on_one_device(world, skip_shard, first_cap, tmp_path):
+    """The library's OWN multi-GPU step (csrc/sdf_comm.inc: sdf_generate_sharded_async / sdf_exchange_wait -- shards of
+    the work list, skip test shared out and its verdicts gathered, slabs, expansion, capacity hints, the retry every
+    rank takes on the same gathered headers, two lanes) between several real processes.  RCCL refuses two ranks on one
+    GPU, so the five RCCL entry points the library dlopens are provided by tests/native/mock_rccl.cpp (shared-memory
+    all-gather, SDF_RCCL_LIB), and torch (gloo) only carries the communicator ids (SDF_DIST_NATIVE=force).  Every rank
+    must end with the single-GPU soup, bit for bit, for example / weave (two-pass, 4-slot libm kernel) / blobby, with one
+    and two shards per rank, and the ranks must agree on retries and per-rank counts."""
+    import shutil
+    import subprocess
+    import torch.multiprocessing as mp
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    mock = str(tmp_path / 'mock_rccl.so')
+    subprocess.run([hipcc, '-shared', '-fPIC', '-O2', '-o', mock, os.path.join(ROOT, 'tests', 'native', 'mock_rccl.cpp')],
+                   check=True, capture_output=True, timeout=300)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 11 * world + (5 if skip_shard else 0) + (3 if first_cap else 0)
+    procs = [ctx.Process(target=_native_exchange_worker, args=(r, world, port, q, mock, skip_shard, first_cap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        out = [q.get(timeout=600) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.terminate()
+    errors = [o for o in out if o[1] == 'ERROR']
+    assert not errors, 'rank %d failed:\n%s' % (errors[0][0], errors[0][2])
+    assert all(o[2] == out[0][2] for o in out)                       # same retries, same per-rank counts on every rank
+    if first_cap:
+        assert any(r[2] >= 1 for r in out[0][2])                     # the tiny first capacity was flagged and repeated
+    else:
+        assert all(r[2] == 0 for r in out[0][2])
