@@ -354,9 +354,15 @@ def main():
             if td is not None:
                 td.barrier()
 
-    if rank != 0:
+    def leave():
+        """every rank tears the process group down at the same point (a rank that closes its connections while another is
+        still alive has been seen to abort the survivor under gloo)"""
         if td is not None:
+            td.barrier()
             td.destroy_process_group()
+
+    if rank != 0:
+        leave()
         return
 
     # ---- roofline of the dominant kernel (k_mesh), from HIP events on the stream the kernel runs on ----
@@ -474,8 +480,7 @@ def main():
         'other_configs': others or None,
     }
     print(json.dumps(out), flush=True)
-    if td is not None:
-        td.destroy_process_group()
+    leave()
 
 
 if __name__ == '__main__':

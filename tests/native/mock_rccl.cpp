@@ -25,7 +25,8 @@ typedef int ncclDataType_t;
 
 namespace {
 enum { MAX_RANKS = 8 };
-const size_t SLOT_BYTES = (size_t)96 << 20;     // per rank; the tests' slabs are a few MB
+// bytes per rank (MOCK_RCCL_SLOT_MB, default 96; the segment is sparse: only what is written is backed by memory)
+const size_t SLOT_BYTES = [] { const char *e = getenv("MOCK_RCCL_SLOT_MB"); return (size_t)(e ? atol(e) : 96) << 20; }();
 struct Shared {
     std::atomic<int> arrived, generation, attached;
     char pad[52];
@@ -100,7 +101,7 @@ const char *ncclGetErrorString(ncclResult_t r) {
     case ncclSuccess: return "no error";
     case ncclUnhandledCudaError: return "mock rccl: HIP error";
     case ncclSystemError: return "mock rccl: shared memory error";
-    case ncclInvalidArgument: return "mock rccl: invalid argument (piece larger than the mock's 96 MB slot?)";
+    case ncclInvalidArgument: return "mock rccl: invalid argument (piece larger than the mock's slot?  MOCK_RCCL_SLOT_MB)";
     default: return "mock rccl: internal error";
     }
 }

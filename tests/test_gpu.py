@@ -448,7 +448,7 @@ def test_bench_two_ranks_on_one_device_exchange_slabs_between_processes(driver, 
         mock = str(tmp_path / 'mock_rccl.so')
         subprocess.run([hipcc, '-shared', '-fPIC', '-O2', '-o', mock, os.path.join(ROOT, 'tests', 'native', 'mock_rccl.cpp')],
                        check=True, capture_output=True, timeout=300)
-        env.update(SDF_DIST_NATIVE='force', SDF_RCCL_LIB=mock)
+        env.update(SDF_DIST_NATIVE='force', SDF_RCCL_LIB=mock, MOCK_RCCL_SLOT_MB='512')    # (512^3, 2 ranks: 302 MB first-call slabs)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
