@@ -124,6 +124,33 @@ def read_clocks():
         return None
 
 
+def trace(msg):
+    """progress markers on stderr (SDF_BENCH_TRACE=1), tagged with the rank"""
+    if os.environ.get('SDF_BENCH_TRACE'):
+        sys.stderr.write('[bench rank %s %.1f s] %s\n' % (os.environ.get('RANK', '0'), time.perf_counter(), msg))
+        sys.stderr.flush()
+
+
+def watchdog(out):
+    """N > 1 only: the optional `other_configs` section must not take the headline line down with it.  If it has not
+    finished after SDF_BENCH_OTHER_TIMEOUT_S (default 600) seconds -- a rank stuck in a collective its peers never
+    entered -- rank 0 prints the line it already has (with the reason in `other_configs`) and every rank exits."""
+    import threading
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return None
+    limit = float(os.environ.get('SDF_BENCH_OTHER_TIMEOUT_S', '600'))
+
+    def fire():
+        if out is not None:
+            out['other_configs'] = [{'error': 'other_configs did not finish within %.0f s; skipped' % limit}]
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def stats3(v):
     v = np.asarray(v, dtype=np.float64)
     return {'min': round(float(v.min()), 4), 'median': round(float(np.median(v)), 4), 'max': round(float(v.max()), 4), 'n': int(len(v))}
@@ -190,6 +217,7 @@ def main():
     def measure(model, samples_log2, steps, warmup, depth, bounds=None):
         """W untimed + K timed steps of one job; a step is complete when its counters (N > 1: the gathered slab
         headers) are back on the host.  Returns timings, per-step kernel times, the last step's soup + statistics."""
+        trace('measure %s 2^%d: %d steps, %d in flight' % (model, samples_log2, steps, depth))
         f, _ = build_model(model)
         tape = eng.tape_for(f)
         if bounds is None:
@@ -258,6 +286,7 @@ def main():
             one_step()
         sync()                                 # every one of the K steps is complete (collected) here
         dt = time.perf_counter() - t0
+        trace('measure %s done: %.3f ms per step' % (model, 1e3 * dt / steps))
         assert len(mesh_ms) == steps
         if td is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=stat_dev)
@@ -329,10 +358,13 @@ def main():
             mesh.close()
         incl = grid_voxels * n_incl / (time.perf_counter() - t1)
 
-    # ---- BASELINE configs 3 - 5 at their real sizes (every rank takes part; a few steps each) ----
-    others = []
-    if not args.no_other_configs and args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64':
+    # ---- BASELINE configs 3 - 5 at their real sizes (every rank takes part; a few steps each).  This section comes LAST
+    # and, for N > 1, under a watchdog: it is the one place where a rank-local failure (an allocation that fails on one
+    # rank only) would leave the other ranks inside a collective for ever, and the headline line must not depend on it ----
+    def run_other_configs():
+        others = []
         for model, log2, want_tris in OTHER_CONFIGS:
+            trace('other config %s 2^%d' % (model, log2))
             try:
                 r = measure(model, log2, 3, 1, 1 if world == 1 else 2)
                 s2, t2 = r['state']['stats'], int(r['state']['tris'])
@@ -353,6 +385,7 @@ def main():
                 others.append({'workload': '%s @ samples=2**%d' % (model, log2), 'error': repr(e)[:300]})
             if td is not None:
                 td.barrier()
+        return others
 
     def leave():
         """every rank tears the process group down at the same point (a rank that closes its connections while another is
@@ -361,7 +394,11 @@ def main():
             td.barrier()
             td.destroy_process_group()
 
+    want_others = not args.no_other_configs and args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64'
     if rank != 0:
+        if want_others:
+            watchdog(None)
+            run_other_configs()
         leave()
         return
 
@@ -477,8 +514,13 @@ def main():
         'roofline': roofline,
         'cpu_baseline': cpu_ref if cpu_ref is not None else cpu,
         'cpu_port': cpu,
-        'other_configs': others or None,
+        'other_configs': None,
     }
+    if want_others:
+        timer = watchdog(out)
+        out['other_configs'] = run_other_configs()
+        if timer is not None:
+            timer.cancel()
     print(json.dumps(out), flush=True)
     leave()
 
