@@ -187,6 +187,7 @@ def main():
     backend = os.environ.get('SDF_BENCH_BACKEND', 'nccl')
     if os.environ.get('SDF_BENCH_ONE_DEVICE'):
         local_rank = 0
+        os.environ['SDF_AMD_DEVICE'] = '0'      # (what engine.get_engine() without an argument -- core._estimate_bounds -- resolves to)
     torch.cuda.set_device(local_rank)
     td = None
     if world > 1:
@@ -223,6 +224,7 @@ def main():
         if bounds is None:
             bounds = EXAMPLE_BOUNDS if model == 'example' else core._estimate_bounds(f)
         X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** samples_log2)
+        trace('bounds and axes ready: %dx%dx%d' % (len(X), len(Y), len(Z)))
         state = {'n': 0}
         inflight, mesh_ms, exch_ms, dev_ms, sclk = [], [], [], [], []
 
@@ -243,6 +245,7 @@ def main():
 
         def collect_dist():
             soup, st = dist.collect_sharded(inflight.pop(0))
+            trace('collected a step: %d triangles, %d retries' % (st['triangles'], st.get('n_retries', 0)))
             state['soup'], state['stats'], state['tris'] = soup, st, st['triangles']
             mesh_ms.append(st['ms_mesh'])            # this rank: prepass + k_mesh of its shard, into the slab
             exch_ms.append((st['ms_exchange'], st['ms_expand']))
@@ -262,7 +265,9 @@ def main():
                 while len(inflight) >= depth:
                     collect_dist()
                 state['n'] += 1
+                trace('submit step %d' % state['n'])
                 inflight.append(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=comm_dev, lane=state['n'] % 2, chunks=args.chunks))
+                trace('submitted step %d' % state['n'])
 
         def sync():
             while inflight:

@@ -37,6 +37,8 @@ struct Comm {
     size_t map_bytes;
     int rank, nranks;
     char name[64];
+    void *bounce = nullptr;
+    size_t bounce_bytes = 0;
 };
 void barrier(Comm *c) {
     const int g = c->sh->generation.load();
@@ -77,6 +79,7 @@ ncclResult_t ncclCommDestroy(void *comm) {
     Comm *c = (Comm *)comm;
     if (!c) return ncclSuccess;
     if (c->rank == 0) shm_unlink(c->name);
+    if (c->bounce) (void)hipHostFree(c->bounce);
     munmap(c->sh, c->map_bytes);
     delete c;
     return ncclSuccess;
@@ -87,11 +90,23 @@ ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t count, n
     if (!c || !sendbuff || !recvbuff || dtype != 1 /* ncclUint8 */) return ncclInvalidArgument;
     if (count > SLOT_BYTES) return ncclInvalidArgument;
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
-    if (count && hipMemcpy(c->slots + (size_t)c->rank * SLOT_BYTES, sendbuff, count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    // (the HIP runtime never sees the shared pages: device <-> a private pinned bounce buffer <-> shared memory)
+    if (count > c->bounce_bytes) {
+        if (c->bounce) (void)hipHostFree(c->bounce);
+        c->bounce = nullptr; c->bounce_bytes = 0;
+        if (hipHostMalloc(&c->bounce, count, hipHostMallocDefault) != hipSuccess) return ncclUnhandledCudaError;
+        c->bounce_bytes = count;
+    }
+    if (count) {
+        if (hipMemcpy(c->bounce, sendbuff, count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+        memcpy(c->slots + (size_t)c->rank * SLOT_BYTES, c->bounce, count);
+    }
     barrier(c);
-    for (int r = 0; r < c->nranks && count; r++)
-        if (hipMemcpy((unsigned char *)recvbuff + (size_t)r * count, c->slots + (size_t)r * SLOT_BYTES, count, hipMemcpyHostToDevice) != hipSuccess)
+    for (int r = 0; r < c->nranks && count; r++) {
+        memcpy(c->bounce, c->slots + (size_t)r * SLOT_BYTES, count);
+        if (hipMemcpy((unsigned char *)recvbuff + (size_t)r * count, c->bounce, count, hipMemcpyHostToDevice) != hipSuccess)
             return ncclUnhandledCudaError;
+    }
     barrier(c);                                            // (the slots may be overwritten by the next collective now)
     return ncclSuccess;
 }
