@@ -361,6 +361,7 @@ class Exchange:
     def __init__(self, comm, handle, tape):
         self.comm, self.handle, self._tape = comm, handle, tape
         self._fin = weakref.finalize(self, comm.engine.lib.sdf_exchange_destroy, handle)
+        comm._live.add(self)          # (a communicator that is closed first takes its steps with it: Comm.close)
 
     def wait(self):
         """the step's one host synchronisation -> (DeviceSoup, stats dict)"""
@@ -398,6 +399,7 @@ class Comm:
         _check(eng.lib, eng.lib.sdf_comm_create(eng.ctx, ctypes.cast(raw, _vp), self.n_lanes, self.rank, self.world,
                                                 ctypes.byref(self.handle)))
         self._fin = weakref.finalize(self, eng.lib.sdf_comm_destroy, self.handle)
+        self._live = weakref.WeakSet()          # steps (Exchange) that still hold a handle into this communicator
 
     def submit(self, sdf, X, Y, Z, batch_size=32, sparse=True, chunks=1, lane=0):
         eng = self.engine
@@ -412,6 +414,10 @@ class Comm:
         return Exchange(self, h, dt)
 
     def close(self):
+        """destroy the communicator -- after the steps that point into it (an sdf_exchange handle must not outlive its
+        sdf_comm: its destructor looks at the communicator's lanes)"""
+        for x in list(self._live):
+            x.close()
         self._fin()
 
 
