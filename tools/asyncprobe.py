@@ -1,3 +1,6 @@
+"""One call at a time, three ways (GPU box only, diagnostics): the soup into library memory, into a caller buffer,
+and submitted asynchronously + collected -- wall time of the call / of reading its statistics / of closing it, the
+prepass and k_mesh by HIP events.  `python tools/asyncprobe.py`"""
 import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
 import numpy as np, torch
