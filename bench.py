@@ -219,6 +219,8 @@ def main():
         """W untimed + K timed steps of one job; a step is complete when its counters (N > 1: the gathered slab
         headers) are back on the host.  Returns timings, per-step kernel times, the last step's soup + statistics."""
         trace('measure %s 2^%d: %d steps, %d in flight' % (model, samples_log2, steps, depth))
+        eng.synchronize()
+        eng.trim()      # (blocks cached for the previous job's sizes would otherwise be evicted -- hipFree -- inside this job's timed steps)
         f, _ = build_model(model)
         tape = eng.tape_for(f)
         if bounds is None:

@@ -91,6 +91,8 @@ int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
  * kernel), 0 = strictly in list order.  Results are identical either way. */
 int sdf_ctx_set_tail_order(sdf_ctx *ctx, int on);
 int sdf_ctx_synchronize(sdf_ctx *ctx);
+/* give the device memory the library caches for reuse back to the driver (between jobs of very different sizes) */
+int sdf_ctx_trim(sdf_ctx *ctx);
 
 /* Upload an op tape produced by sdf_amd/tape.py (2 x uint32 per instruction, float64 constants).
  * Plays the role of the reference's closure tree (reference sdf/d3.py:48-63). */

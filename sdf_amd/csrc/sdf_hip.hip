@@ -1141,6 +1141,20 @@ int sdf_ctx_set_twopass(sdf_ctx *c, int mode) {
     return 0;
 }
 
+// hand the device memory the library keeps for reuse (blocks of destroyed meshes, soup and counter pools) back to the
+// driver: for a caller that switches to a job of a very different size -- the cached blocks of the old job do not fit the
+// new one and would be evicted one by one, each hipFree a device synchronisation in the middle of the new job's calls
+int sdf_ctx_trim(sdf_ctx *c) {
+    if (!c) return fail("sdf_ctx_trim: ctx is NULL");
+    HIPCHK(set_device(c->device));
+    HIPCHK(stream_wait(c->stream));
+    for (auto &cs : c->slots) if (cs.stream) HIPCHK(stream_wait(cs.stream));
+    for (auto &b : c->arena_pool) b.release();
+    c->arena_pool.clear();
+    g_pool.drop_device(c->device);
+    return 0;
+}
+
 int sdf_ctx_synchronize(sdf_ctx *c) {
     if (!c) return fail("sdf_ctx_synchronize: ctx is NULL");
     HIPCHK(set_device(c->device));

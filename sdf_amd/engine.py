@@ -66,6 +66,7 @@ ABI = {
     'sdf_ctx_set_twopass': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_tail_order': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_synchronize': (ctypes.c_int, [_vp]),
+    'sdf_ctx_trim': (ctypes.c_int, [_vp]),
     'sdf_tape_create': (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _f64p, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp)]),
     'sdf_tape_set_prune_info': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16),
@@ -459,6 +460,10 @@ class Engine:
 
     def synchronize(self):
         _check(self.lib, self.lib.sdf_ctx_synchronize(self.ctx))
+
+    def trim(self):
+        """return the library's cached device blocks to the driver (before a job of a very different size)"""
+        _check(self.lib, self.lib.sdf_ctx_trim(self.ctx))
 
     # -- models --
     def tape_for(self, sdf):
