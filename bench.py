@@ -47,7 +47,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARC
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 # BASELINE.json configs[2..4] at their real sizes: (model, log2 samples, triangles the reference / the golden runs give)
-OTHER_CONFIGS = [('gearlike', 30, 10204096), ('weave', 33, 53943912), ('blobby', 30, 4048520)]
+# (+ timed steps: enough of them that filling and draining the four-deep pipeline does not dominate a millisecond job)
+OTHER_CONFIGS = [('gearlike', 30, 10204096, 24), ('weave', 33, 53943912, 6), ('blobby', 30, 4048520, 24)]
 
 
 def build_model(name):
@@ -371,11 +372,9 @@ def main():
     # ---- BASELINE configs 3 - 5 at their real sizes (every rank takes part; a few steps each).  This section comes LAST
     # and, for N > 1, under a watchdog: it is the one place where a rank-local failure (an allocation that fails on one
     # rank only) would leave the other ranks inside a collective for ever, and the headline line must not depend on it ----
-    K_OTHER = 6
-
     def run_other_configs():
         others = []
-        for model, log2, want_tris in OTHER_CONFIGS:
+        for model, log2, want_tris, K_OTHER in OTHER_CONFIGS:
             trace('other config %s 2^%d' % (model, log2))
             try:
                 # (the headline's method: same steps in flight -- and, on one GPU, also one call at a time: the long two-pass

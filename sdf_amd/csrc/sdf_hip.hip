@@ -836,7 +836,9 @@ struct DevPool {
     }
     void give(void *p, size_t bytes, int device) {
         std::lock_guard<std::mutex> g(mu);
-        if (free_list.size() >= 48) {   // evict the oldest block
+        // (four calls in flight x up to twelve buffers each come back at once: a list shorter than that evicts -- hipFree, a
+        // device synchronisation -- blocks the very next call allocates again)
+        if (free_list.size() >= 160) {   // evict the oldest block
             (void)hipFree(free_list.front().p);
             free_list.erase(free_list.begin());
         }
