@@ -69,7 +69,7 @@ def main():
             continue
         p = subprocess.run([sys.executable, '-c', CHILD % dict(root=ROOT, expr=expr, prec=prec)], env=env,
                            capture_output=True, text=True)
-        m = re.findall(r'sample (\d+) count (\d+) list (\d+) emit (\d+)', p.stderr)
+        m = re.findall(r'sample (\d+) count (\d+) \(of which placing the parked batch \d+\) list (\d+) emit (\d+)', p.stderr)
         r = re.search(r'RESULT (\d+) (\d+) ([\d.]+) (\d+)', p.stdout)
         if not m or not r:
             print(name, 'FAILED', p.stderr[-400:])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU session A: new tests first, then the A/B measurements (spin wait, two-pass pipelined)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03a
 mkdir -p $O
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU session B: whole GPU suite on the new build (spin waits, device clocks, comm, sincos64), model times
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03b
 mkdir -p $O
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU session C: A/B of the fast vertex placement, instruction mix after pruning, phase profile
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03c
 mkdir -p $O
 export TMPDIR=/tmp

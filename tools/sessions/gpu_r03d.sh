@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU session D: rotation-form circular_array -- model times, then every test that touches the trig models
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03d
 mkdir -p $O
 export TMPDIR=/tmp

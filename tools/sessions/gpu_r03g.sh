@@ -2,7 +2,7 @@
 # round-3 GPU session G: whole GPU suite, the bench line, rocprofv3 profiles of the headline config (pipelined and one
 # call at a time) and of weave 2^33
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r03g
 mkdir -p $O
 export TMPDIR=/tmp
