@@ -254,3 +254,23 @@ def test_bound_method_closures_keep_their_own_instance():
     def plain(p):
         return p[:, 0]
     assert ir.extern_node(plain) is ir.extern_node(plain)
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` started plainly launches its own ranks -- after checking that N devices are visible;
+    on a box with fewer (none, here) it says so instead of starting ranks that cannot get a GPU"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SDF_BENCH_ONE_DEVICE')}
+    try:
+        import torch
+        if torch.cuda.is_available() and torch.cuda.device_count() >= 64:
+            pytest.skip('64 devices visible')
+    except ImportError:
+        pytest.skip('no torch')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'HIP device(s) visible' in (r.stderr + r.stdout)
+    # ... and a rank that finds itself in a world of another size than it was told refuses as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=dict(env, RANK='0', WORLD_SIZE='3', LOCAL_RANK='0'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=3' in (r.stderr + r.stdout)
