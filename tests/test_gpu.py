@@ -1420,30 +1420,25 @@ def test_circular_array_at_and_around_sector_boundaries(count, ns, oracle_lib, e
     """circular_array in float64 is evaluated in rotation form (csrc/sdf_interp.h L_CIRC_PREP: inline atan2, exact sector
     index, sin / cos of k * da; CIRC_SET: four products) instead of the reference's hypot / arctan2 %% da / cos, sin
     (reference sdf/d3.py:379-392).  The points where the two could part: ON the sector boundaries (angles k * da as exactly
-    as float64 has them), one ulp to a few 1e-12 rad either side, the negative x axis with y = +0 / -0 (arctan2 = +pi /
-    -pi), the axis x = y = 0, tiny and huge radii.  With a child that is symmetric about the x axis the reference's value
-    is continuous across a boundary, so whichever sector a last-bit difference of the arctangent picks, the values must
-    agree to the tolerance of the libm models; twist and bend (the other users of the inline sin / cos) ride along."""
-    rng = np.random.default_rng(count)
-    da = 2 * np.pi / count
-    ks = np.arange(-count, count + 1)
-    ang = (ks * da)[:, None] + np.array([0.0, 1e-16, -1e-16, 3e-13, -3e-13, 1e-9, -1e-9])[None, :]
-    ang = np.concatenate([ang.reshape(-1), np.nextafter(ks * da, 10.0), np.nextafter(ks * da, -10.0), rng.uniform(-np.pi, np.pi, 500)])
-    r = rng.choice([1e-9, 1e-3, 0.3, 1.0, 1.9, 2.0, 2.1, 7.0, 1e6], size=len(ang))
-    P = np.stack([r * np.cos(ang), r * np.sin(ang), rng.uniform(-0.6, 0.6, len(ang))], axis=1)
-    extra = np.array([[-1.0, 0.0, 0.1], [-1.0, -0.0, 0.1], [-2.0, 0.0, 0.0], [-2.0, -0.0, 0.0], [0.0, 0.0, 0.2], [-0.0, 0.0, 0.2],
-                      [0.0, -0.0, 0.2], [-0.0, -0.0, 0.2], [2.0, 0.0, 0.0], [2.0, -0.0, 0.0], [0.0, 2.0, 0.0], [0.0, -2.0, 0.0],
-                      [1e-300, 1e-300, 0.0], [-1e-300, 1e-300, 0.0], [1e150, -1e150, 0.0]])
-    P = np.ascontiguousarray(np.concatenate([P, extra]))
-    for f in (ns['cylinder'](0.25).circular_array(count, 2),
-              ns['sphere'](0.3).circular_array(count, 1.5) | ns['box']((0.2, 0.1, 0.4)).circular_array(count, 0.7),
-              ns['rounded_box']((0.6, 0.2, 0.2), 0.05).circular_array(count, 1.0).twist(0.4),
-              ns['capsule'](-ns['X'], ns['X'], 0.1).circular_array(count, 0.5).bend(0.3)):
+    as float64 has them), one ulp to 1e-9 rad either side, the negative x axis with y = +0 / -0 (arctan2 = +pi / -pi), the
+    axis x = y = 0, tiny and huge radii -- tests/golden/circ_boundaries.npz, produced by RUNNING the reference on them
+    (tools/make_golden_circ.py).  The children are symmetric about the x axis, so the reference's value is continuous across
+    a boundary: whichever sector a last-bit difference of the arctangent picks, the values must agree to the tolerance of
+    the libm models -- with the reference AND with the checker; twist and bend (the other users of the inline sin / cos)
+    ride along."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import make_golden_circ as mgc
+    g = np.load(os.path.join(GOLDEN, 'circ_boundaries.npz'))
+    P = g['P_%d' % count]
+    for i, f in enumerate(mgc.models(ns, count)):
         v = eng.eval_points(f, P)
+        ref = g['v_%d_%d' % (count, i)]
         o = oracle_lib.evaluate(f, P)
-        ok = np.isfinite(o)
+        ok = np.isfinite(ref)
         assert np.array_equal(np.isfinite(v), ok)
-        assert np.all(np.abs(v[ok] - o[ok]) <= value_tolerance(o[ok], P[ok])), float(np.max(np.abs(v[ok] - o[ok]) / value_tolerance(o[ok], P[ok])))
+        for want in (ref, o):
+            assert np.all(np.abs(v[ok] - want[ok]) <= value_tolerance(want[ok], P[ok])), (i, float(np.max(np.abs(v[ok] - want[ok]) / value_tolerance(want[ok], P[ok]))))
 
 
 def _native_exchange_worker(rank, world, port, q, mock, skip_shard, first_cap):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import fixtures
-from conftest import GOLDEN, value_tolerance
+from conftest import GOLDEN, ROOT, value_tolerance
 from sdf_amd import core
 
 
@@ -125,3 +125,23 @@ def test_image_leaf_matches_reference(name, ns, oracle_lib):
     r = oracle_lib.generate(g, X, Y, Z, 32, True)
     assert len(r.points) // 3 == int(TEX['gen_ntri_' + name])
     assert hashlib.sha256(r.points.tobytes()).digest() == TEX['gen_sha_' + name].tobytes()
+
+
+def test_oracle_matches_reference_on_circular_array_boundaries(ns, oracle_lib):
+    """tests/golden/circ_boundaries.npz (tools/make_golden_circ.py: the unmodified reference on points ON the sector
+    boundaries of circular_array, ulps to 1e-9 rad beside them, the negative x axis with +-0, the axis, tiny and huge
+    radii; children symmetric about the x axis, with twist / bend around): the checker agrees to the tolerance of the
+    libm models (NumPy's sin / cos / arctan2 vs glibc's)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import make_golden_circ as mgc
+    from conftest import value_tolerance
+    g = np.load(os.path.join(GOLDEN, 'circ_boundaries.npz'))
+    for count in mgc.COUNTS:
+        P = g['P_%d' % count]
+        for i, f in enumerate(mgc.models(ns, count)):
+            ref = g['v_%d_%d' % (count, i)]
+            o = oracle_lib.evaluate(f, P)
+            ok = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(o), ok)
+            assert np.all(np.abs(o[ok] - ref[ok]) <= value_tolerance(ref[ok], P[ok])), (count, i)
