@@ -7,8 +7,11 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-# -structurizecfg-skip-uniform-regions: every branch of the interpreter is wave-uniform; without it
-# the backend structurises the dispatch tree anyway and pays ~100 register copies per tape instruction
+# -structurizecfg-skip-uniform-regions: every branch of the tape interpreter is wave-uniform and its dispatch is a
+# scalar jump through a table (asm goto + s_setpc, sdf_interp.h); the structurizer has to leave that alone -- a build of
+# the interpreters WITHOUT the option faults on the device.  The option is NOT safe for kernels whose lanes diverge
+# (r03: it miscompiled k_expand), so only the interpreters' translation units get it and every other kernel lives in
+# sdf_plain.hip / sdf_weld.hip.
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -mllvm -structurizecfg-skip-uniform-regions=1"
 mkdir -p build
 rm -f libsdf_hip.so build/*.o
@@ -18,8 +21,10 @@ $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f64 -c -
 $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f64_full -c -o build/mesh_f64_full.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=float -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f32 -c -o build/mesh_f32.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=float -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f32_full -c -o build/mesh_f32_full.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
+# (every kernel that is not a tape interpreter: built WITHOUT the structurizer option, see sdf_plain.hip)
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -c -o build/sdf_plain.o sdf_plain.hip "$@" & pids="$pids $!"
 # (the weld uses hipCUB's radix sort and scan; it has no floating-point arithmetic of its own)
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c -o build/sdf_weld.o sdf_weld.hip "$@" & pids="$pids $!"
 for p in $pids; do wait $p; done
 exec $HIPCC --offload-arch=gfx950 -fPIC -shared -o libsdf_hip.so build/sdf_hip.o build/mesh_f64.o build/mesh_f64_full.o \
-    build/mesh_f32.o build/mesh_f32_full.o build/sdf_weld.o
+    build/mesh_f32.o build/mesh_f32_full.o build/sdf_weld.o build/sdf_plain.o

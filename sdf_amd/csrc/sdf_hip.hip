@@ -1,4 +1,6 @@
-// sdf_hip.hip -- kernels + C ABI of libsdf_hip.so (gfx950 only).
+// sdf_hip.hip -- the tape-interpreter kernels (k_eval_*, k_estimate_bounds, k_skip, k_prune_list, k_cull) + the C ABI of
+// libsdf_hip.so (gfx950 only).  k_mesh is instantiated in sdf_mesh_inst.hip; every kernel that is not an interpreter
+// (k_compact, k_scan_items, k_emit2, k_pack_slab, k_expand, k_mc_*, k_field_*, k_cast_f32, k_stl) in sdf_plain.hip.
 //
 // Kernels (one call of sdf_generate enqueues k_skip -> k_compact [-> k_prune_list] -> k_cull -> k_mesh
 // [-> k_scan_items -> k_emit2] on one stream, without a host round trip in between)
@@ -42,6 +44,8 @@
 #include "mc_table.h"
 #include "sdf_device.h"
 #include "sdf_prune.h"
+#include "sdf_slab.h"
+#include "sdf_plain.h"
 
 using namespace sdfk;
 
@@ -323,439 +327,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
 }
 
-// ordered compaction of the pending batches into the work list (single workgroup)
-// (also clears the look-back words and the counters of the meshing pass that follows, so the
-// common path needs no memset launches)
-__global__ __launch_bounds__(1024) void k_compact(const unsigned char *__restrict__ kinds, int nbatches,
-                                                  int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
-                                                  unsigned long long *__restrict__ status,
-                                                  long long shard_index, long long shard_count) {
-    __shared__ int wave_sums[16];
-    int base = 0;
-    for (int start = 0; start < nbatches; start += 1024) {
-        const int b = start + threadIdx.x;
-        if (b < nbatches) status[b] = 0ull;
-        const int f = (b < nbatches && kinds[b] != 0) ? 1 : 0;
-        int tot;
-        const int pos = block_exclusive_scan<1024>(f, wave_sums, tot);
-        if (f) worklist[base + pos] = b;
-        base += tot;
-    }
-    if (threadIdx.x == 0) {   // contiguous chunk of the work list for this shard (same formula as sdf_amd/dist.py)
-        MeshCounters z = {};
-        *ctr = z;
-        ctr->nwork = base;
-        ctr->work_begin = (int)(((long long)base * shard_index) / shard_count);
-        ctr->work_end = (int)(((long long)base * (shard_index + 1)) / shard_count);
-    }
-}
-
-// ---- marching cubes of a caller-supplied volume -------------------------------------------
-__global__ __launch_bounds__(256) void k_mc_rows(const McTables *__restrict__ mc, const float *__restrict__ vol, int n0, int n1, int n2,
-                                                 unsigned int *__restrict__ row_count) {
-    const int c1 = n1 - 1, c2 = n2 - 1;
-    const long long nrows = (long long)(n0 - 1) * c1;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nrows) return;
-    const int i0 = (int)(t / c1), i1 = (int)(t - (long long)i0 * c1);
-    const int s0 = n1 * n2, s1 = n2;
-    const float *row = vol + (long long)i0 * s0 + (long long)i1 * s1;
-    unsigned prev = plane_bits(row, s0, s1);
-    unsigned cnt = 0;
-    for (int i2 = 0; i2 < c2; i2++) {
-        const unsigned next = plane_bits(row + i2 + 1, s0, s1);
-        const unsigned cfg = spread4(prev) | (spread4(next) << 1);
-        if (mc->amb[cfg]) {
-            double lv[8];
-            int off;
-            mc33_load_cell(row + i2, s0, s1, lv);
-            cnt += (unsigned)mc33_cell(lv, mc->mc33, &off);
-        } else {
-            cnt += mc->ntri[cfg];
-        }
-        prev = next;
-    }
-    row_count[t] = cnt;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_rows(const unsigned int *__restrict__ cnt, long long n,
-                                                    unsigned long long *__restrict__ off, unsigned long long *total) {
-    __shared__ int wave_sums[16];
-    unsigned long long base = 0;
-    for (long long start = 0; start < n; start += 1024) {
-        const long long i = start + threadIdx.x;
-        const int v = i < n ? (int)cnt[i] : 0;
-        int tot;
-        const int pos = block_exclusive_scan<1024>(v, wave_sums, tot);
-        if (i < n) off[i] = base + (unsigned long long)pos;
-        base += (unsigned long long)tot;
-    }
-    if (threadIdx.x == 0) *total = base;
-}
-
-__global__ __launch_bounds__(256) void k_mc_emit(const McTables *__restrict__ mc, const float *__restrict__ vol, int n0, int n1, int n2,
-                                                 const unsigned long long *__restrict__ row_off, float *__restrict__ out,
-                                                 unsigned long long cap) {
-    const int c1 = n1 - 1, c2 = n2 - 1;
-    const long long nrows = (long long)(n0 - 1) * c1;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nrows) return;
-    const int i0 = (int)(t / c1), i1 = (int)(t - (long long)i0 * c1);
-    const int s0 = n1 * n2, s1 = n2;
-    const float *row = vol + (long long)i0 * s0 + (long long)i1 * s1;
-    unsigned long long k = row_off[t];
-    unsigned prev = plane_bits(row, s0, s1);
-    for (int i2 = 0; i2 < c2; i2++) {
-        const unsigned next = plane_bits(row + i2 + 1, s0, s1);
-        const unsigned cfg = spread4(prev) | (spread4(next) << 1);
-        prev = next;
-        if (mc->amb[cfg]) {
-            double lv[8];
-            int off;
-            mc33_load_cell(row + i2, s0, s1, lv);
-            const int nt = mc33_cell(lv, mc->mc33, &off);
-            for (int j = 0; j < nt; j++, k++) {
-                if (k >= cap) return;
-                mc33_triangle(row + i2, s0, s1, i0, i1, i2, mc->mc33, j, out + k * 9ull);
-            }
-            continue;
-        }
-        const int nt = mc->ntri[cfg];
-        for (int j = 0; j < nt; j++, k++) {
-            if (k >= cap) return;
-            for (int q = 0; q < 3; q++) mc_vertex(row + i2, s0, s1, i0, i1, i2, mc->tri[cfg][3 * j + q], out + k * 9ull + q * 3);
-        }
-    }
-}
-
-// ---- marching cubes of MANY caller-supplied tiles in one submission (sdf_generate_field: the volumes of a
-// chunk of batches sampled by a host callback).  A tile has at most 32 x 32 rows of cells; row slot
-// tile * 1024 + t carries the row's triangle count (0 beyond the tile's rows), so one scan over the slots
-// numbers the triangles of the whole chunk in reference order. ----
-struct FieldTile {
-    long long vol_off;      // first sample of the tile in the chunk's value buffer
-    int n0, n1, n2, pad_;
-    double of[3], sc[3];    // points * scale + offset (reference sdf/core.py:58-60)
-};
-
-__global__ __launch_bounds__(256) void k_cast_f32(const double *__restrict__ in, float *__restrict__ out, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (float)in[i];     // volume.astype(float32) inside skimage
-}
-
-__device__ __forceinline__ unsigned mc_row_count(const McTables *__restrict__ mc, const float *__restrict__ row, int s0, int s1, int c2) {
-    unsigned prev = plane_bits(row, s0, s1);
-    unsigned cnt = 0;
-    for (int i2 = 0; i2 < c2; i2++) {
-        const unsigned next = plane_bits(row + i2 + 1, s0, s1);
-        const unsigned cfg = spread4(prev) | (spread4(next) << 1);
-        if (mc->amb[cfg]) {
-            double lv[8];
-            int off;
-            mc33_load_cell(row + i2, s0, s1, lv);
-            cnt += (unsigned)mc33_cell(lv, mc->mc33, &off);
-        } else {
-            cnt += mc->ntri[cfg];
-        }
-        prev = next;
-    }
-    return cnt;
-}
-
-__global__ __launch_bounds__(256) void k_field_rows(const McTables *__restrict__ mc, const float *__restrict__ vol,
-                                                    const FieldTile *__restrict__ tiles, unsigned int *__restrict__ row_count) {
-    const FieldTile tl = tiles[blockIdx.y];
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);        // row slot 0..1023
-    const int c0 = tl.n0 - 1, c1 = tl.n1 - 1, c2 = tl.n2 - 1;
-    unsigned cnt = 0;
-    if (c0 > 0 && c1 > 0 && c2 > 0 && t < c0 * c1) {
-        const int i0 = t / c1, i1 = t - i0 * c1;
-        const int s0 = tl.n1 * tl.n2, s1 = tl.n2;
-        cnt = mc_row_count(mc, vol + tl.vol_off + (long long)i0 * s0 + (long long)i1 * s1, s0, s1, c2);
-    }
-    row_count[(size_t)blockIdx.y * 1024 + t] = cnt;
-}
-
-__global__ __launch_bounds__(256) void k_field_emit(const McTables *__restrict__ mc, const float *__restrict__ vol,
-                                                    const FieldTile *__restrict__ tiles, const unsigned long long *__restrict__ row_off,
-                                                    double *__restrict__ out, unsigned long long base, unsigned long long cap) {
-    const FieldTile tl = tiles[blockIdx.y];
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int c0 = tl.n0 - 1, c1 = tl.n1 - 1, c2 = tl.n2 - 1;
-    if (c0 <= 0 || c1 <= 0 || c2 <= 0 || t >= c0 * c1) return;
-    const int i0 = t / c1, i1 = t - i0 * c1;
-    const int s0 = tl.n1 * tl.n2, s1 = tl.n2;
-    const float *row = vol + tl.vol_off + (long long)i0 * s0 + (long long)i1 * s1;
-    unsigned long long k = base + row_off[(size_t)blockIdx.y * 1024 + t];
-    unsigned prev = plane_bits(row, s0, s1);
-    for (int i2 = 0; i2 < c2; i2++) {
-        const unsigned next = plane_bits(row + i2 + 1, s0, s1);
-        const unsigned cfg = spread4(prev) | (spread4(next) << 1);
-        prev = next;
-        int nt = mc->ntri[cfg];
-        const bool amb = mc->amb[cfg] != 0;
-        if (amb) {
-            double lv[8];
-            int off;
-            mc33_load_cell(row + i2, s0, s1, lv);
-            nt = mc33_cell(lv, mc->mc33, &off);
-        }
-        for (int j = 0; j < nt; j++, k++) {
-            if (k >= cap) return;
-            float o[9];
-            if (amb) mc33_triangle(row + i2, s0, s1, i0, i1, i2, mc->mc33, j, o);
-            else for (int q = 0; q < 3; q++) mc_vertex(row + i2, s0, s1, i0, i1, i2, mc->tri[cfg][3 * j + q], o + q * 3);
-            double *d = out + k * 9ull;
-            for (int q = 0; q < 9; q += 3) {
-                d[q] = (double)o[q] * tl.sc[0] + tl.of[0];
-                d[q + 1] = (double)o[q + 1] * tl.sc[1] + tl.of[1];
-                d[q + 2] = (double)o[q + 2] * tl.sc[2] + tl.of[2];
-            }
-        }
-    }
-}
-
-// ---- two-pass meshing: the second and third kernel (the first is k_mesh with MeshArgs.twopass) ----
-// k_scan_items: the work items' triangle counts -> their inclusive prefix in work-list (= reference) order, written as
-// the same look-back words the one-pass kernel leaves (sdf_mesh_batch_offsets, k_pack_slab read them), and the total.
-__global__ __launch_bounds__(1024) void k_scan_items(const ItemDesc *__restrict__ desc, MeshCounters *__restrict__ ctr,
-                                                     unsigned long long *__restrict__ status, int *__restrict__ block_item,
-                                                     unsigned long long n_blocks) {
-    __shared__ int wave_sums[16];
-    const int w_begin = ctr->work_begin, w_end = ctr->work_end;
-    unsigned long long base = 0;
-    for (int start = w_begin; start < w_end; start += 1024) {
-        const int w = start + (int)threadIdx.x;
-        const int v = w < w_end ? (int)desc[w].ntri : 0;
-        int tot;
-        const int pos = block_exclusive_scan<1024>(v, wave_sums, tot);
-        if (w < w_end) {
-            const unsigned long long first = base + (unsigned long long)pos, end = first + (unsigned long long)v;
-            status[w] = MESH_FLAG_PFX | end;
-            // block_item[b] = the work item that owns triangle 256 b (k_emit2 starts its search there instead of at the
-            // ends of the list: fifteen dependent loads less per workgroup at weave 2^33)
-            for (unsigned long long b = (first + 255ull) >> 8; (b << 8) < end && b < n_blocks; b++) block_item[b] = w;
-        }
-        base += (unsigned long long)tot;
-    }
-    if (threadIdx.x == 0) ctr->total = base;
-}
-
-// k_emit2: one lane per TRIANGLE of the whole soup (256 consecutive triangles per workgroup, whatever work items they
-// belong to): find the triangle's work item in the prefix (binary search over the look-back words, L1-resident), fetch
-// its entry and its cell's record, run the three edge interpolations on the record's 8 corner samples (mc_vertex /
-// mc33_triangle -- the very functions the one-pass kernel runs on its LDS tile, with the strides of a 2 x 2 x 2 volume),
-// pass the 9 local coordinates through LDS so that consecutive lanes store consecutive coordinates, and write
-// `points * scale + offset` (reference sdf/core.py:58-60) of the triangle's own work item -- or, for the multi-GPU
-// exchange, the local float32 form -- straight to the final place.  The grid covers the soup's CAPACITY (the host does
-// not know the count); workgroups beyond the total leave at once.
-__global__ __launch_bounds__(256) void k_emit2(MeshArgs a) {
-    __shared__ float tri[256 * 9];
-    __shared__ unsigned recs[256 * 9];
-    __shared__ int item_of[256];
-    const unsigned long long total = a.ctr->total;
-    const unsigned long long T0 = (unsigned long long)blockIdx.x * 256ull;
-    if (T0 >= total) return;
-    if (total > a.out_cap || (a.ctr->overflow & 1u)) {       // the soup or the arenas were too small: flagged, the call is repeated
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&a.ctr->overflow, 1u);
-        return;
-    }
-    __shared__ int w_range[2];
-    const int tid = threadIdx.x;
-    const int nt = (int)min(256ull, total - T0);
-    const int w_begin = a.ctr->work_begin, w_end = a.ctr->work_end;
-    // the work item of a triangle T: the smallest w whose inclusive prefix exceeds T.  The workgroup's 256 consecutive
-    // triangles span one or two items as a rule: two lanes search the whole prefix (for the first and the last
-    // triangle), everybody else only between their answers
-    if (tid < 2) {
-        const unsigned long long T = tid == 0 ? T0 : T0 + (unsigned long long)(nt - 1);
-        // (k_scan_items' index: the owner of this block's first triangle, and of the next block's -- which is the
-        // last item this block can touch -- bracket the search)
-        int lo = a.block_item ? a.block_item[blockIdx.x] : w_begin, hi = w_end - 1;
-        if (a.block_item && T0 + 256ull < total) hi = a.block_item[blockIdx.x + 1];
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((a.status[mid] & MESH_VAL_MASK) > T) hi = mid; else lo = mid + 1;
-        }
-        w_range[tid] = lo;
-    }
-    __syncthreads();
-    if (tid < nt) {
-        const unsigned long long T = T0 + (unsigned long long)tid;
-        int lo = w_range[0], hi = w_range[1];
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((a.status[mid] & MESH_VAL_MASK) > T) hi = mid; else lo = mid + 1;
-        }
-        const int w = lo;
-        const ItemDesc *d = a.desc + w;
-        const unsigned ntri = d->ntri;
-        const unsigned long long t = T - ((a.status[w] & MESH_VAL_MASK) - ntri);
-        const unsigned e = a.tlist[d->list_off + t];
-        const unsigned *src = a.cells + (d->cell_off + (unsigned long long)(e >> 4)) * 9ull;
-        unsigned *rec = recs + tid * 9;
-        for (int q = 0; q < 9; q++) rec[q] = src[q];
-        const unsigned info = rec[0];
-        const int j = (int)(e & 15u), cfg = (int)((info >> 4) & 255u), cell = (int)(info >> 13);
-        const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
-        const float *corner = reinterpret_cast<const float *>(rec + 1);          // 2 x 2 x 2 samples: strides 4, 2, 1
-        float *o = tri + tid * 9;
-        if (info & 4096u) {
-            float tmp[9];
-            mc33_triangle(corner, 4, 2, i0, i1, i2, a.mc->mc33, j, tmp);
-            for (int q = 0; q < 9; q++) o[q] = tmp[q];
-        } else {
-            const signed char *tt = &a.mc->tri[0][0] + cfg * 16 + 3 * j;
-            float v[3];
-            for (int q = 0; q < 3; q++) { mc_vertex(corner, 4, 2, i0, i1, i2, tt[q], v); o[3 * q] = v[0]; o[3 * q + 1] = v[1]; o[3 * q + 2] = v[2]; }
-        }
-        item_of[tid] = w;
-    }
-    __syncthreads();
-    const int n9 = nt * 9;
-    const unsigned long long at = T0 * 9ull;                  // (a multiple of 9: coordinate e of the workgroup belongs to axis e % 3)
-    if (a.compact) {
-        float *dst = reinterpret_cast<float *>(a.out) + at;
-        for (int e = tid; e < n9; e += 256) dst[e] = tri[e];
-    } else {
-        double *dst = a.out + at;
-        for (int e = tid; e < n9; e += 256) {
-            const double *xf = a.desc[item_of[e / 9]].xf;
-            const int ax = e % 3;
-            dst[e] = (double)tri[e] * xf[3 + ax] + xf[ax];
-        }
-    }
-}
-
-// ---- the multi-GPU exchange unit ("slab"): what one rank contributes to the all-gather (sdf_amd/dist.py) ----
-// [header 128 B | prefix[cap_items] u64 | xf[cap_items][6] f64 | tris[cap_tris][9] f32], a fixed capacity per call so
-// that ONE all-gather of equal-sized slabs moves everything: the counts travel in the header, the triangles in
-// marching cubes' own local float32 form (36 B instead of the 72 B of the float64 soup), the per-batch transforms
-// next to them.  k_expand turns the gathered slabs into the ordered float64 soup on every rank.
-struct SlabHeader {
-    long long n_tris, n_items, overflow, n_empty, n_nonempty, n_eval, n_ambiguous, n_sampled, n_pruned, n_work_total;
-    long long pad_[6];
-};
-static_assert(sizeof(SlabHeader) == 128, "slab header");
-struct SlabLayout {
-    size_t prefix_off, xf_off, tris_off, bytes;
-    __host__ __device__ SlabLayout(long long cap_items, long long cap_tris) {
-        prefix_off = 128;
-        xf_off = prefix_off + (size_t)cap_items * 8;
-        tris_off = (xf_off + (size_t)cap_items * 48 + 15) & ~(size_t)15;
-        bytes = (tris_off + (size_t)cap_tris * 36 + 255) & ~(size_t)255;
-    }
-};
-
-// header + the shard's look-back words (inclusive triangle prefix per work item) into the slab, behind k_mesh
-__global__ __launch_bounds__(256) void k_pack_slab(const MeshCounters *__restrict__ ctr, const unsigned long long *__restrict__ status,
-                                                   unsigned char *__restrict__ slab, long long cap_items, long long cap_tris) {
-    const SlabLayout L(cap_items, cap_tris);
-    const long long n_items = (long long)ctr->work_end - ctr->work_begin;
-    unsigned long long *prefix = reinterpret_cast<unsigned long long *>(slab + L.prefix_off);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_items && i < cap_items; i += (long long)gridDim.x * blockDim.x)
-        prefix[i] = status[ctr->work_begin + i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        SlabHeader h = {};
-        h.n_tris = (long long)ctr->total; h.n_items = n_items;
-        h.overflow = (long long)ctr->overflow | (n_items > cap_items ? 4 : 0) | ((long long)ctr->total > cap_tris ? 1 : 0);
-        h.n_empty = ctr->n_empty; h.n_nonempty = ctr->n_nonempty; h.n_eval = (long long)ctr->n_eval;
-        h.n_ambiguous = (long long)ctr->n_ambiguous; h.n_sampled = (long long)ctr->n_sampled; h.n_pruned = (long long)ctr->n_pruned;
-        h.n_work_total = ctr->nwork;
-        *reinterpret_cast<SlabHeader *>(slab) = h;
-    }
-}
-
-// gathered slabs (in final order) -> the ordered float64 soup: `points * scale + offset` (reference sdf/core.py:58-60)
-// per work item; a workgroup per (slab, work item), consecutive lanes = consecutive coordinates
-struct SlabPtrs { const unsigned char *p[64]; };
-__global__ __launch_bounds__(256) void k_expand(SlabPtrs slabs, int n_slabs, long long cap_items, long long cap_tris,
-                                                double *__restrict__ out, unsigned long long cap_out) {
-    const SlabLayout L(cap_items, cap_tris);
-    const int sidx = blockIdx.y;
-    unsigned long long base = 0;
-    for (int q = 0; q < sidx; q++) {
-        const long long n = reinterpret_cast<const SlabHeader *>(slabs.p[q])->n_tris;
-        base += (unsigned long long)(n < 0 ? 0 : (n > cap_tris ? cap_tris : n));
-    }
-    const unsigned char *slab = slabs.p[sidx];
-    const SlabHeader *h = reinterpret_cast<const SlabHeader *>(slab);
-    const long long n_items = h->n_items < cap_items ? h->n_items : cap_items;
-    const unsigned long long *prefix = reinterpret_cast<const unsigned long long *>(slab + L.prefix_off);
-    const double *xf = reinterpret_cast<const double *>(slab + L.xf_off);
-    const float *tris = reinterpret_cast<const float *>(slab + L.tris_off);
-    for (long long i = blockIdx.x; i < n_items; i += gridDim.x) {
-        const unsigned long long w1 = prefix[i], w0 = i ? prefix[i - 1] : MESH_FLAG_PFX;
-        if ((w1 >> 62) != 2ull || (w0 >> 62) != 2ull) continue;             // (an incomplete pass: flagged in the header)
-        unsigned long long t0 = w0 & MESH_VAL_MASK, t1 = w1 & MESH_VAL_MASK;
-        if (t1 > (unsigned long long)cap_tris) t1 = (unsigned long long)cap_tris;
-        if (t0 >= t1) continue;
-        const double of[3] = {xf[i * 6], xf[i * 6 + 1], xf[i * 6 + 2]}, sc[3] = {xf[i * 6 + 3], xf[i * 6 + 4], xf[i * 6 + 5]};
-        // four coordinates per lane and pass (16-byte loads of the floats, 16-byte stores of the doubles), two passes'
-        // loads in flight before the first store; a work item's range starts at a multiple of 9 coordinates, so the
-        // axis of coordinate e is e % 3 whatever the item
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-        const unsigned long long e_begin = t0 * 9ull, e1 = t1 * 9ull, lim = cap_out * 9ull;
-        for (unsigned long long e0 = e_begin + 4ull * threadIdx.x; e0 < e1; e0 += 2048) {
-            f4u f[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const unsigned long long e = e0 + 1024ull * k;
-                if (e + 3 < e1) f[k] = *reinterpret_cast<const f4u *>(tris + e);
-                else { f[k] = f4u{0.0f, 0.0f, 0.0f, 0.0f}; for (int j = 0; j < 3; j++) if (e + j < e1) f[k][j] = tris[e + j]; }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const unsigned long long e = e0 + 1024ull * k;
-                if (e >= e1) break;
-                const int ax = (int)(e % 3ull);        // axes of e .. e + 3: ax, ax + 1, ax + 2, ax (mod 3)
-                const double s0 = ax == 0 ? sc[0] : (ax == 1 ? sc[1] : sc[2]), o0 = ax == 0 ? of[0] : (ax == 1 ? of[1] : of[2]);
-                const double s1 = ax == 0 ? sc[1] : (ax == 1 ? sc[2] : sc[0]), o1 = ax == 0 ? of[1] : (ax == 1 ? of[2] : of[0]);
-                const double s2 = ax == 0 ? sc[2] : (ax == 1 ? sc[0] : sc[1]), o2 = ax == 0 ? of[2] : (ax == 1 ? of[0] : of[1]);
-                const double v0 = (double)f[k][0] * s0 + o0, v1 = (double)f[k][1] * s1 + o1, v2 = (double)f[k][2] * s2 + o2, v3 = (double)f[k][3] * s0 + o0;
-                const unsigned long long o = base * 9ull + e;
-                if (e + 3 < e1 && o + 3 < lim) {
-                    *reinterpret_cast<d2u *>(out + o) = d2u{v0, v1};
-                    *reinterpret_cast<d2u *>(out + o + 2) = d2u{v2, v3};
-                } else {
-                    if (o < lim) out[o] = v0;
-                    if (e + 1 < e1 && o + 1 < lim) out[o + 1] = v1;
-                    if (e + 2 < e1 && o + 2 < lim) out[o + 2] = v2;
-                    if (e + 3 < e1 && o + 3 < lim) out[o + 3] = v3;
-                }
-            }
-        }
-    }
-}
-
-// ---- STL records (reference sdf/stl.py:4-24): float32 vertices, normal = normalised cross ----
-__global__ __launch_bounds__(256) void k_stl(const double *__restrict__ pts, long long ntri, unsigned short *__restrict__ out) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntri) return;
-    float p[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) p[i] = (float)pts[t * 9 + i];
-    const float ax = p[3] - p[0], ay = p[4] - p[1], az = p[5] - p[2];
-    const float bx = p[6] - p[0], by = p[7] - p[1], bz = p[8] - p[2];
-    // np.cross / np.linalg.norm in float32: separate, individually rounded products, sums and the
-    // quotient (the translation unit is built with -ffp-contract=off; sqrtf and '/' are the
-    // correctly rounded forms, the __f*_rn intrinsics map to native approximations here)
-    float nx = ay * bz - az * by;
-    float ny = az * bx - ax * bz;
-    float nz = ax * by - ay * bx;
-    const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
-    nx = nx / len; ny = ny / len; nz = nz / len;
-    float rec[12] = {nx, ny, nz, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
-    unsigned short *o = out + t * 25;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        const unsigned u = __float_as_uint(rec[i]);
-        o[2 * i] = (unsigned short)(u & 0xFFFFu);
-        o[2 * i + 1] = (unsigned short)(u >> 16);
-    }
-    o[24] = 0;
-}
+// (every kernel that is not a tape interpreter -- the compaction, marching cubes of caller-supplied volumes, the two-pass
+// meshing's scan and emission, the slab kernels, the STL records -- lives in sdf_plain.hip: see build.sh for why)
 
 // ============================================================================================
 // host side: the C ABI
@@ -1388,8 +961,8 @@ int sdf_marching_cubes(sdf_ctx *c, const void *d_volume, int n0, int n1, int n2,
     if (c->rows.ensure((size_t)nrows * 4) || c->rows_off.ensure((size_t)(nrows + 1) * 8)) return 1;
     unsigned long long *d_total = (unsigned long long *)c->rows_off.p + nrows;
     const unsigned grid = (unsigned)((nrows + 255) / 256);
-    hipLaunchKernelGGL(k_mc_rows, dim3(grid), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)d_volume, n0, n1, n2, (unsigned *)c->rows.p);
-    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)c->rows.p, nrows,
+    launch_k_mc_rows(dim3(grid), dim3(256), c->stream, (const McTables *)c->mc.p, (const float *)d_volume, n0, n1, n2, (unsigned *)c->rows.p);
+    launch_k_scan_rows(dim3(1), dim3(1024), c->stream, (const unsigned *)c->rows.p, nrows,
                        (unsigned long long *)c->rows_off.p, d_total);
     HIPCHK(hipGetLastError());
     unsigned long long total = 0;
@@ -1397,7 +970,7 @@ int sdf_marching_cubes(sdf_ctx *c, const void *d_volume, int n0, int n1, int n2,
     HIPCHK(stream_wait(c->stream));
     *n_tris = (int64_t)total;
     if (total && d_out && cap > 0) {
-        hipLaunchKernelGGL(k_mc_emit, dim3(grid), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)d_volume, n0, n1, n2,
+        launch_k_mc_emit(dim3(grid), dim3(256), c->stream, (const McTables *)c->mc.p, (const float *)d_volume, n0, n1, n2,
                            (const unsigned long long *)c->rows_off.p, (float *)d_out, (unsigned long long)cap);
         HIPCHK(hipGetLastError());
         HIPCHK(stream_wait(c->stream));
@@ -1617,7 +1190,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     }
     if (!sparse) HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, st));
     else if (d_kinds_in) HIPCHK(hipMemcpyAsync(m->kinds.p, d_kinds_in, (size_t)nb, hipMemcpyDeviceToDevice, st));   // (k_mesh writes its verdicts into the mesh's own copy)
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
+    launch_k_compact(dim3(1), dim3(1024), st, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p,
                        (MeshCounters *)m->counters.p, (unsigned long long *)m->status.p, (long long)shard_index,
                        (long long)shard_count);
     HIPCHK(hipGetLastError());
@@ -1766,17 +1339,16 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (a.twopass) {
             const unsigned long long emit_blocks = (a.out_cap + 255ull) / 256ull;
             if (emit_blocks > 0x7fffffffull) return fail("sdf_generate: soup capacity too large for one k_emit2 launch");
-            hipLaunchKernelGGL(k_scan_items, dim3(1), dim3(1024), 0, st, (const ItemDesc *)m->desc.p, (MeshCounters *)m->counters.p,
+            launch_k_scan_items(dim3(1), dim3(1024), st, (const ItemDesc *)m->desc.p, (MeshCounters *)m->counters.p,
                                (unsigned long long *)m->status.p, (int *)m->blockidx.p, emit_blocks + 1ull);
-            hipLaunchKernelGGL(k_emit2, dim3((unsigned)std::max<unsigned long long>(emit_blocks, 1ull)), dim3(256), 0, st, a);
+            launch_k_emit2(dim3((unsigned)std::max<unsigned long long>(emit_blocks, 1ull)), dim3(256), st, a);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(cs.e4, st));
         if (compact) {
             const unsigned pack_blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((slab_items + 255) / 256, 1), 1024);
-            hipLaunchKernelGGL(k_pack_slab, dim3(pack_blocks), dim3(256), 0, st, (const MeshCounters *)m->counters.p,
-                               (const unsigned long long *)m->status.p, (unsigned char *)d_out, (long long)slab_items, (long long)cap_out);
-            HIPCHK(hipGetLastError());
+            HIPCHK((hipError_t)sdf_launch_pack_slab(pack_blocks, st, (const MeshCounters *)m->counters.p, (const unsigned long long *)m->status.p,
+                                                    (unsigned char *)d_out, (long long)slab_items, (long long)cap_out));
         }
         MeshCounters *hp = (MeshCounters *)(stage + SDF_STAGE_BYTES - 256);   // pinned
         HIPCHK(hipMemcpyAsync(hp, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -2004,12 +1576,12 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
             return 1;
         HIPCHK(hipMemcpyAsync(c->field_vals.p, vals, npts * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->field_tiles.p, tiles.data(), sizeof(FieldTile) * (size_t)nt, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_cast_f32, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->field_vals.p,
+        launch_k_cast_f32(dim3((unsigned)((npts + 255) / 256)), dim3(256), c->stream, (const double *)c->field_vals.p,
                            (float *)c->field_vol.p, (long long)npts);
-        hipLaunchKernelGGL(k_field_rows, dim3(4, (unsigned)nt), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
+        launch_k_field_rows(dim3(4, (unsigned)nt), dim3(256), c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
                            (const FieldTile *)c->field_tiles.p, (unsigned *)c->rows.p);
         unsigned long long *d_total = (unsigned long long *)c->rows_off.p + nslots;
-        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, c->stream, (const unsigned *)c->rows.p, (long long)nslots,
+        launch_k_scan_rows(dim3(1), dim3(1024), c->stream, (const unsigned *)c->rows.p, (long long)nslots,
                            (unsigned long long *)c->rows_off.p, d_total);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(offs.data(), c->rows_off.p, (nslots + 1) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -2029,7 +1601,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
                 m->out.release();
                 m->out = bigger;
             }
-            hipLaunchKernelGGL(k_field_emit, dim3(4, (unsigned)nt), dim3(256), 0, c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
+            launch_k_field_emit(dim3(4, (unsigned)nt), dim3(256), c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
                                (const FieldTile *)c->field_tiles.p, (const unsigned long long *)c->rows_off.p, (double *)m->out.p, total,
                                (unsigned long long)(m->out.bytes / 72));
             HIPCHK(hipGetLastError());
@@ -2068,10 +1640,9 @@ int sdf_expand_slabs(sdf_ctx *c, const void *const *d_slabs, int n_slabs, int64_
     HIPCHK(set_device(c->device));
     SlabPtrs ptrs = {};
     for (int i = 0; i < n_slabs; i++) { if (!d_slabs[i]) return fail("sdf_expand_slabs: NULL slab"); ptrs.p[i] = (const unsigned char *)d_slabs[i]; }
-    const unsigned gx = (unsigned)std::min<int64_t>(cap_items, 8192);
-    hipLaunchKernelGGL(k_expand, dim3(gx, (unsigned)n_slabs), dim3(256), 0, c->stream, ptrs, n_slabs, (long long)cap_items, (long long)cap_tris,
-                       (double *)d_out, (unsigned long long)cap_out);
-    HIPCHK(hipGetLastError());
+    const unsigned long long blocks = ((unsigned long long)cap_out + 255ull) / 256ull;
+    if (blocks > 0x7fffffffull) return fail("sdf_expand_slabs: soup capacity too large for one launch");
+    HIPCHK((hipError_t)sdf_launch_expand(c->stream, ptrs, n_slabs, (long long)cap_items, (long long)cap_tris, (double *)d_out, (unsigned long long)cap_out));
     return 0;
 }
 
@@ -2217,7 +1788,7 @@ int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
     sdf_ctx *c = m->ctx;
     HIPCHK(set_device(c->device));
     if (c->scratch_out.ensure((size_t)nt * 50)) return 1;
-    hipLaunchKernelGGL(k_stl, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, (const double *)mesh_soup(m), nt,
+    launch_k_stl(dim3((unsigned)((nt + 255) / 256)), dim3(256), c->stream, (const double *)mesh_soup(m), nt,
                        (unsigned short *)c->scratch_out.p);
     HIPCHK(hipGetLastError());
     return copy_to_host(c, h_out, c->scratch_out.p, (size_t)nt * 50);

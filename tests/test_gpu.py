@@ -1126,6 +1126,61 @@ def test_slab_exchange_emulated_ranks(name, samples, ns, eng):
         m.close()
 
 
+def _synthetic_slabs(eng, rng, n, cap_items, cap_tris, sizes_of):
+    """n slabs in the layout of include/sdf_hip.h (header | prefix words | transforms | local float32 triangles) written
+    by NumPy, and the float64 soup `points * scale + offset` (reference sdf/core.py:58-60) they expand to"""
+    sb = eng.slab_bytes(cap_items, cap_tris)
+    host = np.zeros((n, sb), np.uint8)
+    prefix_off = 128
+    xf_off = prefix_off + cap_items * 8
+    tris_off = (xf_off + cap_items * 48 + 15) & ~15
+    want = [np.zeros((0, 9))]
+    for s in range(n):
+        sizes = sizes_of(s)
+        ni, nt = len(sizes), int(sizes.sum())
+        assert ni <= cap_items and nt <= cap_tris
+        head = np.zeros(16, np.int64)
+        head[0], head[1] = nt, ni
+        host[s, :128] = head.view(np.uint8)
+        host[s, prefix_off:prefix_off + ni * 8] = (np.cumsum(sizes).astype(np.uint64) | np.uint64(2 << 62)).view(np.uint8)
+        xf = rng.uniform(-1, 1, (ni, 6))
+        xf[:, 3:] = rng.uniform(0.01, 0.02, (ni, 3))
+        host[s, xf_off:xf_off + ni * 48] = xf.reshape(-1).view(np.uint8)
+        tri = rng.uniform(0, 32, (nt, 9)).astype(np.float32)
+        host[s, tris_off:tris_off + nt * 36] = tri.reshape(-1).view(np.uint8)
+        item = np.repeat(np.arange(ni), sizes)
+        want.append(tri.astype(np.float64) * np.tile(xf[item, 3:], 3) + np.tile(xf[item, :3], 3))
+    return host, np.concatenate(want)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 8, 64])
+def test_expand_synthetic_slabs(n, eng):
+    """k_expand alone against NumPy: slabs of random work items (empty items, empty slabs, items of one triangle and of
+    thousands), so that workgroups of 256 output triangles straddle items and slabs in every way -- in particular into
+    the LAST slab, the case a compiler option once broke (sdf_amd/csrc/sdf_plain.hip)"""
+    import torch
+    rng = np.random.default_rng(100 + n)
+    for scale in (1, 40, 700):
+        def sizes_of(s):
+            k = int(rng.integers(0, 60)) if s != n - 1 else int(rng.integers(1, 60))
+            z = rng.integers(0, scale * 3, k)
+            z[rng.random(k) < 0.3] = 0
+            return z.astype(np.int64)
+        cap_items, cap_tris = 64, 64 * scale * 3
+        host, want = _synthetic_slabs(eng, rng, n, cap_items, cap_tris, sizes_of)
+        T, sb = len(want), host.shape[1]
+        buf = torch.from_numpy(host.reshape(-1)).to('cuda:0')
+        for cap_out in (T + 5, max(T - 300, 0)):                               # (a soup that is too small is filled and not overrun)
+            out = torch.full((9 * (T + 5),), -7.0, dtype=torch.float64, device='cuda:0')
+            torch.cuda.synchronize()
+            eng.expand_slabs([buf.data_ptr() + i * sb for i in range(n)], cap_items, cap_tris, out.data_ptr(), cap_out)
+            eng.synchronize()
+            got = out.cpu().numpy()
+            m = min(T, cap_out)
+            assert np.array_equal(got[:9 * m].reshape(-1, 9), want[:m])
+            assert (got[9 * m:] == -7.0).all()
+
+
 def test_estimate_bounds_failure_is_numpys(ns):
     """a model no probe of the +-1e9 cube comes near: the reference dies in `where.max(axis=0)` of an empty array
     (reference sdf/core.py:80); so does the device loop, with the same exception type"""

@@ -26,8 +26,8 @@ X, Y, Z, _ = core.grid_axes(bench.EXAMPLE_BOUNDS, samples=2 ** LOG2)
 dev = torch.device('cuda', 0)
 for chunks in (1, 2):
     for depth in (1, 2):
-        for _ in range(5):
-            dist.generate_sharded_device(eng, tape, X, Y, Z, 32, True, device=dev, chunks=chunks)
+        for i in range(6):      # (both lanes: a lane's first step allocates its slabs and its soup)
+            dist.collect_sharded(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=dev, chunks=chunks, lane=i % 2))
         torch.cuda.synchronize()
         inflight, acc = [], []
         t0 = time.perf_counter()
