@@ -70,6 +70,22 @@ def test_float32_mode_is_close(ns, golden_values, eng):
     assert np.all(np.abs(v - ref) <= 1e-5 * np.maximum(1.0, np.abs(P).max(axis=1)))
 
 
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 22), ('ex_blobby', 2 ** 21), ('ex_gearlike', 2 ** 21)])
+def test_float32_envelope(name, samples, ns, eng):
+    """the float32 mode's soup against the float64 one (bench.py's SECONDARY field `f32_envelope`, tools/f32envelope.py at
+    the BASELINE sizes): the tolerance north_star states for floating point is 1e-5 relative.  Vertices, not positions in
+    the soup, are compared: a sample whose sign differs between the modes re-triangulates the cells around one grid vertex"""
+    import bench
+    f = fixtures.build(name, ns)
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, BOUNDS[name])), samples=samples)
+    r = bench.f32_envelope(eng, eng.tape_for(f), X, Y, Z, calls=1)
+    cell = float(X[1] - X[0]) * 3 ** 0.5 / float(max(X[-1] - X[0], Y[-1] - Y[0], Z[-1] - Z[0]))
+    assert abs(r['triangles_f32'] - r['triangles_f64']) <= max(8, r['triangles_f64'] // 1000)
+    assert r['skipped_f32'] == r['skipped_f64']
+    for d in (r['rel_distance_f32_to_f64'], r['rel_distance_f64_to_f32']):
+        assert d['p9999'] <= 1e-5 and d['share_within_1e-5'] >= 0.9999 and d['max'] <= cell
+
+
 MC = np.load(os.path.join(GOLDEN, 'mc_volumes.npz'))
 MC_NAMES = sorted(k[4:] for k in MC.files if k.startswith('vol_'))
 

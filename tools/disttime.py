@@ -26,18 +26,19 @@ X, Y, Z, _ = core.grid_axes(bench.EXAMPLE_BOUNDS, samples=2 ** LOG2)
 dev = torch.device('cuda', 0)
 for chunks in (1, 2):
     for depth in (1, 2):
-        for i in range(6):      # (both lanes: a lane's first step allocates its slabs and its soup)
-            dist.collect_sharded(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=dev, chunks=chunks, lane=i % 2))
-        torch.cuda.synchronize()
-        inflight, acc = [], []
-        t0 = time.perf_counter()
-        for i in range(steps):
-            while len(inflight) >= depth:
+        # (the same loop twice, the second pass timed: a lane's first step allocates its slabs and its soup, a call slot's
+        # first use its 1.2 GB of park slots -- with two steps in flight that is a second slot, 45 ms once)
+        for timed in (False, True):
+            inflight, acc = [], []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps if timed else 8):
+                while len(inflight) >= depth:
+                    acc.append(dist.collect_sharded(inflight.pop(0))[1])
+                inflight.append(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=dev, chunks=chunks, lane=i % 2))
+            while inflight:
                 acc.append(dist.collect_sharded(inflight.pop(0))[1])
-            inflight.append(dist.submit_sharded(eng, tape, X, Y, Z, 32, True, device=dev, chunks=chunks, lane=i % 2))
-        while inflight:
-            acc.append(dist.collect_sharded(inflight.pop(0))[1])
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         print('chunks %d, %d step(s) in flight: %.3f ms per step; device: mesh %.3f exchange %.3f expand %.3f ms; slab %.1f MB'
               % (chunks, depth, 1e3 * dt, np.mean([a['ms_mesh'] for a in acc]), np.mean([a['ms_exchange'] for a in acc]),
