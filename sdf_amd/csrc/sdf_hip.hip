@@ -389,6 +389,7 @@ static hipError_t host_malloc(void **p, size_t bytes) { if (alloc_fails_now()) {
 // Device allocations are recycled through a small per-device free list: hipMalloc / hipFree cost
 // tens of microseconds each (and hipFree synchronises), which at ~1 ms per generate call was 10 %
 // of the step when every mesh allocated and freed its seven buffers.
+static const bool g_pool_trace = getenv("SDF_POOL_TRACE") != nullptr;   // every hipMalloc / hipFree behind the pool, to stderr
 struct DevPool {
     struct Blk { void *p; size_t bytes; int device; };
     std::vector<Blk> free_list;
@@ -412,6 +413,7 @@ struct DevPool {
         // (four calls in flight x up to twelve buffers each come back at once: a list shorter than that evicts -- hipFree, a
         // device synchronisation -- blocks the very next call allocates again)
         if (free_list.size() >= 160) {   // evict the oldest block
+            if (g_pool_trace) fprintf(stderr, "[sdf pool] evict %zu bytes (hipFree)\n", free_list.front().bytes);
             (void)hipFree(free_list.front().p);
             free_list.erase(free_list.begin());
         }
@@ -440,6 +442,7 @@ struct DevBuf {
         want = (want + 255) & ~(size_t)255;
         size_t got = 0;
         if (void *q = g_pool.take(want, dev, &got)) { p = q; bytes = got; device = dev; return 0; }
+        if (g_pool_trace) fprintf(stderr, "[sdf pool] miss %zu bytes (hipMalloc)\n", want);
         hipError_t e = dev_malloc(&p, want);
         if (e != hipSuccess && !g_alloc_hook_hit) {   // give the cached blocks back to the driver and retry once
             g_pool.drop_device(dev);

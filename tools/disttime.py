@@ -31,6 +31,8 @@ for chunks in (1, 2):
         for timed in (False, True):
             inflight, acc = [], []
             torch.cuda.synchronize()
+            if timed and os.environ.get('SDF_POOL_TRACE'):
+                print('-- timed pass starts', flush=True)
             t0 = time.perf_counter()
             for i in range(steps if timed else 8):
                 while len(inflight) >= depth:
@@ -40,7 +42,7 @@ for chunks in (1, 2):
                 acc.append(dist.collect_sharded(inflight.pop(0))[1])
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        print('chunks %d, %d step(s) in flight: %.3f ms per step; device: mesh %.3f exchange %.3f expand %.3f ms; slab %.1f MB'
+        print('chunks %d, %d step(s) in flight: %.3f ms per step; device: mesh %.3f exchange %.3f expand %.3f ms; slab %.1f MB; retries %d'
               % (chunks, depth, 1e3 * dt, np.mean([a['ms_mesh'] for a in acc]), np.mean([a['ms_exchange'] for a in acc]),
-                 np.mean([a['ms_expand'] for a in acc]), acc[-1]['slab_bytes'] / 1e6), flush=True)
+                 np.mean([a['ms_expand'] for a in acc]), acc[-1]['slab_bytes'] / 1e6, sum(a.get('n_retries', 0) for a in acc)), flush=True)
 td.destroy_process_group()
