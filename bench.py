@@ -23,6 +23,7 @@ synchronous call costs (min / median / max over back-to-back calls with nothing 
 caller of f.generate() sees), `clocks`, `other_configs` = BASELINE configs 3 - 5 at their real sizes (a few steps each).
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -349,15 +350,23 @@ def main():
             for _ in range(max(depth + 1, 5)):     # use (1.2 GB, ~35 ms each), and output buffers that are too small are replaced
                 one_step()
             sync()
-        for _ in range(warmup):
-            one_step()
-        sync()
-        del mesh_ms[:], exch_ms[:], dev_ms[:], sclk[:]
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            one_step()
-        sync()                                 # every one of the K steps is complete (collected) here
-        dt = time.perf_counter() - t0
+        # (like timeit: no cyclic garbage collection inside the timed region.  With torch imported a full collection takes
+        # 30 - 50 ms on these hosts -- a hundred steps of this job -- and when it falls is a matter of how many containers the
+        # process has allocated so far: tools/disttime.py showed it as a "slow mode" of whichever configuration it hit)
+        gc.collect()
+        gc.disable()
+        try:
+            for _ in range(warmup):
+                one_step()
+            sync()
+            del mesh_ms[:], exch_ms[:], dev_ms[:], sclk[:]
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one_step()
+            sync()                                 # every one of the K steps is complete (collected) here
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         trace('measure %s done: %.3f ms per step' % (model, 1e3 * dt / steps))
         assert len(mesh_ms) == steps
         if td is not None:
