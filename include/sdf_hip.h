@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 4
+#define SDF_ABI_VERSION 5
 
 #define SDF_PRECISION_F64 0 /* parity mode: float64 sampling like the reference's NumPy path */
 #define SDF_PRECISION_F32 1 /* fast mode: float32 sampling */
@@ -196,6 +196,9 @@ int sdf_generate_compact_async(sdf_tape *tape, const double *X, int nx, const do
 int sdf_expand_slabs(sdf_ctx *ctx, const void *const *d_slabs, int n_slabs, int64_t cap_items, int64_t cap_tris,
                      void *d_out, int64_t cap_out_tris);
 /* The multi-GPU step inside the library: one process per GPU, RCCL (dlopen'ed: librccl.so.1) over xGMI.
+ *   sdf_comm_available   1 if librccl could be loaded in this process, else 0 (sdf_last_error says why).  Local and cheap:
+ *                        the ranks agree on it BEFORE anything collective is started, so that a rank without the
+ *                        library does not leave the others inside ncclCommInitRank
  *   sdf_comm_unique_id   rank 0 draws one 128-byte id per lane (ncclGetUniqueId) and hands them to the other ranks out
  *                        of band (sdf_amd/dist.py: through the process group that launched the ranks)
  *   sdf_comm_create      collective: every rank, same ids, its own rank.  A communicator has 1 or 2 LANES -- a lane is
@@ -223,6 +226,7 @@ typedef struct sdf_exchange_stats {
                                                  * shard(s) / until the last all-gather has landed / k_expand / all   */
     int64_t per_rank_triangles[64];
 } sdf_exchange_stats;
+int sdf_comm_available(void);
 int sdf_comm_unique_id(void *out_id128);
 int sdf_comm_create(sdf_ctx *ctx, const void *ids, int n_lanes, int rank, int world, sdf_comm **out);
 int sdf_comm_destroy(sdf_comm *comm);

@@ -199,9 +199,25 @@ def _native_comm(eng, td, group):
     if comm is None:
         from . import engine as _engine
         r, world = td.get_rank(group), td.get_world_size(group)
-        ids = [_engine.Comm.unique_ids(eng.lib, 2) if r == 0 else None]
+        # every rank says whether librccl loads HERE before anything collective inside the library is started: a rank
+        # that raised on its own would leave the others in a broadcast (or, later, in ncclCommInitRank) for ever.
+        # All ranks see the same list and take the same branch.
+        ok, why = _engine.Comm.available(eng.lib)
+        flags = [None] * world
+        td.all_gather_object(flags, (bool(ok), why), group=group)
+        bad = ['rank %d: %s' % (i, f[1]) for i, f in enumerate(flags) if not f[0]]
+        if bad:
+            raise RuntimeError('; '.join(bad))
+        ids = [None]
+        if r == 0:
+            try:
+                ids[0] = _engine.Comm.unique_ids(eng.lib, 2)
+            except Exception as e:           # (the others must hear about it, not wait for it)
+                ids[0] = e
         src = td.get_global_rank(group, 0) if group is not None else 0
         td.broadcast_object_list(ids, src=src, group=group)
+        if isinstance(ids[0], Exception):
+            raise RuntimeError('rank 0 could not draw the communicator ids: %r' % (ids[0],))
         comm = _COMMS[key] = _engine.Comm(eng, ids[0], r, world)
         comm._lane_owner = {}
     return comm

@@ -101,6 +101,7 @@ ABI = {
                                                   ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _vp, _c_i64,
                                                   _c_i64, ctypes.POINTER(_vp)]),
     'sdf_expand_slabs': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int, _c_i64, _c_i64, _vp, _c_i64]),
+    'sdf_comm_available': (ctypes.c_int, []),
     'sdf_comm_unique_id': (ctypes.c_int, [_vp]),
     'sdf_comm_create': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     'sdf_comm_destroy': (ctypes.c_int, [_vp]),
@@ -130,7 +131,7 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -384,6 +385,13 @@ class Exchange:
 class Comm:
     """the ranks of one multi-GPU job (`sdf_comm*`): RCCL communicators + persistent exchange buffers, 1 or 2 lanes.
     Creation is collective: every rank calls it with the ids rank 0 drew (`Comm.unique_ids`)."""
+
+    @staticmethod
+    def available(lib):
+        """(True, '') if librccl loads in this process, else (False, why) -- local, nothing collective"""
+        if lib.sdf_comm_available():
+            return True, ''
+        return False, (lib.sdf_last_error() or b'').decode(errors='replace')
 
     @staticmethod
     def unique_ids(lib, n_lanes=2):

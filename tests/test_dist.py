@@ -137,3 +137,80 @@ def test_sharded_generate_over_gloo(world, chunks):
         assert ntri == int(d['ntri']) == sum(per)
         assert (sk, em, ne) == (44, 60, 112)              # BASELINE config 1 classification
     assert all(o[6] == out[0][6] for o in out) and min(out[0][6]) > 0
+
+
+def _agree_worker(rank, world, port, q, missing_on):
+    """dist._native_comm up to (not including) the RCCL communicator: the ranks' agreement about librccl"""
+    import torch.distributed as td
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sdf_amd import dist, engine
+
+        class FakeEngine:
+            lib = object()
+
+        class StubComm:
+            created = []
+
+            @staticmethod
+            def available(lib):
+                return (False, 'no librccl here') if rank in missing_on else (True, '')
+
+            @staticmethod
+            def unique_ids(lib, n_lanes=2):
+                return bytes([7]) * (engine.COMM_ID_BYTES * n_lanes)
+
+            def __init__(self, eng, ids, r, w):
+                StubComm.created.append((ids, r, w))
+
+            def close(self):
+                pass
+
+        real = engine.Comm
+        engine.Comm = StubComm
+        try:
+            try:
+                fake = FakeEngine()
+                comm = dist._native_comm(fake, td, None)
+                assert dist._native_comm(fake, td, None) is comm and len(StubComm.created) == 1      # (created once per engine and group)
+                got = ('comm', StubComm.created[0][0][:4], StubComm.created[0][1:])
+            except RuntimeError as e:
+                got = ('refused', str(e))
+        finally:
+            engine.Comm = real
+            dist._COMMS.clear()
+        td.barrier()                       # (nobody is left behind in a collective)
+        q.put((rank, got))
+    except BaseException:
+        import traceback
+        q.put((rank, ('ERROR', traceback.format_exc())))
+        raise
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize('missing_on', [(), (1,), (0,)])
+def test_native_communicator_is_agreed_on_by_all_ranks(missing_on):
+    """a rank whose process cannot load librccl must not leave the others in a collective: every rank refuses the native
+    exchange alike (and takes the torch.distributed path) -- or every rank creates its communicator from rank 0's ids"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world = 2
+    port = 31700 + (os.getpid() % 2000) + 3 * len(missing_on) + sum(missing_on)
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q, missing_on)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert out[r][0] != 'ERROR', out[r][1]
+        if missing_on:
+            assert out[r][0] == 'refused' and 'rank %d: no librccl here' % missing_on[0] in out[r][1]
+        else:
+            assert out[r][0] == 'comm' and out[r][1] == bytes([7]) * 4 and out[r][2] == (r, world)
