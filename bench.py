@@ -346,10 +346,13 @@ def main():
                 td.barrier()
                 torch.cuda.synchronize()
 
-        if world == 1:          # set-up, not a step: every one of the context's four call lanes allocates its staging on first
-            for _ in range(max(depth + 1, 5)):     # use (1.2 GB, ~35 ms each), and output buffers that are too small are replaced
-                one_step()
-            sync()
+        # set-up, not a step (every rank alike): each of the context's four call slots allocates its k_mesh park slots on
+        # first use (1.2 GB, ~35 - 50 ms each; the slots rotate, so the FOURTH step of a process would still pay that inside
+        # a timed region that starts after three warm-up steps), output buffers that are too small are replaced (N = 1),
+        # the lanes' slabs and soup shrink from the first step's upper bounds to what the job needs (N > 1)
+        for _ in range(max(depth + 1, 5)):
+            one_step()
+        sync()
         # (like timeit: no cyclic garbage collection inside the timed region.  With torch imported a full collection takes
         # 30 - 50 ms on these hosts -- a hundred steps of this job -- and when it falls is a matter of how many containers the
         # process has allocated so far: tools/disttime.py showed it as a "slow mode" of whichever configuration it hit)
