@@ -275,6 +275,8 @@ struct IaShared {
     int stride;     // threads that share the array
 #if defined(__HIP_DEVICE_COMPILE__)
     __device__ __forceinline__ static int lane_slot() { return (int)threadIdx.x; }
+#elif defined(SDF_HOST_SIMT)
+    static int lane_slot() { return sdf_host_simt_tid(); }   // (host threads playing a workgroup: tests/native/cull_tasks_host.py)
 #else
     static int lane_slot() { return 0; }      // (host build of the interval run: one box at a time, tests/native/interval_tape_host.hip)
 #endif
