@@ -380,7 +380,24 @@ def main():
                 'dev_ms': list(dev_ms), 'sclk': list(sclk), 'state': state, 'grid_voxels': len(X) * len(Y) * len(Z)}
 
     DEPTH = 1 if args.sync else (max(1, min(args.inflight, 4)) if world == 1 else 2)
+    # N > 1: a rank that dies or stalls leaves the others inside a collective for ever.  The headline measurement of a healthy
+    # job takes seconds; if it has not come back after SDF_BENCH_HEADLINE_TIMEOUT_S (default 900) every rank says so and
+    # exits instead of holding its GPU until somebody kills the job.
+    headline_timer = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get('SDF_BENCH_HEADLINE_TIMEOUT_S', '900'))
+
+        def give_up():
+            sys.stderr.write('bench.py rank %d: the headline measurement did not finish within %.0f s (a rank stuck in a collective?); giving up\n' % (rank, limit))
+            sys.stderr.flush()
+            os._exit(3)
+        headline_timer = threading.Timer(limit, give_up)
+        headline_timer.daemon = True
+        headline_timer.start()
     res = measure(args.model, args.samples_log2, args.steps, args.warmup, DEPTH)
+    if headline_timer is not None:
+        headline_timer.cancel()
     clocks_busy = read_clocks() if rank == 0 else None       # (right behind the timed region)
     f, tape, X, Y, Z, dt, state = res['f'], res['tape'], res['X'], res['Y'], res['Z'], res['dt'], res['state']
     grid_voxels = res['grid_voxels']
