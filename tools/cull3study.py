@@ -21,7 +21,8 @@ subprocess.check_call([tih.HIPCC, '--offload-host-only', '-O2', '-std=c++17', '-
 lib = ctypes.CDLL(so)
 lib.ia_tape_boxes.restype = ctypes.c_int
 lib.ia_tape_boxes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
-GOLD = {'example:27': 'full_c2_example_s27.npz', 'blobby:30': 'full_c5_blobby_s30.npz', 'gearlike:30': 'full_c3_gearlike_s30.npz'}
+GOLD = {'example:27': 'full_c2_example_s27.npz', 'blobby:30': 'full_c5_blobby_s30.npz', 'gearlike:30': 'full_c3_gearlike_s30.npz',
+        'weave:24': 'full_weave_s24.npz', 'knurling:27': 'full_knurling_s27.npz'}
 
 
 def intervals(t, boxes):
