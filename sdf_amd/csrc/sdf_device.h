@@ -747,6 +747,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 const int nwords = (nvox + 63) >> 6;
                 for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;   // (+2: the row extraction reads one word ahead)
                 __syncthreads();
+                // <cull-sign-fill>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
                 const int hlast = (c2 - 1) >> 1;                                // the last sub-group along z owns the boundary sample too
                 for (int r = tid; r < lx * ly; r += BLOCK) {                    // a thread per row of lz samples along z
                     const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
@@ -765,6 +766,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         if (sh && (rowmask >> (64 - sh))) atomicOr(&bits[(o >> 6) + 1], rowmask >> (64 - sh));
                     }
                 }
+                // </cull-sign-fill>
                 // (no barrier: the evaluation below only ORs into the same words)
             }
         }
