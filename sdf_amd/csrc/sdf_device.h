@@ -773,6 +773,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (tid == 0) atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
         SDF_SUBPROF(9);
         // ---- 1c. evaluate the listed tasks: NS per wave and pass ----
+        // <sample-loop>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
         for (int t0 = wave * NS; t0 < ntl; t0 += NWAVE * NS) {
             V px, py, pz;
             SDF_UNROLL
@@ -795,6 +796,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 }
             }
         }
+        // </sample-loop>
         __syncthreads();
         SDF_FRESH();
         SDF_SUBPROF(10);

@@ -122,8 +122,33 @@ extern "C" int cull_sign_fill_host(const unsigned char *sstate, int lx, int ly, 
     return 0;
 }
 '''
+    # k_mesh's sampling loop over the listed units, with a stand-in for the tape interpreter (the value of a sample encodes
+    # its coordinates) and all 1024 threads of a workgroup one after the other
+    a, b = src.index('// <sample-loop>'), src.index('// </sample-loop>')
+    loop = src[src.index('\n', a) + 1:b].replace('run_tape<T, FULL, NP, ND, NS>(wcode, consts, px, py, pz)', 'host_field(px, py, pz)')
+    assert 'host_field' in loop
+    loop_fn = '''
+extern "C" int cull_sample_loop_host(const unsigned char *record, int lx, int ly, int lz, const double *axes, float *vol, unsigned long long *bits) {
+    typedef double T;
+    constexpr int NS = 2, BLOCK = 1024, NWAVE = BLOCK / 64;
+    struct V { T v[NS]; };
+    auto host_field = [](const V &x, const V &y, const V &z) { V r; for (int k = 0; k < NS; k++) r.v[k] = x.v[k] + 64.0 * y.v[k] + 4096.0 * z.v[k] - 70000.0; return r; };
+    struct { int lz; bool sample(int, int, int &, int &, int &) const { return false; } } tt{lz};
+    const unsigned *list = reinterpret_cast<const unsigned *>(record);
+    const unsigned short *units = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(list) + CULL_ULIST);   // (as in k_mesh)
+    const int n = (int)reinterpret_cast<const unsigned short *>(list)[0];
+    if (n == 0xFFFF) return 1;
+    const bool culled = true;
+    const int ntl = (n + 7) >> 3, lyz = ly * lz;
+    for (int tid = 0; tid < BLOCK; tid++) {
+        const int wave = tid >> 6, lane = tid & 63;
+''' + loop + '''
+    }
+    return 0;
+}
+'''
     # (`extern "C"` functions inside an anonymous namespace keep C linkage)
-    open(path, 'w').write(PRELUDE + body + fill_fn + POSTLUDE)
+    open(path, 'w').write(PRELUDE + body + fill_fn + loop_fn + POSTLUDE)
 
 
 def build(workdir):
@@ -139,6 +164,8 @@ def build(workdir):
     lib.cull_sample_host.restype = ctypes.c_int
     lib.cull_sample_host.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
     lib.cull_layout.argtypes = [ctypes.c_void_p]
+    lib.cull_sample_loop_host.restype = ctypes.c_int
+    lib.cull_sample_loop_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.cull_sign_fill_host.restype = ctypes.c_int
     lib.cull_sign_fill_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     return lib

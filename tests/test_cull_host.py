@@ -89,7 +89,7 @@ def _run(cull_lib, t, ax, block):
     n = int(rec[:2].view(np.uint16)[0])
     units = rec[ulist_off:ulist_off + 2 * cap].view(np.uint16)
     sstate = rec[sstate_off:sstate_off + 4096].reshape(16, 16, 16)
-    return ntl.value, n, units, sstate
+    return ntl.value, n, units, sstate, rec
 
 
 TILES = [('ex_example', 2 ** 22, 'regular'), ('ex_example', 1500000, 'ragged'), ('ex_blobby', 2 ** 21, 'regular'), ('ex_blobby', 1500000, 'ragged'),
@@ -124,9 +124,9 @@ def test_cull_tasks_on_the_host_match_the_rules(name, samples, kind, libs, ns):
     want_s, want_units = _model(tape_lib, t, ax)
     got = {}
     for block in (64, 128, 256):
-        ntl, cnt, units, sstate = _run(cull_lib, t, ax, block)
-        got[block] = (ntl, cnt, units[:((cnt + 7) & ~7) if cnt != 0xFFFF else 0].copy(), sstate.copy())
-    ntl, cnt, units, sstate = got[256]
+        ntl, cnt, units, sstate, rec = _run(cull_lib, t, ax, block)
+        got[block] = (ntl, cnt, units[:((cnt + 7) & ~7) if cnt != 0xFFFF else 0].copy(), sstate.copy(), rec.copy())
+    ntl, cnt, units, sstate, rec = got[256]
     for block in (64, 128):
         assert got[block][0] == ntl and got[block][1] == cnt and np.array_equal(got[block][2], units) and np.array_equal(got[block][3], sstate)
     assert cnt != 0xFFFF and ntl == (cnt + 7) >> 3
@@ -159,6 +159,20 @@ def test_cull_tasks_on_the_host_match_the_rules(name, samples, kind, libs, ns):
     own = [np.minimum(np.arange(n[d]), cc[d] - 1) >> 1 for d in range(3)]
     assert np.array_equal(got_bits, want_s[np.ix_(own[0], own[1], own[2])] == 1)
     assert not np.unpackbits(bits.view(np.uint8), bitorder='little')[nvox:].any()
+    # k_mesh's sampling loop on the record: exactly the listed samples get their value (here: a code of their coordinates),
+    # and the positive ones their sign bit on top of the fill
+    idx_axes = np.zeros(99)
+    for d_ in range(3):
+        idx_axes[33 * d_:33 * d_ + n[d_]] = np.arange(n[d_])
+    vol = np.full(nvox, np.float32(-12345.0), np.float32)
+    bits2 = bits.copy()
+    assert cull_lib.cull_sample_loop_host(np.ascontiguousarray(rec).ctypes.data, n[0], n[1], n[2], idx_axes.ctypes.data, vol.ctypes.data, bits2.ctypes.data) == 0
+    I, J, K = np.meshgrid(np.arange(n[0]), np.arange(n[1]), np.arange(n[2]), indexing='ij')
+    code_of = (I + 64.0 * J + 4096.0 * K - 70000.0).astype(np.float32)
+    vol3 = vol.reshape(n)
+    assert np.array_equal(vol3[listed], code_of[listed]) and (vol3[~listed] == np.float32(-12345.0)).all()
+    want_bits2 = got_bits | (listed & (code_of > 0))
+    assert np.array_equal(np.unpackbits(bits2.view(np.uint8), bitorder='little')[:nvox].reshape(n).astype(bool), want_bits2)
     # soundness: every sample that belongs to an undecided sub-group is evaluated
     c = [m - 1 for m in n]
     for h in np.argwhere(want_s == 0):
@@ -175,5 +189,5 @@ def test_a_tile_with_nearly_everything_undecided_is_not_culled(libs, ns):
     ax = [np.linspace(0.0, 0.32, 33)] * 3
     want_s, want_units = _model(tape_lib, t, ax)
     assert len(want_units) > 3072
-    ntl, cnt, units, sstate = _run(cull_lib, t, ax, 128)
+    ntl, cnt, units, sstate, rec = _run(cull_lib, t, ax, 128)
     assert ntl == -1
