@@ -357,24 +357,42 @@ struct TileTasks {
     }
 };
 
-// Where can the surface not be?  The cells of the tile are taken in groups of 4^3; one thread runs
-// the tape in interval arithmetic (sdf_interval.h) over the box of a group's samples.  A group whose
-// interval excludes zero has no surface cell and its samples only matter by their sign: a sample is
-// evaluated iff it belongs to a group that could not be decided (a sample belongs to up to 8 groups:
-// along an axis, cell groups (i - 1) / 4 and i / 4).  Results are the same bit for bit: marching
-// cubes reads values only at the corners of cells with a sign change, and every such cell lies in an
-// undecided group.  (Two decided neighbours share a face of samples, so they cannot carry opposite
-// signs.)  The bound 1e-30 keeps the sign through the cast to float32.
+// Where can the surface not be?  Three levels of interval arithmetic (sdf_interval.h) over boxes of the tile's cells: the
+// (up to) 4^3 boxes of 8^3 cells, the groups of 4^3 cells inside the boxes that could not be decided, the SUB-GROUPS of 2^3
+// cells inside the groups that could not be decided; one thread per box.  A sub-group whose interval excludes zero has no
+// surface cell and its samples only matter by their sign: a sample is evaluated iff it belongs to an undecided sub-group
+// (a sample belongs to up to 8 of them: along an axis, sub-groups (i - 1) / 2 and i / 2).  Results are the same bit for
+// bit: marching cubes reads values only at the corners of cells with a sign change, and every such cell lies in an
+// undecided sub-group.  (Two decided neighbours share a face of samples, so they cannot carry opposite signs.)  The
+// bound 1e-30 keeps the sign through the cast to float32.
 //
-// Writes the list of tasks to evaluate to tlist and +-1 to the samples of decided groups; returns
-// the number of listed tasks, or -1 when the tile is not culled (degenerate tile, or the interval
-// state of the tape does not fit in LDS).  Listing more tasks than necessary is harmless, missing one
-// is not.  This is the body of k_cull (sdf_hip.hip), a kernel of its own in front of k_mesh: inside
-// k_mesh the interval pass would run on half the waves of a workgroup that holds a whole CU, and its
-// registers would compete with the interpreter's.
-// scratch: u16 task count, tlist (u16 each), CULL_GSTATE: group states | from CULL_COUNT + 16: the states
-// of the 8^3-cell boxes (64 bytes) and the list of groups to evaluate (512 u16)
-enum { CULL_GSTATE = 1152, CULL_COUNT = 1664, CULL_RECORD = 1664, CULL_SCRATCH = 2816 };   // a batch's record in global memory: bytes [0, CULL_RECORD)
+// What is evaluated is listed in UNITS of 2^3 samples [2u, 2u + 1] per axis (u = 0 .. 16; unit 16 is the lone sample 32 of
+// a full axis), eight units to a task of 64 lanes: a unit is listed iff one of the sub-groups {u - 1, u}^3 is undecided.
+// (Until r03 the last level were the groups of 4^3 cells and a task a cube of 4^3 samples: tools/cull3study.py -- the
+// interpreter saw 21 - 28 % of the surviving batches' samples; with this level 10 - 14 %.  Every tile shape goes the same way:
+// the units are clipped to the tile.)
+//
+// Writes the record of the batch -- u16 number of listed units (0xFFFF: not culled), the units (u16 each: u0 << 10 | u1 << 5 |
+// u2, ascending, padded with 0xFFFF to whole tasks), the sub-group states -- and returns the number of TASKS, or -1 when the tile is not culled
+// (degenerate tile, the interval state of the tape does not fit in LDS, or so many units that listing them saves nothing).
+// Listing more units than necessary is harmless, missing one is not.  This is the body of k_cull (sdf_hip.hip), a kernel
+// of its own in front of k_mesh: inside k_mesh the interval pass would run on half the waves of a workgroup that holds a
+// whole CU, and its registers would compete with the interpreter's.
+// record / scratch: [0] u16 unit count | CULL_ULIST: units | CULL_SSTATE: 16^3 sub-group states (0 unknown, 1 positive,
+// 2 negative) || scratch only, from CULL_RECORD: box states (64 B), group states (512 B), the groups to evaluate (512 u16)
+enum { CULL_UNIT_CAP = 3072, CULL_ULIST = 8, CULL_SSTATE = CULL_ULIST + 2 * CULL_UNIT_CAP, CULL_RECORD = CULL_SSTATE + 4096,
+       CULL_MSTATE = CULL_RECORD, CULL_GSTATE = CULL_MSTATE + 64, CULL_ELIST = CULL_GSTATE + 512, CULL_PACC = CULL_ELIST + 1024,
+       CULL_SCRATCH = CULL_PACC + 64 };
+static_assert(CULL_RECORD % 8 == 0 && CULL_SSTATE % 8 == 0, "the record is copied in words; its state rows are read as u64");
+// sample `lane` of task `task` of a culled tile (units: the record's list); false: no such sample (ix, iy, iz are valid
+// indices all the same)
+__device__ __forceinline__ bool cull_sample(const unsigned short *units, int task, int lane, int lx, int ly, int lz, int &ix, int &iy, int &iz) {
+    const unsigned u = units[8 * task + (lane >> 3)];                    // u0 << 10 | u1 << 5 | u2; the padding 0xFFFF lies outside every tile
+    const int x = (int)((u >> 9) & 62u) + ((lane >> 2) & 1), y = (int)((u >> 4) & 62u) + ((lane >> 1) & 1), z = (int)((u << 1) & 62u) + (lane & 1);
+    const bool ok = x < lx && y < ly && z < lz;
+    ix = ok ? x : 0; iy = ok ? y : 0; iz = ok ? z : 0;
+    return ok;
+}
 template <int BLOCK, bool FULL, bool RARE>
 __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *consts, int n_instr_w, int lx, int ly, int lz,
                                        const double *axes, double *ia_state, int ia_bytes, unsigned char *scratch, int *wave_sums,
@@ -384,15 +402,17 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
     // global counters by the caller when the workgroup is done (an atomic per phase would stall the phases it measures:
     // the workgroups of a launch run in step)
     long long tprev = prof ? clock64() : 0;
-    unsigned *pacc = reinterpret_cast<unsigned *>(scratch + CULL_COUNT + 80 + 1024);
+    unsigned *pacc = reinterpret_cast<unsigned *>(scratch + CULL_PACC);
     if (prof && tid == 0) for (int k = 0; k < 12; k++) pacc[k] = 0;
 #define SDF_CULL_PROF(K) do { if (prof && tid == 0) { const long long tn = clock64(); pacc[(K) - 16] += (unsigned)(tn - tprev); tprev = tn; } } while (0)
-    const TileTasks tt(lx, ly, lz);
     const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
     const int per_pass = min(BLOCK, ia_bytes / ((6 * ia_np + 2 * ia_nd) * 8)) & ~63;
     if (c0 <= 0 || c1 <= 0 || c2 <= 0 || per_pass < 64) return -1;
-    unsigned short *tlist = reinterpret_cast<unsigned short *>(scratch) + 1;   // (u16 0 of the record is the task count)
-    unsigned char *gstate = scratch + CULL_GSTATE;   // per cell group: 0 unknown, 1 positive, 2 negative
+    unsigned short *ulist = reinterpret_cast<unsigned short *>(scratch + CULL_ULIST);
+    unsigned char *sstate = scratch + CULL_SSTATE;   // per sub-group of 2^3 cells, [h0][h1][h2], 16 per axis
+    unsigned char *mstate = scratch + CULL_MSTATE;   // per box of 8^3 cells
+    unsigned char *gstate = scratch + CULL_GSTATE;   // per group of 4^3 cells
+    unsigned short *elist = reinterpret_cast<unsigned short *>(scratch + CULL_ELIST);   // up to 512 groups: to evaluate, then the undecided ones
     // the interval of the model over the box of cells [x0, x1) x [y0, y1) x [z0, z1) (clipped to the tile) -> 0 / 1 / 2
     auto box_state = [&](int x0, int x1, int y0, int y1, int z0, int z1) -> unsigned char {
         Ival bx{axes[x0], axes[min(x1, c0)]}, by{axes[33 + y0], axes[33 + min(y1, c1)]}, bz{axes[66 + z0], axes[66 + min(z1, c2)]};
@@ -404,33 +424,56 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
                                           IaShared{ia_state, ia_np, per_pass}, ia_nd, nullptr);
         return v.lo > 1e-30 ? 1 : (v.hi < -1e-30 ? 2 : 0);
     };
-    // two levels: the (up to) 4^3 boxes of 8^3 cells first, one wave; then only the groups inside the
-    // boxes that could not be decided, per_pass at a time.  ONE loop over both (stage 0 = the boxes) so that the
-    // interval interpreter is instantiated once per kernel, not once per level.
-    unsigned char *mstate = scratch + CULL_COUNT + 16;                                 // 64 bytes
-    unsigned short *elist = reinterpret_cast<unsigned short *>(scratch + CULL_COUNT + 80);   // up to 512 groups to evaluate
-    int nev = 0;
-    for (int stage = 0;; stage++) {
-        const int e0 = (stage - 1) * per_pass;
-        if (stage > 0 && e0 >= nev) break;                                             // (uniform)
-        const bool run = stage == 0 ? tid < 64 : (tid < per_pass && e0 + (tid & ~63) < nev);   // (whole waves)
-        int gq = 0, x0, y0, z0, ext;
+    // ONE loop over the three levels (phase 0: the boxes, one wave; 1: the groups inside undecided boxes; 2: the sub-groups
+    // inside undecided groups; per_pass boxes at a time) so that the interval interpreter is instantiated once per kernel.
+    int phase = 0, e0 = 0, nev = 0;
+    for (;;) {
+        if (phase == 1 && e0 >= nev) {                                                 // (uniform) groups done: on to the sub-groups
+            __syncthreads();
+            SDF_CULL_PROF(19);
+            int nund = 0;
+            for (int g0 = 0; g0 < 512; g0 += BLOCK) {   // the undecided groups, compacted (elist is free: every listed group has been evaluated)
+                const int gi = g0 + tid;
+                const bool und = gi < 512 && gstate[gi] == 0;
+                int n;
+                const int pos = nund + block_exclusive_count<BLOCK>(und, wave_sums, n);
+                if (und) elist[pos] = (unsigned short)gi;
+                nund += n;
+            }
+            for (int h = tid; h < 4096; h += BLOCK) {   // a sub-group inherits the state of its group; one outside the tile counts as decided
+                const int h0 = h >> 8, h1 = (h >> 4) & 15, h2 = h & 15;
+                const bool exists = 2 * h0 < c0 && 2 * h1 < c1 && 2 * h2 < c2;
+                sstate[h] = exists ? gstate[((h0 >> 1) * 8 + (h1 >> 1)) * 8 + (h2 >> 1)] : 1;
+            }
+            __syncthreads();
+            phase = 2; e0 = 0; nev = 8 * nund;
+        }
+        if (phase == 2 && e0 >= nev) break;                                            // (uniform)
+        const bool run = phase == 0 ? tid < 64 : (tid < per_pass && e0 + (tid & ~63) < nev);   // (whole waves)
+        int target = 0, x0, y0, z0, ext;
         bool live;
-        if (stage == 0) {
+        if (phase == 0) {
             const int m0 = tid >> 4, m1 = (tid >> 2) & 3, m2 = tid & 3;
             live = 8 * m0 < c0 && 8 * m1 < c1 && 8 * m2 < c2;
             x0 = live ? 8 * m0 : 0; y0 = live ? 8 * m1 : 0; z0 = live ? 8 * m2 : 0; ext = 8;
-        } else {
+        } else if (phase == 1) {
             live = e0 + tid < nev;
-            gq = run ? (int)elist[min(e0 + tid, nev - 1)] : 0;
-            x0 = 4 * (gq >> 6); y0 = 4 * ((gq >> 3) & 7); z0 = 4 * (gq & 7); ext = 4;
+            target = run ? (int)elist[min(e0 + tid, nev - 1)] : 0;
+            x0 = 4 * (target >> 6); y0 = 4 * ((target >> 3) & 7); z0 = 4 * (target & 7); ext = 4;
+        } else {
+            const int e = min(e0 + tid, nev - 1);
+            const int gq = run ? (int)elist[e >> 3] : 0, ch = e & 7;
+            const int h0 = 2 * (gq >> 6) + (ch >> 2), h1 = 2 * ((gq >> 3) & 7) + ((ch >> 1) & 1), h2 = 2 * (gq & 7) + (ch & 1);
+            live = e0 + tid < nev && 2 * h0 < c0 && 2 * h1 < c1 && 2 * h2 < c2;
+            target = (h0 * 16 + h1) * 16 + h2;
+            x0 = live ? 2 * h0 : 0; y0 = live ? 2 * h1 : 0; z0 = live ? 2 * h2 : 0; ext = 2;
         }
         if (run) {
             const unsigned char st = box_state(x0, x0 + ext, y0, y0 + ext, z0, z0 + ext);
-            if (stage == 0) mstate[tid & 63] = live ? st : 1;
-            else if (live) gstate[gq] = st;
+            if (phase == 0) mstate[tid & 63] = live ? st : 1;
+            else if (live) (phase == 1 ? gstate : sstate)[target] = st;
         }
-        if (stage > 0) { SDF_CULL_PROF(19); if (prof && tid == 0) pacc[7]++; continue; }
+        if (phase != 0) { if (prof && tid == 0) pacc[7]++; e0 += per_pass; continue; }
         SDF_CULL_PROF(17);
         __syncthreads();
         for (int g0 = 0; g0 < 512; g0 += BLOCK) {   // a group inherits the state of its box; the undecided ones are listed
@@ -447,69 +490,56 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
         __syncthreads();
         SDF_CULL_PROF(18);
         if (prof && tid == 0) pacc[6] = (unsigned)nev;
-    }
-    __syncthreads();
-    SDF_CULL_PROF(19);
-    // the undecided groups as bit rows: ubits[q0 * 8 + q1] has bit q2 set (the 64 bytes of the box states, done with)
-    unsigned char *ubits = mstate;
-    if (tid < 64) {
-        const unsigned long long g8 = *reinterpret_cast<const unsigned long long *>(gstate + 8 * tid);
-        unsigned bitsq = 0;
-        SDF_UNROLL for (int k = 0; k < 8; k++) bitsq |= ((g8 >> (8 * k)) & 255ull) == 0ull ? 1u << k : 0u;
-        ubits[tid] = (unsigned char)bitsq;
-    }
-    __syncthreads();
-    auto unknown_in = [&](int j0lo, int j0hi, int j1lo, int j1hi, int j2lo, int j2hi) -> bool {   // any undecided group in a box of cells
-        const int z0 = max(j2lo, 0) >> 2, z1 = min(j2hi, c2 - 1) >> 2;
-        const unsigned zmask = z1 >= z0 ? ((2u << z1) - 1u) & ~((1u << z0) - 1u) : 0u;
-        unsigned u = 0;
-        for (int q0 = max(j0lo, 0) >> 2; q0 <= (min(j0hi, c0 - 1) >> 2); q0++)
-            for (int q1 = max(j1lo, 0) >> 2; q1 <= (min(j1hi, c1 - 1) >> 2); q1++) u |= ubits[q0 * 8 + q1];
-        return (u & zmask) != 0u;
-    };
-    // one thread per task: the cells around its samples, as a box (for the tasks that are runs of
-    // samples the box spans the rows / planes the run touches); the listed tasks in ascending order
-    int ntl = 0;
-    for (int t0 = 0; t0 < tt.ntask; t0 += BLOCK) {
-        const int task = t0 + tid;
-        bool need = false;
-        if (task < tt.ntask) {
-            if (!tt.regular) {
-                const int i0 = task * 64, i1 = min(i0 + 63, tt.nvox - 1);
-                const int x0 = i0 / tt.lyz, x1 = i1 / tt.lyz;
-                int y0 = 0, y1 = ly - 1, z0 = 0, z1 = lz - 1;
-                if (x0 == x1) {
-                    y0 = (i0 - x0 * tt.lyz) / lz; y1 = (i1 - x0 * tt.lyz) / lz;
-                    if (y0 == y1) { z0 = i0 - x0 * tt.lyz - y0 * lz; z1 = i1 - x0 * tt.lyz - y0 * lz; }
-                }
-                need = unknown_in(x0 - 1, x1, y0 - 1, y1, z0 - 1, z1);
-            } else if (task < 512) {   // a cube of 4^3 samples touches the cells of groups a - 1 and a along every axis
-                const int a0 = task >> 6, a1 = (task >> 3) & 7, a2 = task & 7;
-                const int p0 = max(a0 - 1, 0), p1 = max(a1 - 1, 0);
-                const unsigned u = ubits[a0 * 8 + a1] | ubits[p0 * 8 + a1] | ubits[a0 * 8 + p1] | ubits[p0 * 8 + p1];
-                need = (u & ((3u << a2) >> 1)) != 0u;
-            } else if (task < 530) {
-                const int p0 = (task - 512) * 64, r0 = p0 / 33, r1 = min(p0 + 63, 1088) / 33;
-                need = unknown_in(31, 31, r0 - 1, r1, 0, 31);
-            } else if (task < 547) {
-                const int p0 = (task - 530) * 64, r0 = p0 / 33, r1 = min(p0 + 63, 1055) / 33;
-                need = unknown_in(r0 - 1, r1, 31, 31, 0, 31);
-            } else {
-                const int p0 = (task - 547) * 64, r0 = p0 >> 5, r1 = (p0 + 63) >> 5;
-                need = unknown_in(r0 - 1, r1, 0, 31, 31, 31);
-            }
-        }
-        SDF_CULL_PROF(24);
-        int n;
-        const int pos = ntl + block_exclusive_count<BLOCK>(need, wave_sums, n);
-        SDF_CULL_PROF(25);
-        if (need) tlist[pos] = (unsigned short)task;
-        ntl += n;
+        phase = 1; e0 = 0;
     }
     __syncthreads();
     SDF_CULL_PROF(20);
+    // the undecided sub-groups as bit rows: ub[h0 * 16 + h1] has bit h2 set (over the group states and the group list, done with)
+    unsigned short *ub = reinterpret_cast<unsigned short *>(scratch + CULL_GSTATE);    // 256 u16 = 512 B
+    for (int r = tid; r < 256; r += BLOCK) {
+        const unsigned long long lo8 = *reinterpret_cast<const unsigned long long *>(sstate + 16 * r);
+        const unsigned long long hi8 = *reinterpret_cast<const unsigned long long *>(sstate + 16 * r + 8);
+        unsigned m = 0;
+        SDF_UNROLL for (int k = 0; k < 8; k++) m |= ((lo8 >> (8 * k)) & 255ull) == 0ull ? 1u << k : 0u;
+        SDF_UNROLL for (int k = 0; k < 8; k++) m |= ((hi8 >> (8 * k)) & 255ull) == 0ull ? 256u << k : 0u;
+        ub[r] = (unsigned short)m;
+    }
+    __syncthreads();
+    // one thread per COLUMN (u0, u1) of units: unit u2 of the column is listed iff one of the sub-groups {u0 - 1, u0} x
+    // {u1 - 1, u1} x {u2 - 1, u2} is undecided; the listed units in ascending order
+    const int nu0 = (lx + 1) >> 1, nu1 = (ly + 1) >> 1, nu2 = (lz + 1) >> 1;           // units per axis (<= 17)
+    int nlisted = 0;
+    for (int q0 = 0; q0 < 17 * 17; q0 += BLOCK) {
+        const int q = q0 + tid, u0 = q / 17, u1 = q - 17 * u0;
+        unsigned um = 0;
+        if (q < 17 * 17 && u0 < nu0 && u1 < nu1) {
+            unsigned m = 0;
+            for (int d0 = 0; d0 < 2; d0++)
+                for (int d1 = 0; d1 < 2; d1++) {
+                    const int h0 = u0 - d0, h1 = u1 - d1;
+                    if (h0 >= 0 && h0 < 16 && h1 >= 0 && h1 < 16) m |= ub[h0 * 16 + h1];
+                }
+            um = (m | (m << 1)) & ((1u << nu2) - 1u);
+        }
+        int n;
+        int pos = nlisted + block_exclusive_scan<BLOCK>(__popc(um), wave_sums, n);
+        nlisted += n;
+        if (nlisted <= CULL_UNIT_CAP) {                                                // (uniform)
+            while (um) {
+                const int u2 = __ffs((int)um) - 1;
+                um &= um - 1u;
+                ulist[pos++] = (unsigned short)((u0 << 10) | (u1 << 5) | u2);
+            }
+        }
+    }
+    SDF_CULL_PROF(24);
+    if (nlisted > CULL_UNIT_CAP) { __syncthreads(); return -1; }                        // (uniform) nearly everything: the dense path is cheaper
+    if (tid < 8 && nlisted + tid < ((nlisted + 7) & ~7)) ulist[nlisted + tid] = 0xFFFFu;   // whole tasks
+    if (tid == 0) reinterpret_cast<unsigned short *>(scratch)[0] = (unsigned short)nlisted;
+    __syncthreads();
+    SDF_CULL_PROF(25);
 #undef SDF_CULL_PROF
-    return ntl;
+    return (nlisted + 7) >> 3;
 }
 
 // Stores of the soup.  Marking them non-temporal (so that 200 MB of output would not flush the parked
@@ -669,7 +699,13 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (w >= work_end) { if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x + 1] = wall_clock64(); break; }
         const int b = a.worklist[w];
         // k_cull's record of the batch (cull_tasks) travels next to the axes: into the list region, idle until phase 3
-        if (a.cull && tid < CULL_RECORD / 4) list[tid] = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[tid];
+        if (a.cull) {   // (the header word first, a uniform load: only the listed units and the sub-group states are fetched)
+            const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
+            const unsigned n0 = rec[0] & 0xFFFFu;
+            const int nwords = n0 == 0xFFFFu ? 1 : (int)((CULL_ULIST + 2u * ((n0 + 7u) & ~7u) + 3u) >> 2);
+            for (int i = tid; i < nwords; i += BLOCK) list[i] = rec[i];
+            if (n0 != 0xFFFFu) for (int i = tid; i < 1024; i += BLOCK) list[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
+        }
         int ox, oy, oz, lx, ly, lz;
         batch_origin(g, b, ox, oy, oz, lx, ly, lz);
         if (tid < lx) axes[tid] = g.X[ox + tid];
@@ -689,38 +725,40 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         const int nvox = tt.nvox, lyz = tt.lyz;
         const int wave = tid >> 6, lane = tid & 63;
         constexpr int NWAVE = BLOCK / 64;
-        // ---- 1a. groups of 4^3 cells whose interval excludes the surface are not sampled: k_cull left the
-        // list of tasks to evaluate and the sign of the decided groups (cull_tasks) ----
+        // ---- 1a. sub-groups of 2^3 cells whose interval excludes the surface are not sampled: k_cull left the
+        // list of units to evaluate and the sign of the decided sub-groups (cull_tasks) ----
         long long tsub = a.prof ? clock64() : 0;
 #define SDF_SUBPROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tsub)); tsub = tn; } } while (0)
-        const unsigned short *tlist = reinterpret_cast<const unsigned short *>(list) + 1;   // (the list region is idle while sampling)
-        const unsigned char *gstate = reinterpret_cast<const unsigned char *>(list) + CULL_GSTATE;
+        const unsigned short *units = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(list) + CULL_ULIST);   // (the list region is idle while sampling)
+        const unsigned char *sstate = reinterpret_cast<const unsigned char *>(list) + CULL_SSTATE;
         int ntl = tt.ntask;
         bool culled = false;
         if (a.cull) {
             const int n = (int)reinterpret_cast<const unsigned short *>(list)[0];
             culled = n != 0xFFFF;
             if (culled) {
-                ntl = n;
-                // Only SIGNS matter at the samples of decided groups (marching cubes reads values at the corners
-                // of cells with a sign change, and those lie in undecided groups): their bits of the sign-bit
-                // volume are set here straight from the group states -- no float is written for them -- and the
-                // evaluated samples OR theirs in as they are stored (1c).  A sample owned by an undecided group
-                // starts at 0; an evaluated sample owned by a decided group has the group's sign anyway.
+                ntl = (n + 7) >> 3;
+                // Only SIGNS matter at the samples of decided sub-groups (marching cubes reads values at the corners
+                // of cells with a sign change, and those lie in undecided sub-groups): their bits of the sign-bit
+                // volume are set here straight from the sub-group states -- no float is written for them -- and the
+                // evaluated samples OR theirs in as they are stored (1c).  A sample owned by an undecided sub-group
+                // starts at 0; an evaluated sample owned by a decided sub-group has the sub-group's sign anyway.
                 const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
                 const int nwords = (nvox + 63) >> 6;
                 for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;   // (+2: the row extraction reads one word ahead)
                 __syncthreads();
-                const int glast = (c2 - 1) >> 2;                                // the last group along z owns the boundary sample too
+                // <cull-sign-fill>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
+                const int hlast = (c2 - 1) >> 1;                                // the last sub-group along z owns the boundary sample too
                 for (int r = tid; r < lx * ly; r += BLOCK) {                    // a thread per row of lz samples along z
                     const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
-                    const unsigned long long st8 = *reinterpret_cast<const unsigned long long *>(gstate + ((min(ix, c0 - 1) >> 2) * 8 + (min(iy, c1 - 1) >> 2)) * 8);
+                    const unsigned char *row = sstate + ((min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)) * 16;
+                    const unsigned long long st8[2] = {*reinterpret_cast<const unsigned long long *>(row), *reinterpret_cast<const unsigned long long *>(row + 8)};
                     unsigned long long rowmask = 0ull;
                     SDF_UNROLL
-                    for (int gq = 0; gq < 8; gq++) {
-                        const int hi = gq == glast ? c2 : 4 * gq + 3;           // samples 4 gq .. hi
-                        if (gq <= glast && ((st8 >> (8 * gq)) & 255ull) == 1ull)
-                            rowmask |= ((2ull << hi) - 1ull) & ~((1ull << (4 * gq)) - 1ull);
+                    for (int hq = 0; hq < 16; hq++) {
+                        const int hi = hq == hlast ? c2 : 2 * hq + 1;           // samples 2 hq .. hi
+                        if (hq <= hlast && ((st8[hq >> 3] >> (8 * (hq & 7))) & 255ull) == 1ull)
+                            rowmask |= ((2ull << hi) - 1ull) & ~((1ull << (2 * hq)) - 1ull);
                     }
                     if (rowmask) {
                         const int o = r * lz, sh = o & 63;
@@ -728,26 +766,28 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         if (sh && (rowmask >> (64 - sh))) atomicOr(&bits[(o >> 6) + 1], rowmask >> (64 - sh));
                     }
                 }
+                // </cull-sign-fill>
                 // (no barrier: the evaluation below only ORs into the same words)
             }
         }
         if (tid == 0) atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
         SDF_SUBPROF(9);
         // ---- 1c. evaluate the listed tasks: NS per wave and pass ----
+        // <sample-loop>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
         for (int t0 = wave * NS; t0 < ntl; t0 += NWAVE * NS) {
             V px, py, pz;
             SDF_UNROLL
             for (int k = 0; k < NS; k++) {
                 const int tk = min(t0 + k, ntl - 1);
                 int ix, iy, iz;
-                tt.sample(culled ? (int)tlist[tk] : tk, lane, ix, iy, iz);
+                if (culled) cull_sample(units, tk, lane, lx, ly, lz, ix, iy, iz); else tt.sample(tk, lane, ix, iy, iz);
                 px.v[k] = (T)axes[ix]; py.v[k] = (T)axes[33 + iy]; pz.v[k] = (T)axes[66 + iz];
             }
             const V val = run_tape<T, FULL, NP, ND, NS>(wcode, consts, px, py, pz);
             SDF_UNROLL
             for (int k = 0; k < NS; k++) {   // (the sample index is worked out again rather than kept across the interpreter)
                 int ix, iy, iz;
-                const bool valid = t0 + k < ntl && tt.sample(culled ? (int)tlist[t0 + k] : t0 + k, lane, ix, iy, iz);
+                const bool valid = t0 + k < ntl && (culled ? cull_sample(units, t0 + k, lane, lx, ly, lz, ix, iy, iz) : tt.sample(t0 + k, lane, ix, iy, iz));
                 if (valid) {
                     const int i = ix * lyz + iy * tt.lz + iz;
                     const float fv = (float)val.v[k];
@@ -756,6 +796,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 }
             }
         }
+        // </sample-loop>
         __syncthreads();
         SDF_FRESH();
         SDF_SUBPROF(10);

@@ -278,10 +278,15 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     if (prof) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart1) : "s"(n_instr_w) : "memory");
     const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd, prof);
     const long long tw = prof ? clock64() : 0;
-    if (tid == 0) reinterpret_cast<unsigned short *>(scratch)[0] = ntl < 0 ? (unsigned short)0xFFFF : (unsigned short)ntl;
+    if (tid == 0 && ntl < 0) reinterpret_cast<unsigned short *>(scratch)[0] = (unsigned short)0xFFFF;   // (else: the number of listed units, cull_tasks)
     __syncthreads();
-    for (int i = tid; i < CULL_RECORD / 4; i += CB)
-        reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD)[i] = reinterpret_cast<const unsigned *>(scratch)[i];
+    {   // the record: header + the listed units (whole tasks), and the sub-group states
+        unsigned *rec = reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD);
+        const unsigned *src = reinterpret_cast<const unsigned *>(scratch);
+        const int nwords = ntl < 0 ? 1 : (CULL_ULIST + 16 * ntl + 3) >> 2;
+        for (int i = tid; i < nwords; i += CB) rec[i] = src[i];
+        if (ntl >= 0) for (int i = tid; i < 1024; i += CB) rec[CULL_SSTATE / 4 + i] = src[CULL_SSTATE / 4 + i];
+    }
     // ---- every work item of the tail of the list leaves its cost estimate for k_mesh, which hands the tail out by
     // descending cost (MeshArgs::order) ----
     if (order && tid == 0) {
@@ -289,7 +294,7 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
         if (tpos >= 0) order[tpos] = (ntl < 0 ? 563 : ntl) * max(n_instr_w, 1);
     }
     if (prof && tid == 0) {
-        const unsigned *pacc = reinterpret_cast<const unsigned *>(scratch + CULL_COUNT + 80 + 1024);
+        const unsigned *pacc = reinterpret_cast<const unsigned *>(scratch + CULL_PACC);
         atomicAdd(&prof[32 + (ntl < 0 ? 9 : min(ntl >> 6, 8))], 1ull);   // histogram of the listed tasks per work item, bins of 64
         atomicAdd(&prof[16], (unsigned long long)(tstart1 - tstart));
         atomicAdd(&prof[21], (unsigned long long)(clock64() - tw));
@@ -1206,8 +1211,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                            (const uint16_t *)t->d_lstart);
         HIPCHK(hipGetLastError());
     }
-    // second interval pass, per surviving batch: the groups of 4^3 cells the surface cannot be in are not sampled
-    const bool culling = c->cull && intervals_ok && t->ia_complete;
+    // second interval pass, per surviving batch: the sub-groups of 2^3 cells the surface cannot be in are not sampled
+    // (k_mesh reads the batch's record into the list region of its LDS, which has to hold it: launch_mesh's layout)
+    const size_t mesh_nvox = (size_t)(bs + 1) * (bs + 1) * (bs + 1);
+    const size_t mesh_bits_off = (MESH_LDS_VOL + mesh_nvox * 4 + 15) & ~(size_t)15;
+    const size_t mesh_list_off = (mesh_bits_off + ((mesh_nvox + 63) / 64 + 2) * 8 + 15) & ~(size_t)15;
+    const bool culling = c->cull && intervals_ok && t->ia_complete && mesh_list_off + CULL_RECORD <= c->lds_max;
     // the tail of the work list is handed out by descending cost (MeshArgs::order, k_cull's estimates); fewer items
     // than k_mesh has workgroups
     const int tail_max = std::min<int>(MESH_TAIL_MAX, std::min(nb, c->n_cu) - 1);
@@ -1230,7 +1239,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             cull_block = c->cull_block == 64 ? 64 : 128;
             kc = cull_block == 64 ? k_cull<true, false, 64> : k_cull<true, false, 128>;
         }
-        const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 4096);
+        const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 896 - CULL_SCRATCH);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
