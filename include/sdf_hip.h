@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 5
+#define SDF_ABI_VERSION 6
 
 #define SDF_PRECISION_F64 0 /* parity mode: float64 sampling like the reference's NumPy path */
 #define SDF_PRECISION_F32 1 /* fast mode: float32 sampling */
@@ -86,6 +86,15 @@ int sdf_ctx_set_cull(sdf_ctx *ctx, int enabled);
  * (sample + classify / number the triangles / emit), -1 = the library's choice by the tape's length (default; the
  * environment variable SDF_MESH_TWOPASS sets the initial state).  Results are identical either way. */
 int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
+/* Inside the one-kernel scheme: 1 (default; SDF_DEFER sets the initial state) = a culled batch keeps only the samples the
+ * interval pass listed (a sparse tile) and STAYS in the CU's LDS while the workgroup samples its next batch, so that its
+ * triangles are written once, in their final place, when the earlier batches' counts are known; 0 = dense tiles, a
+ * batch whose predecessors are not counted yet is parked in device memory and moved later (the r03 scheme).  Results are
+ * identical either way. */
+int sdf_ctx_set_defer(sdf_ctx *ctx, int on);
+/* interval levels of the second interval pass: 2 = boxes of 8^3 and groups of 4^3 cells, 3 = + sub-groups of 2^3 cells,
+ * 0 = the library's choice by the tape (default; SDF_CULL_LEVELS sets the initial state).  Results are identical. */
+int sdf_ctx_set_cull_levels(sdf_ctx *ctx, int levels);
 /* Scheduling of the meshing pass: 1 (default; SDF_TAIL_ORDER sets the initial state) = the last few hundred surviving
  * batches are handed to the workgroups by descending cost estimate instead of by position (shorter tail of the
  * kernel), 0 = strictly in list order.  Results are identical either way. */

@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "sdf_interp.h"
 #include "sdf_mc33.h"
@@ -85,6 +86,7 @@ struct MeshArgs {
     int park_cap;
     unsigned park_spins;           // polls of the predecessors' counts before a batch is parked
     const unsigned char *cull;     // NULL, or k_cull's records: per work item, the sampling tasks to evaluate (cull_tasks)
+    int slot_bytes;                // 0, or the size of one of the two slots of sparse tiles in the dense tile's region (deferred emission, k_mesh)
     // compact output (multi-GPU exchange, sdf_generate_compact_async): `out` then holds 9 FLOAT32 per triangle in the
     // batch's local voxel coordinates (what marching cubes itself produces, 36 bytes instead of 72) and xf[] the
     // per-work-item transform (offset[3], scale[3], indexed by w - work_begin) that k_expand applies after the gather
@@ -197,20 +199,12 @@ __device__ __forceinline__ unsigned cell_config(const unsigned long long *rb, in
 #ifndef SDF_FAST_VERTEX
 #define SDF_FAST_VERTEX 1
 #endif
-// One marching-cubes vertex on edge e of the cell at (i0,i1,i2); v points at the cell's corner 0
-// in a volume with strides (s0, s1, 1).  skimage's placement: with w = 1/(eps+|v|),
-// t = w_hi / (w_lo + w_hi), evaluated in float64 on the float32 samples, stored as float32.
-__device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0, int i1, int i2, int e, float *o) {
-    const int axis = e >> 2, oa = (e >> 1) & 1, ob = e & 1;
-    int o0, o1, o2, stride;
-    if (axis == 0) { o0 = 0; o1 = oa; o2 = ob; stride = s0; }
-    else if (axis == 1) { o0 = oa; o1 = 0; o2 = ob; stride = s1; }
-    else { o0 = oa; o1 = ob; o2 = 0; stride = 1; }
-    const int base = o0 * s0 + o1 * s1 + o2;
-    const double vlo = (double)v[base], vhi = (double)v[base + stride];
+// The coordinate of a marching-cubes vertex along its edge: samples vlo (at grid index ibase) and vhi (at ibase + 1).
+// skimage's placement: with w = 1/(eps+|v|), t = w_hi / (w_lo + w_hi), evaluated in float64 on the
+// float32 samples, stored as float32.
+__device__ __forceinline__ float mc_edge_pos(double vlo, double vhi, double ibase) {
     const double eps = 2.220446049250313e-16;
     const double a = eps + fabs(vlo), b = eps + fabs(vhi);
-    const double ibase = (double)(axis == 0 ? i0 : (axis == 1 ? i1 : i2));
     float pf;
 #if SDF_FAST_VERTEX
     // skimage's t = whi / (wlo + whi) with wlo = 1 / a, whi = 1 / b is a / (a + b) up to its three roundings (<= 5e-16
@@ -235,7 +229,55 @@ __device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0
         const double t = whi / (wlo + whi);
         pf = (float)(ibase + t);
     }
+    return pf;
+}
+// One marching-cubes vertex on edge e of the cell at (i0,i1,i2); v points at the cell's corner 0
+// in a volume with strides (s0, s1, 1).
+__device__ __forceinline__ void mc_vertex(const float *v, int s0, int s1, int i0, int i1, int i2, int e, float *o) {
+    const int axis = e >> 2, oa = (e >> 1) & 1, ob = e & 1;
+    int o0, o1, o2, stride;
+    if (axis == 0) { o0 = 0; o1 = oa; o2 = ob; stride = s0; }
+    else if (axis == 1) { o0 = oa; o1 = 0; o2 = ob; stride = s1; }
+    else { o0 = oa; o1 = ob; o2 = 0; stride = 1; }
+    const int base = o0 * s0 + o1 * s1 + o2;
+    const float pf = mc_edge_pos((double)v[base], (double)v[base + stride], (double)(axis == 0 ? i0 : (axis == 1 ? i1 : i2)));
     o[0] = axis == 0 ? pf : (float)(i0 + o0); o[1] = axis == 1 ? pf : (float)(i1 + o1); o[2] = axis == 2 ? pf : (float)(i2 + o2);
+}
+
+// ---- the tile of one batch as the marching phases of k_mesh see it -----------------------------
+// dense:  every sample of the (<= 33)^3 tile, x-major (what k_mesh sampled until r03).
+// sparse: ONLY the samples of the units k_cull listed (cull_tasks: units of 2^3 samples, the rest of the tile matters by
+//         its sign bits alone), eight floats per listed unit in the order of the list; `colinfo` (k_cull's column words:
+//         listed u2 of column (u0, u1) | index of the column's first listed unit << 17) finds a sample's unit.  A tile
+//         of the 512^3 example lists ~ 450 of its 4913 units: 14 KB instead of 144 KB, which is what lets TWO tiles live
+//         in the CU's LDS -- the batch being sampled and the previous one, whose triangles are written one batch later,
+//         when its predecessors have long published their counts (k_mesh: deferred emission).
+// Marching cubes reads values only at the corners of cells with a sign change; those lie in undecided sub-groups, whose
+// samples all belong to listed units (cull_tasks) -- `at` is never asked for a sample the sparse form does not hold.
+struct TileView {
+    const float *smp;
+    const unsigned *colinfo;
+    int lyz, lz;
+    bool sparse;                 // (workgroup-uniform)
+    __device__ __forceinline__ float at(int ix, int iy, int iz) const {
+        if (!sparse) return smp[ix * lyz + iy * lz + iz];
+        const unsigned c = colinfo[(ix >> 1) * 17 + (iy >> 1)];
+        const int k = (int)(c >> 17) + __popc(c & ((1u << (iz >> 1)) - 1u));
+        return smp[8 * k + ((ix & 1) << 2) + ((iy & 1) << 1) + (iz & 1)];
+    }
+    // the 8 corner samples of cell (i0, i1, i2) as a 2 x 2 x 2 volume (strides 4, 2, 1)
+    __device__ __forceinline__ void cell(int i0, int i1, int i2, float *c8) const {
+#pragma unroll
+        for (int q = 0; q < 8; q++) c8[q] = at(i0 + (q >> 2), i1 + ((q >> 1) & 1), i2 + (q & 1));
+    }
+};
+__device__ __forceinline__ void mc_vertex_view(const TileView &vw, int i0, int i1, int i2, int e, float *o) {
+    const int axis = e >> 2, oa = (e >> 1) & 1, ob = e & 1;
+    const int o0 = axis == 0 ? 0 : oa, o1 = axis == 0 ? oa : (axis == 1 ? 0 : ob), o2 = axis == 2 ? 0 : ob;
+    const int x = i0 + o0, y = i1 + o1, z = i2 + o2;
+    const float vlo = vw.at(x, y, z), vhi = vw.at(x + (axis == 0 ? 1 : 0), y + (axis == 1 ? 1 : 0), z + (axis == 2 ? 1 : 0));
+    const float pf = mc_edge_pos((double)vlo, (double)vhi, (double)(axis == 0 ? i0 : (axis == 1 ? i1 : i2)));
+    o[0] = axis == 0 ? pf : (float)x; o[1] = axis == 1 ? pf : (float)y; o[2] = axis == 2 ? pf : (float)z;
 }
 
 // ---- ordered allocation: exclusive prefix of the triangle counts over the work list -----------
@@ -380,10 +422,13 @@ struct TileTasks {
 // whole CU, and its registers would compete with the interpreter's.
 // record / scratch: [0] u16 unit count | CULL_ULIST: units | CULL_SSTATE: 16^3 sub-group states (0 unknown, 1 positive,
 // 2 negative) || scratch only, from CULL_RECORD: box states (64 B), group states (512 B), the groups to evaluate (512 u16)
-enum { CULL_UNIT_CAP = 3072, CULL_ULIST = 8, CULL_SSTATE = CULL_ULIST + 2 * CULL_UNIT_CAP, CULL_RECORD = CULL_SSTATE + 4096,
+// CULL_COLINFO: per COLUMN (u0, u1) of units one word, `listed u2 (17 bits) | index of the column's first listed unit << 17`:
+// with it k_mesh finds a sample of a listed unit in a tile that stores ONLY the listed units (TileView, sparse form)
+enum { CULL_UNIT_CAP = 3072, CULL_ULIST = 8, CULL_SSTATE = CULL_ULIST + 2 * CULL_UNIT_CAP, CULL_COLINFO = CULL_SSTATE + 4096,
+       CULL_RECORD = CULL_COLINFO + 1160,
        CULL_MSTATE = CULL_RECORD, CULL_GSTATE = CULL_MSTATE + 64, CULL_ELIST = CULL_GSTATE + 512, CULL_PACC = CULL_ELIST + 1024,
        CULL_SCRATCH = CULL_PACC + 64 };
-static_assert(CULL_RECORD % 8 == 0 && CULL_SSTATE % 8 == 0, "the record is copied in words; its state rows are read as u64");
+static_assert(CULL_RECORD % 8 == 0 && CULL_SSTATE % 8 == 0 && CULL_COLINFO % 8 == 0, "the record is copied in words; its state rows are read as u64");
 // sample `lane` of task `task` of a culled tile (units: the record's list); false: no such sample (ix, iy, iz are valid
 // indices all the same)
 __device__ __forceinline__ bool cull_sample(const unsigned short *units, int task, int lane, int lx, int ly, int lz, int &ix, int &iy, int &iz) {
@@ -396,7 +441,7 @@ __device__ __forceinline__ bool cull_sample(const unsigned short *units, int tas
 template <int BLOCK, bool FULL, bool RARE>
 __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *consts, int n_instr_w, int lx, int ly, int lz,
                                        const double *axes, double *ia_state, int ia_bytes, unsigned char *scratch, int *wave_sums,
-                                       int ia_np, int ia_nd, unsigned long long *prof = nullptr) {
+                                       int ia_np, int ia_nd, unsigned long long *prof = nullptr, int levels = 3) {
     const int tid = threadIdx.x;
     // SDF_MESH_PROF: cycles of thread 0 per phase, collected in LDS (12 words behind the group list) and added to the
     // global counters by the caller when the workgroup is done (an atomic per phase would stall the phases it measures:
@@ -432,7 +477,7 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
             __syncthreads();
             SDF_CULL_PROF(19);
             int nund = 0;
-            for (int g0 = 0; g0 < 512; g0 += BLOCK) {   // the undecided groups, compacted (elist is free: every listed group has been evaluated)
+            for (int g0 = 0; levels >= 3 && g0 < 512; g0 += BLOCK) {   // the undecided groups, compacted (elist is free: every listed group has been evaluated)
                 const int gi = g0 + tid;
                 const bool und = gi < 512 && gstate[gi] == 0;
                 int n;
@@ -446,7 +491,7 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
                 sstate[h] = exists ? gstate[((h0 >> 1) * 8 + (h1 >> 1)) * 8 + (h2 >> 1)] : 1;
             }
             __syncthreads();
-            phase = 2; e0 = 0; nev = 8 * nund;
+            phase = 2; e0 = 0; nev = 8 * nund;   // (two levels: none -- the sub-groups keep their groups' states)
         }
         if (phase == 2 && e0 >= nev) break;                                            // (uniform)
         const bool run = phase == 0 ? tid < 64 : (tid < per_pass && e0 + (tid & ~63) < nev);   // (whole waves)
@@ -509,6 +554,7 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
     // {u1 - 1, u1} x {u2 - 1, u2} is undecided; the listed units in ascending order
     const int nu0 = (lx + 1) >> 1, nu1 = (ly + 1) >> 1, nu2 = (lz + 1) >> 1;           // units per axis (<= 17)
     int nlisted = 0;
+    unsigned *colinfo = reinterpret_cast<unsigned *>(scratch + CULL_COLINFO);
     for (int q0 = 0; q0 < 17 * 17; q0 += BLOCK) {
         const int q = q0 + tid, u0 = q / 17, u1 = q - 17 * u0;
         unsigned um = 0;
@@ -524,6 +570,7 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
         int n;
         int pos = nlisted + block_exclusive_scan<BLOCK>(__popc(um), wave_sums, n);
         nlisted += n;
+        if (q < 17 * 17) colinfo[q] = um | ((unsigned)min(pos, 32767) << 17);
         if (nlisted <= CULL_UNIT_CAP) {                                                // (uniform)
             while (um) {
                 const int u2 = __ffs((int)um) - 1;
@@ -554,18 +601,27 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
 #define SDF_SOUP_STORE(PTR, VAL) (*(PTR) = (VAL))
 #endif
 
+// ---- deferred emission: the slots of sparse tiles ----------------------------------------------
+// The region of the dense tile ([MESH_LDS_VOL, bits_off) of dynamic LDS) holds TWO slots when tiles are sparse; a slot:
+//   [0, 64)        the batch as the emission needs it later: offset[3], scale[3] (double), work item, triangles, tasks
+//   [64, 1232)     k_cull's column words (TileView::colinfo)
+//   [1232, ..)     64 floats per listed task (eight units of 2^3 samples), then the batch's triangle list
+enum { MESH_SLOT_HDR = 1232, MESH_SLOT_COLINFO = 64 };
+
 template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK, bool TWOPASS = false>
 __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
     typedef Vec<T, NS> V;
     constexpr int RPT = 1024 / BLOCK;   // (i0, i1) rows of cells per thread (a tile has <= 32 x 32 rows)
+    constexpr int MESH_CELL_CHUNKS = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *wave_sums = reinterpret_cast<int *>(smem);                 // 16 ints
     int *bcast = wave_sums + 16;                                    // 16 ints of scratch
     unsigned char *ntri_lds = smem + MESH_LDS_NTRI;                 // 256 B: ntri | ambiguous << 7
     double *axes = reinterpret_cast<double *>(smem + MESH_LDS_AXES);  // 3 * 33 doubles (X, Y, Z of the tile)
-    float *vol = reinterpret_cast<float *>(smem + MESH_LDS_VOL);    // (bs+1)^3 floats
+    float *vol = reinterpret_cast<float *>(smem + MESH_LDS_VOL);    // (bs+1)^3 floats: the dense tile
     unsigned long long *bits = reinterpret_cast<unsigned long long *>(smem + a.bits_off);   // 1 bit per sample: value > 0
-    unsigned *list = reinterpret_cast<unsigned *>(smem + a.list_off);
+    // behind the sign bits: k_cull's record of the batch while it is sampled; the cell table and triangle list of a DENSE tile
+    unsigned *wlist = reinterpret_cast<unsigned *>(smem + a.list_off);
     // `tid` is made opaque to the optimiser at every phase boundary (SDF_FRESH): whatever a phase derives
     // from it is worked out again there instead of being kept -- i.e. spilled -- across the interpreter
     int tid = threadIdx.x;
@@ -590,7 +646,6 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         else if (excl + total_ > a.out_cap) atomicOr(&a.ctr->overflow, 1u);
         if (w_ == work_end - 1 && excl != ~0ull) a.ctr->total = excl + total_;
     };
-    // the parked batch of this workgroup (all values workgroup-uniform)
     // The parked batches of this workgroup: a FIFO of up to MESH_PARK_DEPTH, each in its own staging slot (all
     // values workgroup-uniform).  Sampling times differ a lot between batches (pruned tapes, culled tiles): with
     // ONE slot a workgroup that met a slow predecessor twice in a row stood still -- 12 % of the kernel's
@@ -659,54 +714,106 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             __syncthreads();   // (bcast is reused)
         }
     };
+    // ---- deferred emission ----
+    // A batch whose predecessors are still sampling when it has been counted used to be PARKED: its triangles went to a
+    // staging slot as 9 floats each and were moved to their place one batch later -- 97 % of the batches of the 512^3
+    // example, 2.4 x the soup's bytes through the memory system and a tenth of the kernel spent moving them.  With sparse
+    // tiles (TileView) the counted batch simply STAYS in LDS -- its listed samples, its column words, its triangle list,
+    // in one of two slots -- while the workgroup samples and counts its next batch in the other slot; then, one batch
+    // later, the look-back finds every predecessor published and the triangles are written ONCE, as float64, where they
+    // belong.  What cannot be deferred -- a tile that is not culled or lists too many units (it takes the whole region:
+    // a waiting batch is written first), a batch whose triangle list does not fit -- goes the old way, and so does a
+    // deferred batch whose predecessors are STILL not done one batch later (it is parked then; nothing ever waits).
     // (Taking the NEXT work item early -- thread 0 issuing the atomic and the work-list load behind the sampling phase, so
     // that their two dependent round trips hide behind counting and emit -- was built and measured in r02: the time
     // at the top of the loop did not move (it is the barrier and the record / axis loads, not the atomic), and the two
     // values carried across the phases cost the 2- and 4-slot variants 6 - 9 more spilled registers: k_mesh
     // 0.288 -> 0.300 ms.  Rejected.)
+    const int slot_bytes = TWOPASS ? 0 : a.slot_bytes;
+    auto slot_base = [&](int s_) { return smem + MESH_LDS_VOL + (size_t)s_ * (size_t)slot_bytes; };
+    int dq_slot = -1;          // the slot of the counted batch whose triangles are still to be written (-1: none)
+    bool carry = false;        // the work item in `w` was taken in the previous round (which only wrote the waiting batch)
+    int w = 0;
     for (;;) {
         SDF_FRESH();
-        if (tid == 0) { const int idx = (int)atomicAdd(&a.ctr->work_counter, 1u); bcast[0] = work_begin + idx; bcast[1] = idx; }
-        __syncthreads();
-        int w = bcast[0];
-        // Items are handed out in list order, so that the predecessors of a batch are always held by running
-        // workgroups -- except inside the tail, which goes by descending cost (MeshArgs::order): the r-th workgroup to
-        // arrive there takes the item of rank r (every thread ranks one item among the tail's <= 255 costs; ties by
-        // position).  That is safe: a batch publishes its COUNT before anything that can wait, so the look-back
-        // needs every earlier batch to be sampled, no more; a workgroup that waits (full FIFO, a batch too large to
-        // park) holds one item of the tail at most that others wait for, and the tail has fewer items than there are
-        // workgroups, hence some workgroup is always free to take the item everybody waits for.
-        {
-            const int n_work = work_end - work_begin, tail = min(a.tail, n_work), r = bcast[1] - (n_work - tail);
-            if (a.order && r >= 0 && r < tail) {   // (uniform)
-                int *cost = reinterpret_cast<int *>(list), *rnk = cost + 256;   // (the list region is idle here)
-                for (int i = tid; i < 256; i += BLOCK) { cost[i] = i < tail ? a.order[i] : -1; rnk[i] = 0; }
-                __syncthreads();
-                {   // item i = tid % 256 against a quarter (half) of the others, the partial ranks added up in LDS
-                    constexpr int PARTS = BLOCK / 256, SPAN = 256 / PARTS;
-                    const int i = tid & 255, j0 = (tid >> 8) * SPAN, ci = cost[i];
-                    int part = 0;
-                    for (int j = j0; j < j0 + SPAN; j++) { const int cj = cost[j]; part += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
-                    if (part) atomicAdd(&rnk[i], part);
+        if (!carry) {
+            if (tid == 0) { const int idx = (int)atomicAdd(&a.ctr->work_counter, 1u); bcast[0] = work_begin + idx; bcast[1] = idx; }
+            __syncthreads();
+            w = bcast[0];
+            // Items are handed out in list order, so that the predecessors of a batch are always held by running
+            // workgroups -- except inside the tail, which goes by descending cost (MeshArgs::order): the r-th workgroup to
+            // arrive there takes the item of rank r (every thread ranks one item among the tail's <= 255 costs; ties by
+            // position).  That is safe: a batch publishes its COUNT before anything that can wait, so the look-back
+            // needs every earlier batch to be sampled, no more; a workgroup that waits (full FIFO, a batch too large to
+            // park) holds one item of the tail at most that others wait for, and the tail has fewer items than there are
+            // workgroups, hence some workgroup is always free to take the item everybody waits for.
+            {
+                const int n_work = work_end - work_begin, tail = min(a.tail, n_work), r = bcast[1] - (n_work - tail);
+                if (a.order && r >= 0 && r < tail) {   // (uniform)
+                    int *cost = reinterpret_cast<int *>(wlist), *rnk = cost + 256;   // (the work area is idle here)
+                    for (int i = tid; i < 256; i += BLOCK) { cost[i] = i < tail ? a.order[i] : -1; rnk[i] = 0; }
+                    __syncthreads();
+                    {   // item i = tid % 256 against a quarter (half) of the others, the partial ranks added up in LDS
+                        constexpr int PARTS = BLOCK / 256, SPAN = 256 / PARTS;
+                        const int i = tid & 255, j0 = (tid >> 8) * SPAN, ci = cost[i];
+                        int part = 0;
+                        for (int j = j0; j < j0 + SPAN; j++) { const int cj = cost[j]; part += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+                        if (part) atomicAdd(&rnk[i], part);
+                    }
+                    __syncthreads();
+                    if (tid < tail && rnk[tid] == r) bcast[0] = work_end - tail + tid;
+                    __syncthreads();
+                    w = bcast[0];
+                    __syncthreads();   // (the work area takes the batch's record next)
                 }
-                __syncthreads();
-                if (tid < tail && rnk[tid] == r) bcast[0] = work_end - tail + tid;
-                __syncthreads();
-                w = bcast[0];
-                __syncthreads();   // (the list region takes the batch's record next)
             }
+            w = __builtin_amdgcn_readfirstlane(w);
         }
-        if (w >= work_end) { if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x + 1] = wall_clock64(); break; }
-        const int b = a.worklist[w];
-        // k_cull's record of the batch (cull_tasks) travels next to the axes: into the list region, idle until phase 3
-        if (a.cull) {   // (the header word first, a uniform load: only the listed units and the sub-group states are fetched)
+        carry = false;
+        const bool finished = w >= work_end;
+        if (finished && a.prof && tid == 0 && a.prof[64 + 4 * blockIdx.x + 1] == 0) a.prof[64 + 4 * blockIdx.x + 1] = wall_clock64();
+        if (finished && dq_slot < 0) break;
+        // ---- what kind of tile?  (the header word of k_cull's record: a uniform load) ----
+        bool flush_only = finished;   // this round only writes the waiting batch
+        int b = 0, ntl_cull = -1;     // listed tasks of a culled tile (-1: not culled)
+        bool sparse = false;
+        if (!finished) {
+            b = __builtin_amdgcn_readfirstlane(a.worklist[w]);
+            if (a.cull) {
+                const unsigned n0 = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[0]) & 0xFFFFu;
+                if (n0 != 0xFFFFu) ntl_cull = (int)((n0 + 7u) >> 3);
+            }
+            sparse = ntl_cull >= 0 && slot_bytes > 0 && MESH_SLOT_HDR + 256 * ntl_cull + 4 * MESH_CELL_CHUNKS * BLOCK <= slot_bytes;
+            if (!sparse && dq_slot >= 0) { flush_only = true; carry = true; }   // a dense tile takes the slots' region
+        }
+        const bool culled = ntl_cull >= 0;
+        const int cur_slot = dq_slot == 0 ? 1 : 0;
+        // the current batch: where its samples, its cell table / triangle list live
+        unsigned char *cs = slot_base(sparse ? cur_slot : 0);
+        float *smp = reinterpret_cast<float *>(cs + MESH_SLOT_HDR);
+        unsigned *clist = sparse ? reinterpret_cast<unsigned *>(cs + MESH_SLOT_HDR + 256 * ntl_cull) : wlist;
+        const int lcap = sparse ? min((slot_bytes - MESH_SLOT_HDR - 256 * ntl_cull) >> 2, 16384) : a.list_cap;
+        int lx = 2, ly = 2, lz = 2, lyz = 4;
+        int row_tris[RPT], row_off[RPT], row_cell0[RPT];
+        unsigned row_mask[RPT];
+        unsigned long long row_bits[RPT][4];   // sign bits of the four sample rows (o0, o1) of a cell row
+        // (left uninitialised on purpose: written by the counting of THIS batch, read by its own emission only -- zeroes here
+        // would be carried through the interpreter in registers)
+        int total = 0, c1 = 1;
+        float inv_c1 = 1.0f;
+        bool list_ready = false, emit_cur = false;
+        unsigned long long pre_own = 0, pre_dq = 0;
+        if (!flush_only) {
+        // k_cull's record of the batch (cull_tasks) travels next to the axes: units and sub-group states into the work area
+        // (idle until the cells of a dense tile are listed), the column words into the batch's slot
+        if (culled) {
             const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
-            const unsigned n0 = rec[0] & 0xFFFFu;
-            const int nwords = n0 == 0xFFFFu ? 1 : (int)((CULL_ULIST + 2u * ((n0 + 7u) & ~7u) + 3u) >> 2);
-            for (int i = tid; i < nwords; i += BLOCK) list[i] = rec[i];
-            if (n0 != 0xFFFFu) for (int i = tid; i < 1024; i += BLOCK) list[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
+            const int nwords = (CULL_ULIST + 16 * ntl_cull + 3) >> 2;
+            for (int i = tid; i < nwords; i += BLOCK) wlist[i] = rec[i];
+            for (int i = tid; i < 1024; i += BLOCK) wlist[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
+            if (sparse) for (int i = tid; i < 289; i += BLOCK) reinterpret_cast<unsigned *>(cs + MESH_SLOT_COLINFO)[i] = rec[CULL_COLINFO / 4 + i];
         }
-        int ox, oy, oz, lx, ly, lz;
+        int ox, oy, oz;
         batch_origin(g, b, ox, oy, oz, lx, ly, lz);
         if (tid < lx) axes[tid] = g.X[ox + tid];
         else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
@@ -717,62 +824,59 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // ---- 1. sample: volume = sdf(P).reshape(shape), cast to float32 (core.py:50-52) ----
         // (with the interval prepass on, this batch has its own tape with the irrelevant instructions removed)
         // (`code` stays the base of every address so that the loads remain scalar loads from a read-only
-        // kernel argument; w comes out of LDS, hence the readfirstlane)
+        // kernel argument; b comes out of LDS, hence the readfirstlane)
         const uint32_t *wcode = code + (size_t)__builtin_amdgcn_readfirstlane(b) * (size_t)a.tape_stride * 2;
         if (a.tape_stride && tid == 0)
             atomicAdd(&a.ctr->n_pruned, (unsigned long long)a.n_instr - reinterpret_cast<const unsigned long long *>(wcode)[a.tape_stride - 1]);
         const TileTasks tt(lx, ly, lz);
-        const int nvox = tt.nvox, lyz = tt.lyz;
+        const int nvox = tt.nvox;
+        lyz = tt.lyz;
         const int wave = tid >> 6, lane = tid & 63;
         constexpr int NWAVE = BLOCK / 64;
         // ---- 1a. sub-groups of 2^3 cells whose interval excludes the surface are not sampled: k_cull left the
         // list of units to evaluate and the sign of the decided sub-groups (cull_tasks) ----
         long long tsub = a.prof ? clock64() : 0;
 #define SDF_SUBPROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tsub)); tsub = tn; } } while (0)
-        const unsigned short *units = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(list) + CULL_ULIST);   // (the list region is idle while sampling)
-        const unsigned char *sstate = reinterpret_cast<const unsigned char *>(list) + CULL_SSTATE;
+        const unsigned short *units = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(wlist) + CULL_ULIST);
+        const unsigned char *sstate = reinterpret_cast<const unsigned char *>(wlist) + CULL_SSTATE;
         int ntl = tt.ntask;
-        bool culled = false;
-        if (a.cull) {
-            const int n = (int)reinterpret_cast<const unsigned short *>(list)[0];
-            culled = n != 0xFFFF;
-            if (culled) {
-                ntl = (n + 7) >> 3;
-                // Only SIGNS matter at the samples of decided sub-groups (marching cubes reads values at the corners
-                // of cells with a sign change, and those lie in undecided sub-groups): their bits of the sign-bit
-                // volume are set here straight from the sub-group states -- no float is written for them -- and the
-                // evaluated samples OR theirs in as they are stored (1c).  A sample owned by an undecided sub-group
-                // starts at 0; an evaluated sample owned by a decided sub-group has the sub-group's sign anyway.
-                const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
-                const int nwords = (nvox + 63) >> 6;
-                for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;   // (+2: the row extraction reads one word ahead)
-                __syncthreads();
-                // <cull-sign-fill>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
-                const int hlast = (c2 - 1) >> 1;                                // the last sub-group along z owns the boundary sample too
-                for (int r = tid; r < lx * ly; r += BLOCK) {                    // a thread per row of lz samples along z
-                    const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
-                    const unsigned char *row = sstate + ((min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)) * 16;
-                    const unsigned long long st8[2] = {*reinterpret_cast<const unsigned long long *>(row), *reinterpret_cast<const unsigned long long *>(row + 8)};
-                    unsigned long long rowmask = 0ull;
-                    SDF_UNROLL
-                    for (int hq = 0; hq < 16; hq++) {
-                        const int hi = hq == hlast ? c2 : 2 * hq + 1;           // samples 2 hq .. hi
-                        if (hq <= hlast && ((st8[hq >> 3] >> (8 * (hq & 7))) & 255ull) == 1ull)
-                            rowmask |= ((2ull << hi) - 1ull) & ~((1ull << (2 * hq)) - 1ull);
-                    }
-                    if (rowmask) {
-                        const int o = r * lz, sh = o & 63;
-                        atomicOr(&bits[o >> 6], rowmask << sh);
-                        if (sh && (rowmask >> (64 - sh))) atomicOr(&bits[(o >> 6) + 1], rowmask >> (64 - sh));
-                    }
+        if (culled) {
+            ntl = ntl_cull;
+            // Only SIGNS matter at the samples of decided sub-groups (marching cubes reads values at the corners
+            // of cells with a sign change, and those lie in undecided sub-groups): their bits of the sign-bit
+            // volume are set here straight from the sub-group states -- no float is written for them -- and the
+            // evaluated samples OR theirs in as they are stored (1c).  A sample owned by an undecided sub-group
+            // starts at 0; an evaluated sample owned by a decided sub-group has the sub-group's sign anyway.
+            const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
+            const int nwords = (nvox + 63) >> 6;
+            for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;   // (+2: the row extraction reads one word ahead)
+            __syncthreads();
+            // <cull-sign-fill>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
+            const int hlast = (c2 - 1) >> 1;                                // the last sub-group along z owns the boundary sample too
+            for (int r = tid; r < lx * ly; r += BLOCK) {                    // a thread per row of lz samples along z
+                const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
+                const unsigned char *row = sstate + ((min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)) * 16;
+                const unsigned long long st8[2] = {*reinterpret_cast<const unsigned long long *>(row), *reinterpret_cast<const unsigned long long *>(row + 8)};
+                unsigned long long rowmask = 0ull;
+                SDF_UNROLL
+                for (int hq = 0; hq < 16; hq++) {
+                    const int hi = hq == hlast ? c2 : 2 * hq + 1;           // samples 2 hq .. hi
+                    if (hq <= hlast && ((st8[hq >> 3] >> (8 * (hq & 7))) & 255ull) == 1ull)
+                        rowmask |= ((2ull << hi) - 1ull) & ~((1ull << (2 * hq)) - 1ull);
                 }
-                // </cull-sign-fill>
-                // (no barrier: the evaluation below only ORs into the same words)
+                if (rowmask) {
+                    const int o = r * lz, sh = o & 63;
+                    atomicOr(&bits[o >> 6], rowmask << sh);
+                    if (sh && (rowmask >> (64 - sh))) atomicOr(&bits[(o >> 6) + 1], rowmask >> (64 - sh));
+                }
             }
+            // </cull-sign-fill>
+            // (no barrier: the evaluation below only ORs into the same words)
         }
         if (tid == 0) atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
         SDF_SUBPROF(9);
-        // ---- 1c. evaluate the listed tasks: NS per wave and pass ----
+        // ---- 1c. evaluate the listed tasks: NS per wave and pass.  A sparse tile keeps sample `lane` of task t at
+        // smp[64 t + lane] (unit 8 t + lane / 8 of the list, sample lane % 8 of the unit: TileView::at) ----
         // <sample-loop>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
         for (int t0 = wave * NS; t0 < ntl; t0 += NWAVE * NS) {
             V px, py, pz;
@@ -791,7 +895,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (valid) {
                     const int i = ix * lyz + iy * tt.lz + iz;
                     const float fv = (float)val.v[k];
-                    vol[i] = fv;
+                    if (sparse) smp[64 * (t0 + k) + lane] = fv; else vol[i] = fv;
                     if (culled && fv > 0.0f) atomicOr(&bits[i >> 6], 1ull << (i & 63));
                 }
             }
@@ -819,22 +923,22 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
 #undef SDF_SUBPROF
         SDF_PROF(1);
         SDF_FRESH();
+        const TileView cvw{sparse ? smp : vol, reinterpret_cast<const unsigned *>(cs + MESH_SLOT_COLINFO), lyz, lz, sparse};
 
         // ---- 2. count: a thread owns the i2-rows of cells (i0, i1) = row tid + k * BLOCK ----
-        // (wave 0 first asks for the predecessors' status words -- of this batch and of the parked one --
-        // so that the answers arrive while the cells are counted)
-        unsigned long long pre_own = 0, pre_pend = 0;
+        // (wave 0 first asks for the predecessors' status words -- of this batch, of the waiting one and of the oldest
+        // parked one -- so that the answers arrive while the cells are counted)
+        unsigned long long pre_pend = 0;
         if (tid < 64 && !TWOPASS) {
-            pre_own = lookback_prefetch(a.status, w, work_begin);
+            if (!sparse) pre_own = lookback_prefetch(a.status, w, work_begin);   // (a sparse tile's batch waits a round: asked for then)
+            if (dq_slot >= 0) pre_dq = lookback_prefetch(a.status, reinterpret_cast<const int *>(slot_base(dq_slot) + 48)[0], work_begin);
             if (pq_count > 0) pre_pend = lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin);
         }
-        const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
+        const int c0 = lx - 1, c2 = lz - 1;
+        c1 = ly - 1;
         const int nrows = (c0 > 0 && c1 > 0 && c2 > 0) ? c0 * c1 : 0;
-        const float inv_c1 = 1.0f / (float)max(c1, 1);
-        int row_tris[RPT], row_off[RPT];
-        unsigned row_mask[RPT];
-        unsigned long long row_bits[RPT][4];   // sign bits of the four sample rows (o0, o1) of a cell row
-        int total = 0, my_amb = 0;
+        inv_c1 = 1.0f / (float)max(c1, 1);
+        int my_amb = 0;
         // sign strings of the four sample rows around cell row (i0, i1) and the mask of its surface cells
         auto row_signs = [&](int i0, int i1, unsigned long long *rb) -> unsigned {
             SDF_UNROLL
@@ -850,8 +954,17 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             const unsigned long long ones = all & (all >> 1), zeros = ~any & ~(any >> 1);
             return (unsigned)(~(ones | zeros)) & (c2 >= 32 ? 0xFFFFFFFFu : ((1u << c2) - 1u));
         };
+        // triangles of an ambiguous cell: Lewiner's tests on its 8 corner samples pick the tiling (rare)
+        auto amb_count = [&](int i0, int i1, int i2) -> int {
+            float c8[8];
+            double lv[8];
+            int off;
+            cvw.cell(i0, i1, i2, c8);
+            mc33_load_cell(c8, 4, 2, lv);
+            return mc33_cell(lv, a.mc->mc33, &off);
+        };
         // ---- 2a. surface cells per row, their running count over the rows (the order of the soup) ----
-        int ncells = 0, row_cell0[RPT];
+        int ncells = 0;
         SDF_UNROLL
         for (int k = 0; k < RPT; k++) {
             const int r = tid + k * BLOCK;
@@ -867,7 +980,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             ncells += tot;
         }
         // ---- 2b. ONE THREAD PER SURFACE CELL (up to MESH_CELL_CHUNKS * BLOCK of them).  The row's thread only
-        // SCATTERS its cells -- (row, column, sign configuration) into a table at the cell's running index, a few
+        // SCATTERS its cells -- (row, column) into a table at the cell's running index, a few
         // ALU instructions and one LDS write each, nothing to wait for; then thread s takes cell s: looks up its
         // triangles and, after a scan, writes them into the triangle list right away.  A thread per ROW used to
         // walk its surface cells one dependent LDS look-up after the other, here and again when the list was
@@ -876,12 +989,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // more cells, or more triangles than the list holds, take the per-row path below.  (The table lives in
         // the list region: every thread has read its entry before the scan's barriers, the list is written
         // behind them.) ----
-        bool list_ready = false;
-        constexpr int MESH_CELL_CHUNKS = 2;
         unsigned cinfo[MESH_CELL_CHUNKS];
         int cn[MESH_CELL_CHUNKS], coff[MESH_CELL_CHUNKS];
         bool per_cell = false;            // the per-cell path ran (cinfo / cn / coff are valid)
-        if (ncells <= MESH_CELL_CHUNKS * BLOCK && (size_t)a.list_cap >= (size_t)MESH_CELL_CHUNKS * BLOCK) {
+        if (ncells <= MESH_CELL_CHUNKS * BLOCK && lcap >= MESH_CELL_CHUNKS * BLOCK) {
             SDF_UNROLL
             for (int k = 0; k < RPT; k++) {
                 const int r = tid + k * BLOCK;
@@ -890,7 +1001,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 while (m) {
                     const int i2 = __ffs((int)m) - 1;
                     m &= m - 1u;
-                    list[pos++] = (unsigned)r | ((unsigned)i2 << 10);   // (the cell's thread works out the configuration: below)
+                    clist[pos++] = (unsigned)r | ((unsigned)i2 << 10);   // (the cell's thread works out the configuration: below)
                 }
             }
             __syncthreads();
@@ -901,7 +1012,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 int n = 0;
                 unsigned info = 0;
                 if (sidx < ncells) {
-                    const unsigned ce = list[sidx];
+                    const unsigned ce = clist[sidx];
                     const int r = (int)(ce & 1023u), i2 = (int)((ce >> 10) & 31u), i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
                     // the sign configuration from the row's four sign strings, read again here: in the scatter above it
                     // cost the thread of a row ~40 instructions per surface cell, one cell after the other -- 32 in a row
@@ -910,15 +1021,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     row_signs(i0, i1, rb);
                     const unsigned cfg = cell_config(rb, i2);
                     const unsigned e = ntri_lds[cfg];
-                    if (e & 128u) {   // ambiguous configuration: Lewiner's tests pick the tiling (rare)
-                        double lv[8];
-                        int off;
-                        mc33_load_cell(vol + i0 * lyz + i1 * lz + i2, lyz, lz, lv);
-                        n = mc33_cell(lv, a.mc->mc33, &off);
-                        my_amb++;
-                    } else {
-                        n = (int)(e & 7u);
-                    }
+                    if (e & 128u) { n = amb_count(i0, i1, i2); my_amb++; }
+                    else n = (int)(e & 7u);
                     // entry: cell (15 bits) | ambiguous (1) | configuration (8) | triangle in cell (4)
                     info = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((e & 128u) << 5) | (cfg << 4);
                 }
@@ -929,10 +1033,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
             if (TWOPASS) {
                 list_ready = true;        // (no list in LDS: the entries go to the arena below)
-            } else if (total <= a.list_cap) {
+            } else if (total <= lcap) {
                 SDF_UNROLL
                 for (int k = 0; k < MESH_CELL_CHUNKS; k++)
-                    for (int j = 0; j < cn[k]; j++) list[coff[k] + j] = cinfo[k] | (unsigned)j;
+                    for (int j = 0; j < cn[k]; j++) clist[coff[k] + j] = cinfo[k] | (unsigned)j;
                 list_ready = true;        // (made visible by the barriers of the allocation below)
             } else {
                 per_cell = false;
@@ -953,15 +1057,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         const int i2 = __ffs((int)m) - 1;
                         m &= m - 1u;
                         const unsigned e = ntri_lds[cell_config(row_bits[k], i2)];
-                        if (e & 128u) {
-                            double lv[8];
-                            int off;
-                            mc33_load_cell(vol + i0 * lyz + i1 * lz + i2, lyz, lz, lv);
-                            n += mc33_cell(lv, a.mc->mc33, &off);
-                            my_amb++;
-                        } else {
-                            n += (int)(e & 7u);
-                        }
+                        if (e & 128u) { n += amb_count(i0, i1, i2); my_amb++; }
+                        else n += (int)(e & 7u);
                     }
                 }
                 row_tris[k] = n;
@@ -1013,11 +1110,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             if (total && cell_base != ~0ull) {
                 auto put_cell = [&](unsigned long long idx, unsigned info, int i0, int i1, int i2) {
                     unsigned *rec = a.cells + idx * 9ull;
-                    const float *corner = vol + i0 * lyz + i1 * lz + i2;
+                    float c8[8];
+                    cvw.cell(i0, i1, i2, c8);
                     rec[0] = info;
                     SDF_UNROLL
-                    for (int q = 0; q < 8; q++)     // corner q = 4 * o0 + 2 * o1 + o2
-                        rec[1 + q] = __float_as_uint(corner[(q >> 2) * lyz + ((q >> 1) & 1) * lz + (q & 1)]);
+                    for (int q = 0; q < 8; q++) rec[1 + q] = __float_as_uint(c8[q]);   // corner q = 4 * o0 + 2 * o1 + o2
                 };
                 if (per_cell) {
                     SDF_UNROLL
@@ -1043,12 +1140,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                             const unsigned cfg = cell_config(row_bits[k], i2);
                             const unsigned en = ntri_lds[cfg];
                             int n = (int)(en & 7u);
-                            if (en & 128u) {
-                                double lv[8];
-                                int off;
-                                mc33_load_cell(vol + i0 * lyz + i1 * lz + i2, lyz, lz, lv);
-                                n = mc33_cell(lv, a.mc->mc33, &off);
-                            }
+                            if (en & 128u) n = amb_count(i0, i1, i2);
                             put_cell(cell_base + (unsigned long long)sidx, ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((en & 128u) << 5) | (cfg << 4), i0, i1, i2);
                             for (int j = 0; j < n; j++, pos++) a.tlist[list_base + (unsigned long long)pos] = ((unsigned)sidx << 4) | (unsigned)j;
                             sidx++;
@@ -1064,105 +1156,144 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         { const long long tp0 = a.prof ? clock64() : 0;
         place_parked(pre_pend, false);
         if (a.prof && tid == 0) atomicAdd(&a.prof[6], (unsigned long long)(clock64() - tp0)); }
-        // ---- ordered allocation (wave 0): take the position if every predecessor has published its
-        // count, else park this batch instead of waiting for them ----
-        const bool may_park = a.park && total <= a.park_cap;
-        if (tid < 64) {
-            const unsigned long long excl = ordered_base(a.status, w, work_begin, (unsigned long long)total, may_park ? a.park_spins : MESH_SPIN_FOREVER, pre_own);
+        // ---- this batch: its triangles are written one batch later (it stays in its slot), or right away ----
+        if (sparse && list_ready) {
             if (tid == 0) {
-                if (excl != MESH_NOT_READY) settle(w, excl, (unsigned long long)total);
-                reinterpret_cast<unsigned long long *>(bcast + 2)[0] = excl;
+                double *xf = reinterpret_cast<double *>(cs);
+                xf[0] = axes[0]; xf[1] = axes[33]; xf[2] = axes[66];
+                xf[3] = axes[1] - axes[0]; xf[4] = axes[34] - axes[33]; xf[5] = axes[67] - axes[66];
+                int *m = reinterpret_cast<int *>(cs + 48);
+                m[0] = w; m[1] = total; m[2] = ntl_cull;
             }
-        }
-        __syncthreads();
-        const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
-        const bool parking = base == MESH_NOT_READY;
-        const bool fits = parking || (base != ~0ull && base + (unsigned long long)total <= a.out_cap);
-        // points * scale + offset (reference sdf/core.py:58-60): scale = first axis step of the
-        // batch, offset = its first sample, per axis
-        const double of0 = axes[0], of1 = axes[33], of2 = axes[66];
-        const double sc0 = axes[1] - of0, sc1 = axes[34] - of1, sc2 = axes[67] - of2;
-        const int park_slot = (pq_head + pq_count) % MESH_PARK_DEPTH;   // (the FIFO has room: a full one was waited for above)
-        if (parking) {
-            if (tid == 0) {
-                double *xf = pend_xf(park_slot);
-                xf[0] = of0; xf[1] = of1; xf[2] = of2; xf[3] = sc0; xf[4] = sc1; xf[5] = sc2;
-                pend_wt(park_slot)[0] = w; pend_wt(park_slot)[1] = total;
-            }
-            pq_count++;
-            if (a.prof && tid == 0) atomicAdd(&a.prof[7], 1ull);
-        }
+        } else emit_cur = true;
         SDF_PROF(2);
+        }   // (!flush_only)
         SDF_FRESH();
+        __syncthreads();   // (the slot's header)
 
-        // ---- 3 + 4. per-triangle work list in LDS, then one lane per triangle ----
-        for (int lo = 0; fits && lo < total; lo += a.list_cap) {
-            const int cn = min(a.list_cap, total - lo);
-            SDF_UNROLL
-            for (int k = 0; k < RPT; k++) {
-                if (list_ready || row_tris[k] == 0 || row_off[k] >= lo + cn || row_off[k] + row_tris[k] <= lo) continue;
-                const int r = tid + k * BLOCK;
-                const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
-                const float *row = vol + i0 * lyz + i1 * lz;
-                int pos = row_off[k] - lo;
-                unsigned m = row_mask[k];
-                while (m) {
-                    const int i2 = __ffs((int)m) - 1;
-                    m &= m - 1u;
-                    const unsigned cfg = cell_config(row_bits[k], i2);
-                    const unsigned en = ntri_lds[cfg];
-                    int n = (int)(en & 7u);
-                    if (en & 128u) {
-                        double lv[8];
-                        int off;
-                        mc33_load_cell(row + i2, lyz, lz, lv);
-                        n = mc33_cell(lv, a.mc->mc33, &off);
-                    }
-                    // entry: cell (15 bits) | ambiguous (1) | configuration (8) | triangle in cell (4)
-                    const unsigned e = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((en & 128u) << 5) | (cfg << 4);
-                    for (int j = 0; j < n; j++, pos++)
-                        if (pos >= 0 && pos < cn) list[pos] = e | (unsigned)j;
+        // ---- 3 + 4. the triangles: first the waiting batch's (pass 0), then this batch's if it cannot wait (pass 1).  Ordered
+        // allocation (wave 0): the batch takes its position if every predecessor has published its count -- the waiting
+        // batch's have had a whole batch's time -- else it is PARKED (staging slot, 9 floats per triangle, placed later).
+        // Then the per-triangle work list in LDS, one lane per triangle. ----
+        const bool sparse_next = !flush_only && !emit_cur;   // this batch becomes the waiting one
+        // (two copies of this code, one per kind of batch, rather than one loop over both: the rows' sign strings and offsets
+        // that only a list built in passes needs would otherwise stay in registers through the waiting batch's emission)
+        auto emit_stage = [&](auto is_dq_tag) {
+            constexpr bool is_dq = decltype(is_dq_tag)::value;
+            const unsigned char *ds = slot_base(max(dq_slot, 0));
+            const int e_w = is_dq ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(ds + 48)[0]) : w;
+            const int e_total = is_dq ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(ds + 48)[1]) : total;
+            const int e_ntl = is_dq ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(ds + 48)[2]) : 0;
+            const bool e_ready = is_dq || list_ready;
+            const int e_lcap = is_dq ? 16384 : lcap;
+            unsigned *lst = is_dq ? const_cast<unsigned *>(reinterpret_cast<const unsigned *>(ds + MESH_SLOT_HDR + 256 * e_ntl)) : clist;
+            const TileView vw{is_dq ? reinterpret_cast<const float *>(ds + MESH_SLOT_HDR) : (sparse ? smp : vol),
+                              reinterpret_cast<const unsigned *>((is_dq ? ds : cs) + MESH_SLOT_COLINFO), lyz, lz, is_dq || sparse};
+            // points * scale + offset (reference sdf/core.py:58-60): scale = first axis step of the batch, offset = its
+            // first sample, per axis
+            const double *exf = reinterpret_cast<const double *>(ds);
+            const double of0 = is_dq ? exf[0] : axes[0], of1 = is_dq ? exf[1] : axes[33], of2 = is_dq ? exf[2] : axes[66];
+            const double sc0 = is_dq ? exf[3] : axes[1] - of0, sc1 = is_dq ? exf[4] : axes[34] - of1, sc2 = is_dq ? exf[5] : axes[67] - of2;
+            const bool may_park = a.park && e_total <= a.park_cap;
+            const bool block = !may_park || (is_dq && finished);   // (at the end of the list there is nothing else to do but wait)
+            if (tid < 64) {
+                const unsigned long long pre = is_dq ? (flush_only ? lookback_prefetch(a.status, e_w, work_begin) : pre_dq)
+                                                     : (sparse ? lookback_prefetch(a.status, e_w, work_begin) : pre_own);
+                const unsigned long long excl = ordered_base(a.status, e_w, work_begin, (unsigned long long)e_total, block ? MESH_SPIN_FOREVER : a.park_spins, pre);
+                if (tid == 0) {
+                    if (excl != MESH_NOT_READY) settle(e_w, excl, (unsigned long long)e_total);
+                    reinterpret_cast<unsigned long long *>(bcast + 2)[0] = excl;
                 }
             }
             __syncthreads();
-            SDF_PROF(3);
-            double *dst0 = a.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
-            float *park0 = my_park + ((size_t)park_slot * (size_t)a.park_cap + (size_t)lo) * 9;
-            for (int t = tid; t < cn; t += BLOCK) {
-                const unsigned e = list[t];
-                const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
-                const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
-                const float *corner = vol + i0 * lyz + i1 * lz + i2;
-                float o[9];
-                if (e & 4096u) {
-                    mc33_triangle(corner, lyz, lz, i0, i1, i2, a.mc->mc33, j, o);
-                } else {
-                    const signed char *tt = tri_tab + cfg * 16 + 3 * j;
-                    mc_vertex(corner, lyz, lz, i0, i1, i2, tt[0], o);
-                    mc_vertex(corner, lyz, lz, i0, i1, i2, tt[1], o + 3);
-                    mc_vertex(corner, lyz, lz, i0, i1, i2, tt[2], o + 6);
+            const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
+            const bool parking = base == MESH_NOT_READY;
+            const bool fits = parking || (base != ~0ull && base + (unsigned long long)e_total <= a.out_cap);
+            const int park_slot = (pq_head + pq_count) % MESH_PARK_DEPTH;   // (the FIFO has room: a full one was waited for above)
+            if (parking) {
+                if (tid == 0) {
+                    double *xf = pend_xf(park_slot);
+                    xf[0] = of0; xf[1] = of1; xf[2] = of2; xf[3] = sc0; xf[4] = sc1; xf[5] = sc2;
+                    pend_wt(park_slot)[0] = e_w; pend_wt(park_slot)[1] = e_total;
                 }
-                if (parking || a.compact) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
-                    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                    float *dst = parking ? park0 + (size_t)t * 9
-                                         : reinterpret_cast<float *>(a.out) + (base + (unsigned long long)lo + (unsigned long long)t) * 9ull;
-                    *reinterpret_cast<f4u *>(dst) = f4u{o[0], o[1], o[2], o[3]};
-                    *reinterpret_cast<f4u *>(dst + 4) = f4u{o[4], o[5], o[6], o[7]};
-                    dst[8] = o[8];
-                } else {
-                    double *dst = dst0 + (size_t)t * 9;
-                    SDF_UNROLL
-                    for (int q = 0; q < 9; q += 3) {
-                        SDF_SOUP_STORE(dst + q, (double)o[q] * sc0 + of0);
-                        SDF_SOUP_STORE(dst + q + 1, (double)o[q + 1] * sc1 + of1);
-                        SDF_SOUP_STORE(dst + q + 2, (double)o[q + 2] * sc2 + of2);
+                pq_count++;
+                if (a.prof && tid == 0) atomicAdd(&a.prof[7], 1ull);
+            }
+            if (a.prof && tid == 0 && is_dq) atomicAdd(&a.prof[12], 1ull);
+            for (int lo = 0; fits && lo < e_total; lo += e_lcap) {
+                const int ecn = min(e_lcap, e_total - lo);
+                SDF_UNROLL
+                for (int k = 0; k < RPT; k++) {
+                    if (is_dq || e_ready || row_tris[k] == 0 || row_off[k] >= lo + ecn || row_off[k] + row_tris[k] <= lo) continue;
+                    const int r = tid + k * BLOCK;
+                    const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
+                    int pos = row_off[k] - lo;
+                    unsigned m = row_mask[k];
+                    while (m) {
+                        const int i2 = __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        const unsigned cfg = cell_config(row_bits[k], i2);
+                        const unsigned en = ntri_lds[cfg];
+                        int n = (int)(en & 7u);
+                        if (en & 128u) {
+                            float c8[8];
+                            double lv[8];
+                            int off;
+                            vw.cell(i0, i1, i2, c8);
+                            mc33_load_cell(c8, 4, 2, lv);
+                            n = mc33_cell(lv, a.mc->mc33, &off);
+                        }
+                        // entry: cell (15 bits) | ambiguous (1) | configuration (8) | triangle in cell (4)
+                        const unsigned e = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((en & 128u) << 5) | (cfg << 4);
+                        for (int j = 0; j < n; j++, pos++)
+                            if (pos >= 0 && pos < ecn) lst[pos] = e | (unsigned)j;
                     }
                 }
+                __syncthreads();
+                SDF_PROF(3);
+                double *dst0 = a.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
+                float *park0 = my_park + ((size_t)park_slot * (size_t)a.park_cap + (size_t)lo) * 9;
+                for (int t = tid; t < ecn; t += BLOCK) {
+                    const unsigned e = lst[t];
+                    const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
+                    const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
+                    float o[9];
+                    if (e & 4096u) {
+                        float c8[8];
+                        vw.cell(i0, i1, i2, c8);
+                        mc33_triangle(c8, 4, 2, i0, i1, i2, a.mc->mc33, j, o);
+                    } else {
+                        const signed char *tt3 = tri_tab + cfg * 16 + 3 * j;
+                        mc_vertex_view(vw, i0, i1, i2, tt3[0], o);
+                        mc_vertex_view(vw, i0, i1, i2, tt3[1], o + 3);
+                        mc_vertex_view(vw, i0, i1, i2, tt3[2], o + 6);
+                    }
+                    if (parking || a.compact) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
+                        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                        float *dst = parking ? park0 + (size_t)t * 9
+                                             : reinterpret_cast<float *>(a.out) + (base + (unsigned long long)lo + (unsigned long long)t) * 9ull;
+                        *reinterpret_cast<f4u *>(dst) = f4u{o[0], o[1], o[2], o[3]};
+                        *reinterpret_cast<f4u *>(dst + 4) = f4u{o[4], o[5], o[6], o[7]};
+                        dst[8] = o[8];
+                    } else {
+                        double *dst = dst0 + (size_t)t * 9;
+                        SDF_UNROLL
+                        for (int q = 0; q < 9; q += 3) {
+                            SDF_SOUP_STORE(dst + q, (double)o[q] * sc0 + of0);
+                            SDF_SOUP_STORE(dst + q + 1, (double)o[q + 1] * sc1 + of1);
+                            SDF_SOUP_STORE(dst + q + 2, (double)o[q + 2] * sc2 + of2);
+                        }
+                    }
+                }
+                __syncthreads();   // list / tile are reused
+                SDF_PROF(4);
             }
-            __syncthreads();   // list / vol are reused
-            SDF_PROF(4);
-        }
-        __syncthreads();   // vol / bcast are reused by the next batch
+            __syncthreads();   // (bcast is reused by the next stage; the slot by the next batch)
+        };
+        if (emit_cur) emit_stage(std::integral_constant<bool, false>());       // (uniform)
+        if (dq_slot >= 0) emit_stage(std::integral_constant<bool, true>());    // (uniform)
+        dq_slot = sparse_next ? cur_slot : -1;
+        if (finished) break;
     }
     SDF_FRESH();
     place_parked(pq_count > 0 && tid < 64 ? lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin) : 0ull, true);

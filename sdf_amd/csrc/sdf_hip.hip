@@ -251,7 +251,7 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned char *cull_smem, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max) {
+                                                     int *__restrict__ order, int tail_max, int levels) {
     int *wave_sums = reinterpret_cast<int *>(cull_smem);                       // 64 B
     double *axes = reinterpret_cast<double *>(cull_smem + 64);                 // 3 * 33 doubles
     unsigned char *scratch = cull_smem + 896;                                  // CULL_SCRATCH bytes
@@ -276,7 +276,7 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
     long long tstart1 = 0;   // (profiling: the clock once the work item, its axes and the length of its tape have arrived)
     if (prof) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart1) : "s"(n_instr_w) : "memory");
-    const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd, prof);
+    const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd, prof, levels);
     const long long tw = prof ? clock64() : 0;
     if (tid == 0 && ntl < 0) reinterpret_cast<unsigned short *>(scratch)[0] = (unsigned short)0xFFFF;   // (else: the number of listed units, cull_tasks)
     __syncthreads();
@@ -285,7 +285,7 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
         const unsigned *src = reinterpret_cast<const unsigned *>(scratch);
         const int nwords = ntl < 0 ? 1 : (CULL_ULIST + 16 * ntl + 3) >> 2;
         for (int i = tid; i < nwords; i += CB) rec[i] = src[i];
-        if (ntl >= 0) for (int i = tid; i < 1024; i += CB) rec[CULL_SSTATE / 4 + i] = src[CULL_SSTATE / 4 + i];
+        if (ntl >= 0) for (int i = tid; i < (CULL_RECORD - CULL_SSTATE) / 4; i += CB) rec[CULL_SSTATE / 4 + i] = src[CULL_SSTATE / 4 + i];   // sub-group states + column words
     }
     // ---- every work item of the tail of the list leaves its cost estimate for k_mesh, which hands the tail out by
     // descending cost (MeshArgs::order) ----
@@ -307,9 +307,9 @@ __global__ __launch_bounds__(CB) void k_cull(const uint32_t *__restrict__ code, 
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max) {
+                                                     int *__restrict__ order, int tail_max, int levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<FULL, RARE, CB>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
+    cull_body<FULL, RARE, CB>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
 }
 // the variant for tapes without trigonometry and without the rarer leaves: 70 VGPRs without spilling, seven waves per
 // SIMD (the others take 99 - 104; holding them to five or six waves was measured in r02p: no faster)
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max) {
+                                                     int *__restrict__ order, int tail_max, int levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
+    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
 }
 // (experiment: the same with two waves per workgroup -- twelve workgroups fit a CU, every work item of the 512^3
 // example is resident at once instead of in two rounds)
@@ -327,9 +327,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max) {
+                                                     int *__restrict__ order, int tail_max, int levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max);
+    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
 }
 
 // (every kernel that is not a tape interpreter -- the compaction, marching cubes of caller-supplied volumes, the two-pass
@@ -504,6 +504,8 @@ struct sdf_ctx {
     int cull_block = 0;               // SDF_CULL_BLOCK=64 / 128 / 256: threads per work item of k_cull (0: the default of the variant)
     int tail_order = 1;               // SDF_TAIL_ORDER=0: k_mesh takes the whole work list in order
     int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
+    int defer = 1;                    // SDF_DEFER=0: k_mesh keeps every tile dense and writes (or parks) a batch's triangles right after counting it
+    int cull_levels = 0;              // SDF_CULL_LEVELS=2 / 3: interval levels of k_cull (3: + sub-groups of 2^3 cells); 0: by the tape (see generate_impl)
 };
 
 struct sdf_tape {
@@ -670,6 +672,8 @@ static int ctx_init(sdf_ctx *c) {
     if (const char *e = getenv("SDF_PARK")) c->parking = atoi(e);
     if (const char *e = getenv("SDF_PRUNE_LIST_MIN")) c->prune_list_min = std::max(atoi(e), 0);
     if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
+    if (const char *e = getenv("SDF_DEFER")) c->defer = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("SDF_CULL_LEVELS")) c->cull_levels = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
     if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(512 + 4096 * 32)) return 1; }
     return 0;
@@ -710,6 +714,18 @@ int sdf_ctx_set_prune(sdf_ctx *c, int enabled) {
 int sdf_ctx_set_cull(sdf_ctx *c, int enabled) {
     if (!c) return fail("sdf_ctx_set_cull: ctx is NULL");
     c->cull = enabled ? 1 : 0;
+    return 0;
+}
+
+int sdf_ctx_set_defer(sdf_ctx *c, int on) {
+    if (!c) return fail("sdf_ctx_set_defer: ctx is NULL");
+    c->defer = on ? 1 : 0;
+    return 0;
+}
+int sdf_ctx_set_cull_levels(sdf_ctx *c, int levels) {
+    if (!c) return fail("sdf_ctx_set_cull_levels: ctx is NULL");
+    if (levels != 0 && levels != 2 && levels != 3) return fail("sdf_ctx_set_cull_levels: 0 (the library's choice), 2 or 3");
+    c->cull_levels = levels;
     return 0;
 }
 
@@ -1019,6 +1035,10 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     a.bits_off = (int)bits_off;
     const size_t list_cap = std::min<size_t>((c->lds_max - list_off) / 4, 16384);
     a.list_off = (int)list_off; a.list_cap = (int)list_cap;
+    // two slots of sparse tiles share the dense tile's region (deferred emission, k_mesh); a slot has to hold its header,
+    // some samples and the cell table of the per-cell counting -- else every tile stays dense
+    a.slot_bytes = c->defer && !a.twopass && a.cull ? (int)(((bits_off - MESH_LDS_VOL) / 2) & ~(size_t)15) : 0;
+    if (a.slot_bytes < MESH_SLOT_HDR + 2048 + 8192) a.slot_bytes = 0;
     const size_t lds = list_off + list_cap * 4;
     // the first register-file variant that holds the tape's slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (2,4), 4 = (4,4), 5 = (8,8)
     static const uint32_t kFile[6][2] = {{1, 1}, {2, 2}, {4, 2}, {2, 4}, {4, 4}, {8, 8}};
@@ -1239,6 +1259,14 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             cull_block = c->cull_block == 64 ? 64 : 128;
             kc = cull_block == 64 ? k_cull<true, false, 64> : k_cull<true, false, 128>;
         }
+        // The third interval level (sub-groups of 2^3 cells) halves what k_mesh samples and costs 8 interval runs per
+        // undecided group of 4^3 cells.  r04a, same box, prepass + k_mesh in ms, two levels -> three: example 2^27 0.068 + 0.280
+        // -> 0.104 + 0.240, pawn 0.132 + 0.416 -> 0.276 + 0.289, blobby 2^30 0.229 + 0.874 -> 0.505 + 0.612 (level with or
+        // ahead, and the prepass of the NEXT call hides behind k_mesh when calls are in flight); with trigonometry in the tape
+        // the interval forms are dearer than the samples they save: gearlike 2^30 0.271 + 1.23 -> 0.64 + 0.99, knurling 2^27
+        // 0.364 + 1.52 -> 1.58 + 1.25, weave 2^33 6.6 + 24.2 -> 19.9 + 15.4.  Hence three levels for the lean tapes, two for
+        // the others -- which still list units of 2^3 samples instead of r03's cubes of 4^3.
+        const int cull_levels = c->cull_levels ? c->cull_levels : (kc == k_cull_lean || kc == k_cull_lean128 ? 3 : 2);
         const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 896 - CULL_SCRATCH);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1246,7 +1274,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                            pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
                            (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
                            ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p, (unsigned long long *)c->prof.p,
-                           tail_order ? (int *)m->order.p : (int *)nullptr, tail_max);
+                           tail_order ? (int *)m->order.p : (int *)nullptr, tail_max, cull_levels);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(cs.e2, st));
@@ -1401,8 +1429,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                     pc[16], pc[17], pc[18], pc[19], pc[23], pc[22], pc[20], pc[21]);
             fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu\n", pc[24], pc[25]);
             fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu\n", pc[8], pc[9], pc[10], pc[11]);
-            fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked\n",
-                    ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7]);
+            fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked, %llu written one batch later from their slot\n",
+                    ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7], pc[12]);
         }
         m->st.n_retries = attempt;
         if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");

@@ -65,6 +65,8 @@ ABI = {
     'sdf_ctx_set_cull': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_twopass': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_tail_order': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'sdf_ctx_set_defer': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'sdf_ctx_set_cull_levels': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_synchronize': (ctypes.c_int, [_vp]),
     'sdf_ctx_trim': (ctypes.c_int, [_vp]),
     'sdf_tape_create': (ctypes.c_int, [_vp, _u32p, ctypes.c_uint32, _f64p, ctypes.c_uint32,
@@ -131,7 +133,7 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -460,6 +462,14 @@ class Engine:
     def set_tail_order(self, on):
         """hand the tail of the work list to the workgroups by descending cost (default) or in order; same results"""
         _check(self.lib, self.lib.sdf_ctx_set_tail_order(self.ctx, int(bool(on))))
+
+    def set_defer(self, on):
+        """one-kernel meshing: sparse tiles + deferred emission (default) or dense tiles + parking; same results"""
+        _check(self.lib, self.lib.sdf_ctx_set_defer(self.ctx, int(bool(on))))
+
+    def set_cull_levels(self, levels):
+        """interval levels of the culling pass: 2, 3 or 0 = the library's choice by the tape (default); same results"""
+        _check(self.lib, self.lib.sdf_ctx_set_cull_levels(self.ctx, int(levels)))
 
     def set_twopass(self, mode):
         """meshing scheme: 0 one kernel (look-back + parking), 1 three kernels (sample / number / emit), -1 the

@@ -54,7 +54,7 @@ template <int BLOCK> int host_count(bool p, int *wave_sums, int &total) { return
 
 POSTLUDE = r'''
 template <int BLOCK> static int run_block(const uint32_t *code, const double *consts, int n_instr, int n_p, int n_d, int lx, int ly, int lz,
-                                          const double *axes99, unsigned char *record, int *ntl_out) {
+                                          const double *axes99, unsigned char *record, int *ntl_out, int levels) {
     const int per_thread = (6 * n_p + 2 * n_d) * 8;
     std::vector<unsigned char> scratch(CULL_SCRATCH + 64, 0xA5);            // (garbage, like LDS)
     std::vector<double> ia_state((size_t)BLOCK * (6 * n_p + 2 * n_d) + 8);
@@ -68,7 +68,7 @@ template <int BLOCK> static int run_block(const uint32_t *code, const double *co
         th.emplace_back([&, t] {
             g_simt_tid = t;
             ret[t] = cull_tasks<BLOCK, true, true>(code, consts, n_instr, lx, ly, lz, axes.data(), ia_state.data(), BLOCK * per_thread,
-                                                   scratch.data(), wave_sums, n_p, n_d, nullptr);
+                                                   scratch.data(), wave_sums, n_p, n_d, nullptr, levels);
         });
     for (auto &x : th) x.join();
     for (int t = 1; t < BLOCK; t++) if (ret[t] != ret[0]) return 2;          // (the return value is workgroup-uniform)
@@ -77,15 +77,15 @@ template <int BLOCK> static int run_block(const uint32_t *code, const double *co
     return 0;
 }
 extern "C" int cull_record_bytes() { return CULL_RECORD; }
-extern "C" int cull_layout(int *out) { out[0] = CULL_ULIST; out[1] = CULL_SSTATE; out[2] = CULL_UNIT_CAP; return 0; }
+extern "C" int cull_layout(int *out) { out[0] = CULL_ULIST; out[1] = CULL_SSTATE; out[2] = CULL_UNIT_CAP; out[3] = CULL_COLINFO; return 0; }
 extern "C" int cull_host(int block, const uint32_t *code, const double *consts, int n_instr, int n_p, int n_d, int lx, int ly, int lz,
-                         const double *axes99, unsigned char *record, int *ntl_out) {
+                         const double *axes99, unsigned char *record, int *ntl_out, int levels) {
     if (n_p < 1) n_p = 1;
     if (n_d < 1) n_d = 1;
     switch (block) {
-    case 64: return run_block<64>(code, consts, n_instr, n_p, n_d, lx, ly, lz, axes99, record, ntl_out);
-    case 128: return run_block<128>(code, consts, n_instr, n_p, n_d, lx, ly, lz, axes99, record, ntl_out);
-    case 256: return run_block<256>(code, consts, n_instr, n_p, n_d, lx, ly, lz, axes99, record, ntl_out);
+    case 64: return run_block<64>(code, consts, n_instr, n_p, n_d, lx, ly, lz, axes99, record, ntl_out, levels);
+    case 128: return run_block<128>(code, consts, n_instr, n_p, n_d, lx, ly, lz, axes99, record, ntl_out, levels);
+    case 256: return run_block<256>(code, consts, n_instr, n_p, n_d, lx, ly, lz, axes99, record, ntl_out, levels);
     }
     return 1;
 }
@@ -128,8 +128,10 @@ extern "C" int cull_sign_fill_host(const unsigned char *sstate, int lx, int ly, 
     loop = src[src.index('\n', a) + 1:b].replace('run_tape<T, FULL, NP, ND, NS>(wcode, consts, px, py, pz)', 'host_field(px, py, pz)')
     assert 'host_field' in loop
     loop_fn = '''
-extern "C" int cull_sample_loop_host(const unsigned char *record, int lx, int ly, int lz, const double *axes, float *vol, unsigned long long *bits) {
+extern "C" int cull_sample_loop_host(const unsigned char *record, int lx, int ly, int lz, const double *axes, float *vol, unsigned long long *bits,
+                                     int sparse_tile, float *smp) {
     typedef double T;
+    const bool sparse = sparse_tile != 0;
     constexpr int NS = 2, BLOCK = 1024, NWAVE = BLOCK / 64;
     struct V { T v[NS]; };
     auto host_field = [](const V &x, const V &y, const V &z) { V r; for (int k = 0; k < NS; k++) r.v[k] = x.v[k] + 64.0 * y.v[k] + 4096.0 * z.v[k] - 70000.0; return r; };
@@ -147,8 +149,17 @@ extern "C" int cull_sample_loop_host(const unsigned char *record, int lx, int ly
     return 0;
 }
 '''
+    # k_mesh's view of a tile (dense / sparse): the struct as it stands in the device source
+    a, b = src.index('struct TileView {'), src.index('__device__ __forceinline__ void mc_vertex_view(')
+    view = src[a:b].replace('__device__ __forceinline__', 'inline').replace('__popc(', '__builtin_popcount(').replace('#pragma unroll', '')
+    view_fn = view + '''
+extern "C" float tile_at_host(const float *smp, const unsigned *colinfo, int ix, int iy, int iz) {
+    const TileView vw{smp, colinfo, 0, 0, true};
+    return vw.at(ix, iy, iz);
+}
+'''
     # (`extern "C"` functions inside an anonymous namespace keep C linkage)
-    open(path, 'w').write(PRELUDE + body + fill_fn + loop_fn + POSTLUDE)
+    open(path, 'w').write(PRELUDE + body + fill_fn + loop_fn + view_fn + POSTLUDE)
 
 
 def build(workdir):
@@ -160,12 +171,15 @@ def build(workdir):
                            '-I', os.path.join(ROOT, 'sdf_amd', 'csrc'), '-o', so, gen])
     lib = ctypes.CDLL(so)
     lib.cull_host.restype = ctypes.c_int
-    lib.cull_host.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.cull_host.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     lib.cull_sample_host.restype = ctypes.c_int
     lib.cull_sample_host.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
     lib.cull_layout.argtypes = [ctypes.c_void_p]
     lib.cull_sample_loop_host.restype = ctypes.c_int
-    lib.cull_sample_loop_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.cull_sample_loop_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int, ctypes.c_void_p]
+    lib.tile_at_host.restype = ctypes.c_float
+    lib.tile_at_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.cull_sign_fill_host.restype = ctypes.c_int
     lib.cull_sign_fill_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     return lib

@@ -34,12 +34,13 @@ def _intervals(tape_lib, t, boxes):
     return np.where(out[:, 0] > 1e-30, 1, np.where(out[:, 1] < -1e-30, 2, 0)).astype(np.uint8)
 
 
-def _model(tape_lib, t, ax):
-    """sub-group states (16^3, non-existent = 1) and the listed units (packed, ascending) by the rules, level by level"""
+def _model(tape_lib, t, ax, levels=3):
+    """sub-group states (16^3, non-existent = 1) and the listed units (packed, ascending) by the rules, level by level
+    (two levels: the sub-groups keep the states of their groups)"""
     n = [len(a) for a in ax]
     c = [m - 1 for m in n]
 
-    def level(size, count, parent):
+    def level(size, count, parent, evaluate=True):
         st = np.ones((count,) * 3, np.uint8)
         idx = [(i, j, k) for i in range(count) for j in range(count) for k in range(count)
                if size * i < c[0] and size * j < c[1] and size * k < c[2]]
@@ -47,6 +48,8 @@ def _model(tape_lib, t, ax):
             for q in idx:
                 st[q] = parent[q[0] >> 1, q[1] >> 1, q[2] >> 1]
             idx = [q for q in idx if st[q] == 0]
+        if not evaluate:
+            return st
         boxes = []
         for q in idx:
             b = []
@@ -60,7 +63,7 @@ def _model(tape_lib, t, ax):
         return st
     m = level(8, 4, None)
     g = level(4, 8, m)
-    s = level(2, 16, g)
+    s = level(2, 16, g, evaluate=levels >= 3)
     nu = [(m_ + 1) >> 1 for m_ in n]
     units = []
     for u0 in range(nu[0]):
@@ -72,8 +75,8 @@ def _model(tape_lib, t, ax):
     return s, np.array(units, np.uint16)
 
 
-def _run(cull_lib, t, ax, block):
-    lay = (ctypes.c_int * 3)()
+def _run(cull_lib, t, ax, block, levels=3):
+    lay = (ctypes.c_int * 4)()
     cull_lib.cull_layout(lay)
     ulist_off, sstate_off, cap = lay[0], lay[1], lay[2]
     rec = np.zeros(cull_lib.cull_record_bytes(), np.uint8)
@@ -84,7 +87,7 @@ def _run(cull_lib, t, ax, block):
     code = np.ascontiguousarray(t.code, dtype=np.uint32)
     consts = np.ascontiguousarray(np.concatenate([t.consts, [0.0]]))
     rc = cull_lib.cull_host(block, code.ctypes.data, consts.ctypes.data, t.n_instr, t.n_pslots, t.n_dslots, len(ax[0]), len(ax[1]), len(ax[2]),
-                            axes.ctypes.data, rec.ctypes.data, ctypes.byref(ntl))
+                            axes.ctypes.data, rec.ctypes.data, ctypes.byref(ntl), levels)
     assert rc == 0
     n = int(rec[:2].view(np.uint16)[0])
     units = rec[ulist_off:ulist_off + 2 * cap].view(np.uint16)
@@ -92,12 +95,19 @@ def _run(cull_lib, t, ax, block):
     return ntl.value, n, units, sstate, rec
 
 
+def _colinfo(cull_lib, rec):
+    lay = (ctypes.c_int * 4)()
+    cull_lib.cull_layout(lay)
+    return rec[lay[3]:lay[3] + 4 * 289].view(np.uint32)
+
+
 TILES = [('ex_example', 2 ** 22, 'regular'), ('ex_example', 1500000, 'ragged'), ('ex_blobby', 2 ** 21, 'regular'), ('ex_blobby', 1500000, 'ragged'),
          ('ex_gearlike', 2 ** 21, 'regular'), ('ex_gearlike', 1200000, 'ragged'), ('ex_weave', 2 ** 22, 'regular'), ('ex_knurling', 2 ** 21, 'regular')]
 
 
+@pytest.mark.parametrize('levels', [3, 2])
 @pytest.mark.parametrize('name,samples,kind', TILES, ids=['%s-%s' % (n[3:], k) for n, _, k in TILES])
-def test_cull_tasks_on_the_host_match_the_rules(name, samples, kind, libs, ns):
+def test_cull_tasks_on_the_host_match_the_rules(name, samples, kind, levels, libs, ns):
     from sdf_amd import core, tape as tape_mod
     cull_lib, tape_lib = libs
     f = fixtures.build(name, ns)
@@ -121,10 +131,10 @@ def test_cull_tasks_on_the_host_match_the_rules(name, samples, kind, libs, ns):
     assert ax is not None, 'no such batch on this grid'
     n = [len(a) for a in ax]
     t = tape_mod.lower(f)
-    want_s, want_units = _model(tape_lib, t, ax)
+    want_s, want_units = _model(tape_lib, t, ax, levels)
     got = {}
     for block in (64, 128, 256):
-        ntl, cnt, units, sstate, rec = _run(cull_lib, t, ax, block)
+        ntl, cnt, units, sstate, rec = _run(cull_lib, t, ax, block, levels)
         got[block] = (ntl, cnt, units[:((cnt + 7) & ~7) if cnt != 0xFFFF else 0].copy(), sstate.copy(), rec.copy())
     ntl, cnt, units, sstate, rec = got[256]
     for block in (64, 128):
@@ -166,13 +176,35 @@ def test_cull_tasks_on_the_host_match_the_rules(name, samples, kind, libs, ns):
         idx_axes[33 * d_:33 * d_ + n[d_]] = np.arange(n[d_])
     vol = np.full(nvox, np.float32(-12345.0), np.float32)
     bits2 = bits.copy()
-    assert cull_lib.cull_sample_loop_host(np.ascontiguousarray(rec).ctypes.data, n[0], n[1], n[2], idx_axes.ctypes.data, vol.ctypes.data, bits2.ctypes.data) == 0
+    assert cull_lib.cull_sample_loop_host(np.ascontiguousarray(rec).ctypes.data, n[0], n[1], n[2], idx_axes.ctypes.data, vol.ctypes.data, bits2.ctypes.data, 0, None) == 0
     I, J, K = np.meshgrid(np.arange(n[0]), np.arange(n[1]), np.arange(n[2]), indexing='ij')
     code_of = (I + 64.0 * J + 4096.0 * K - 70000.0).astype(np.float32)
     vol3 = vol.reshape(n)
     assert np.array_equal(vol3[listed], code_of[listed]) and (vol3[~listed] == np.float32(-12345.0)).all()
     want_bits2 = got_bits | (listed & (code_of > 0))
     assert np.array_equal(np.unpackbits(bits2.view(np.uint8), bitorder='little')[:nvox].reshape(n).astype(bool), want_bits2)
+    # the same loop on a SPARSE tile (k_mesh keeps only the listed units' samples, 64 floats per task): sample `lane` of
+    # task t sits at smp[64 t + lane], and TileView::at finds every listed sample there through the column words
+    smp = np.full(64 * ntl, np.float32(-777.0), np.float32)
+    vol_s = np.full(nvox, np.float32(-12345.0), np.float32)
+    bits3 = bits.copy()
+    assert cull_lib.cull_sample_loop_host(np.ascontiguousarray(rec).ctypes.data, n[0], n[1], n[2], idx_axes.ctypes.data, vol_s.ctypes.data, bits3.ctypes.data,
+                                          1, smp.ctypes.data) == 0
+    assert (vol_s == np.float32(-12345.0)).all() and np.array_equal(bits3, bits2)
+    colinfo = np.ascontiguousarray(_colinfo(cull_lib, rec))
+    nu = [(m_ + 1) >> 1 for m_ in n]
+    k = 0
+    for u0 in range(17):               # the column words: listed u2 | index of the column's first listed unit << 17
+        for u1 in range(17):
+            mine = [int(u) & 31 for u in want_units if (int(u) >> 10, (int(u) >> 5) & 31) == (u0, u1)]
+            word = int(colinfo[u0 * 17 + u1])
+            assert word & 0x1FFFF == sum(1 << u2 for u2 in mine), (u0, u1)
+            if mine:
+                assert word >> 17 == k
+            k += len(mine)
+    for (ix, iy, iz) in np.argwhere(listed)[::7]:
+        got_v = cull_lib.tile_at_host(smp.ctypes.data, colinfo.ctypes.data, int(ix), int(iy), int(iz))
+        assert got_v == code_of[ix, iy, iz], (ix, iy, iz)
     # soundness: every sample that belongs to an undecided sub-group is evaluated
     c = [m - 1 for m in n]
     for h in np.argwhere(want_s == 0):
