@@ -87,6 +87,7 @@ struct MeshArgs {
     unsigned park_spins;           // polls of the predecessors' counts before a batch is parked
     const unsigned char *cull;     // NULL, or k_cull's records: per work item, the sampling tasks to evaluate (cull_tasks)
     int slot_bytes;                // 0, or the size of one of the two slots of sparse tiles in the dense tile's region (deferred emission, k_mesh)
+    int stage_off;                 // byte offset of the transposition area behind the slots (MESH_STAGE_BYTES per wave, up to the end of LDS)
     // compact output (multi-GPU exchange, sdf_generate_compact_async): `out` then holds 9 FLOAT32 per triangle in the
     // batch's local voxel coordinates (what marching cubes itself produces, 36 bytes instead of 72) and xf[] the
     // per-work-item transform (offset[3], scale[3], indexed by w - work_begin) that k_expand applies after the gather
@@ -294,6 +295,11 @@ __device__ __forceinline__ void mc_vertex_view(const TileView &vw, int i0, int i
 // triangles in compact form (9 floats each) into its own staging slot ("parks" the batch), goes on
 // with the next batch, and moves the parked triangles to their place once that batch is sampled
 // too (k_mesh).  Only the aggregate has to be published early; the walk can happen any time later.
+// a workgroup-uniform value the compiler cannot see as one (it came through LDS): back into scalar registers
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
 #define MESH_NOT_READY (~0ull - 1ull)
 #define MESH_FLAG_AGG (1ull << 62)
 #define MESH_FLAG_PFX (2ull << 62)
@@ -320,32 +326,50 @@ __device__ __forceinline__ unsigned long long lookback_prefetch(const unsigned l
 // the exclusive prefix of work item w; ~0 on timeout; with max_spins small: MESH_NOT_READY when a
 // predecessor has not published its count yet.  `first` = lookback_prefetch(w), possibly stale
 // (a stale word can only say "not ready yet").
+// Behind the prefetched window the walk takes FOUR windows (256 predecessors) per round trip: with deferred emission a
+// batch publishes its inclusive prefix a whole batch after its count, so ~ two items per workgroup -- 500 words -- carry
+// only a count at any time, and one window per round trip made the walk eight dependent trips to the coherent level
+// (6 k cycles per batch).  The lanes add up what they see; ONE wave reduction at the end.
 __device__ __forceinline__ unsigned long long ordered_base(unsigned long long *status, int w, int w_begin, unsigned long long total,
                                                            unsigned max_spins, unsigned long long first) {
     const int lane = threadIdx.x & 63;
     if (w == w_begin) return 0;
-    unsigned long long excl = 0;
+    unsigned long long acc = 0;   // this lane's share of the exclusive prefix
     int idx = w - 1;
     bool use_first = true;
     for (unsigned spins = 0; spins < max_spins;) {   // (only waiting counts as a spin, walking back does not)
-        const int j = idx - lane;
-        unsigned long long sw = first;
-        if (!use_first)
-            sw = j >= w_begin ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                              : MESH_FLAG_PFX;   // in front of the shard: prefix 0
-        use_first = false;
-        const unsigned flag = (unsigned)(sw >> 62);
-        const unsigned long long pending = __ballot(flag == 0), is_pfx = __ballot(flag == 2);
-        if (is_pfx) {
-            const int p = __ffsll((long long)is_pfx) - 1;                 // nearest predecessor with a prefix
-            if (pending & ((1ull << p) - 1ull)) { __builtin_amdgcn_s_sleep(1); spins++; continue; }
-            excl += wave_sum_u64(lane <= p ? (sw & MESH_VAL_MASK) : 0ull);
-            if (lane == 0) __hip_atomic_store(&status[w], MESH_FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return excl;
+        constexpr int NW = 4;
+        unsigned long long sw[NW];
+        const int nwin = use_first ? 1 : NW;
+        if (use_first) sw[0] = first;
+        else {
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int j = idx - 64 * k - lane;
+                sw[k] = j >= w_begin ? __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : MESH_FLAG_PFX;   // in front of the shard: prefix 0
+            }
         }
-        if (pending) { __builtin_amdgcn_s_sleep(1); spins++; continue; }
-        excl += wave_sum_u64(sw & MESH_VAL_MASK);
-        idx -= 64;
+        use_first = false;
+        bool wait = false;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            if (k >= nwin || wait) break;   // (uniform)
+            const unsigned flag = (unsigned)(sw[k] >> 62);
+            const unsigned long long pending = __ballot(flag == 0), is_pfx = __ballot(flag == 2);
+            if (is_pfx) {
+                const int p = __ffsll((long long)is_pfx) - 1;                 // nearest predecessor with a prefix
+                if (pending & ((1ull << p) - 1ull)) { wait = true; break; }
+                acc += lane <= p ? (sw[k] & MESH_VAL_MASK) : 0ull;
+                const unsigned long long excl = wave_sum_u64(acc);
+                if (lane == 0) __hip_atomic_store(&status[w], MESH_FLAG_PFX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return excl;
+            }
+            if (pending) { wait = true; break; }
+            acc += sw[k] & MESH_VAL_MASK;
+            idx -= 64;
+        }
+        if (wait) { __builtin_amdgcn_s_sleep(1); spins++; }
     }
     return max_spins < (1u << 24) ? MESH_NOT_READY : ~0ull;
 }
@@ -606,7 +630,10 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
 //   [0, 64)        the batch as the emission needs it later: offset[3], scale[3] (double), work item, triangles, tasks
 //   [64, 1232)     k_cull's column words (TileView::colinfo)
 //   [1232, ..)     64 floats per listed task (eight units of 2^3 samples), then the batch's triangle list
-enum { MESH_SLOT_HDR = 1232, MESH_SLOT_COLINFO = 64 };
+//   behind the two slots, up to the end of LDS (over the sign bits and the work area, both idle by then): per wave 64 x 9
+//   floats through which the triangles of a waiting batch are transposed, so that consecutive lanes store consecutive
+//   coordinates of the soup (whole cache lines per store instruction instead of 72-byte strides)
+enum { MESH_SLOT_HDR = 1232, MESH_SLOT_COLINFO = 64, MESH_STAGE_BYTES = 64 * 9 * 4 };
 
 template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK, bool TWOPASS = false>
 __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
@@ -657,11 +684,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     auto pend_xf = [&](int k) { return reinterpret_cast<double *>(pend_base + 64 * k); };
     auto pend_wt = [&](int k) { return reinterpret_cast<int *>(pend_base + 64 * k + 48); };
     // place the parked batches whose predecessors have published, oldest first; `must`: wait for ALL of them
-    auto place_parked = [&](unsigned long long pre_pend, bool must) {
+    auto place_parked = [&](unsigned long long pre_pend, bool must, int need) {   // need: free entries wanted afterwards
         bool first = true;
         while (pq_count > 0) {
-            const int pend_w = pend_wt(pq_head)[0], pend_total = pend_wt(pq_head)[1];
-            const bool block = must || pq_count == MESH_PARK_DEPTH;
+            const int pend_w = uni(pend_wt(pq_head)[0]), pend_total = uni(pend_wt(pq_head)[1]);
+            const bool block = must || pq_count > MESH_PARK_DEPTH - need;
             if (tid < 64) {
                 const unsigned long long pre = first ? pre_pend : lookback_prefetch(a.status, pend_w, work_begin);
                 const unsigned long long excl = ordered_base(a.status, pend_w, work_begin, (unsigned long long)pend_total,
@@ -673,7 +700,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
             first = false;
             __syncthreads();
-            const unsigned long long pbase = reinterpret_cast<unsigned long long *>(bcast + 4)[0];
+            const unsigned long long pbase = uni64(reinterpret_cast<unsigned long long *>(bcast + 4)[0]);
             if (pbase == MESH_NOT_READY) { __syncthreads(); break; }   // (bcast is reused)
             if (pbase != ~0ull && pbase + (unsigned long long)pend_total <= a.out_cap) {
                 double *dst0 = a.out + pbase * 9ull;
@@ -736,6 +763,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     int w = 0;
     for (;;) {
         SDF_FRESH();
+        dq_slot = uni(dq_slot); pq_head = uni(pq_head); pq_count = uni(pq_count);   // (uniform by construction)
         if (!carry) {
             if (tid == 0) { const int idx = (int)atomicAdd(&a.ctr->work_counter, 1u); bcast[0] = work_begin + idx; bcast[1] = idx; }
             __syncthreads();
@@ -767,8 +795,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     __syncthreads();   // (the work area takes the batch's record next)
                 }
             }
-            w = __builtin_amdgcn_readfirstlane(w);
         }
+        w = uni(w);
         carry = false;
         const bool finished = w >= work_end;
         if (finished && a.prof && tid == 0 && a.prof[64 + 4 * blockIdx.x + 1] == 0) a.prof[64 + 4 * blockIdx.x + 1] = wall_clock64();
@@ -778,11 +806,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         int b = 0, ntl_cull = -1;     // listed tasks of a culled tile (-1: not culled)
         bool sparse = false;
         if (!finished) {
-            b = __builtin_amdgcn_readfirstlane(a.worklist[w]);
-            if (a.cull) {
-                const unsigned n0 = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[0]) & 0xFFFFu;
-                if (n0 != 0xFFFFu) ntl_cull = (int)((n0 + 7u) >> 3);
-            }
+            const int b_v = a.worklist[w];                                        // (both loads in flight before either is waited for)
+            const unsigned n0_v = a.cull ? reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[0] : 0xFFFFu;
+            b = uni(b_v);
+            const unsigned n0 = (unsigned)uni((int)n0_v) & 0xFFFFu;
+            if (n0 != 0xFFFFu) ntl_cull = (int)((n0 + 7u) >> 3);
             sparse = ntl_cull >= 0 && slot_bytes > 0 && MESH_SLOT_HDR + 256 * ntl_cull + 4 * MESH_CELL_CHUNKS * BLOCK <= slot_bytes;
             if (!sparse && dq_slot >= 0) { flush_only = true; carry = true; }   // a dense tile takes the slots' region
         }
@@ -802,7 +830,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         int total = 0, c1 = 1;
         float inv_c1 = 1.0f;
         bool list_ready = false, emit_cur = false;
-        unsigned long long pre_own = 0, pre_dq = 0;
+        unsigned long long pre_own = 0, pre_dq = 0, pre_pend = 0;
         if (!flush_only) {
         // k_cull's record of the batch (cull_tasks) travels next to the axes: units and sub-group states into the work area
         // (idle until the cells of a dense tile are listed), the column words into the batch's slot
@@ -928,7 +956,6 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // ---- 2. count: a thread owns the i2-rows of cells (i0, i1) = row tid + k * BLOCK ----
         // (wave 0 first asks for the predecessors' status words -- of this batch, of the waiting one and of the oldest
         // parked one -- so that the answers arrive while the cells are counted)
-        unsigned long long pre_pend = 0;
         if (tid < 64 && !TWOPASS) {
             if (!sparse) pre_own = lookback_prefetch(a.status, w, work_begin);   // (a sparse tile's batch waits a round: asked for then)
             if (dq_slot >= 0) pre_dq = lookback_prefetch(a.status, reinterpret_cast<const int *>(slot_base(dq_slot) + 48)[0], work_begin);
@@ -979,6 +1006,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             row_cell0[k] = ncells + block_exclusive_scan<BLOCK>(__popc(mask), wave_sums, tot);
             ncells += tot;
         }
+        ncells = uni(ncells);
         // ---- 2b. ONE THREAD PER SURFACE CELL (up to MESH_CELL_CHUNKS * BLOCK of them).  The row's thread only
         // SCATTERS its cells -- (row, column) into a table at the cell's running index, a few
         // ALU instructions and one LDS write each, nothing to wait for; then thread s takes cell s: looks up its
@@ -1067,6 +1095,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 total += tot;
             }
         }
+        total = uni(total);
         // ---- the batch's count is public from here on; bookkeeping that needs no position ----
         if (tid < 64 && !TWOPASS) publish_count(a.status, w, work_begin, (unsigned long long)total);
         if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
@@ -1152,10 +1181,6 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             __syncthreads();   // vol / bcast are reused by the next batch
             continue;
         }
-        // ---- a parked batch is older than this one: its predecessors have long published, place it ----
-        { const long long tp0 = a.prof ? clock64() : 0;
-        place_parked(pre_pend, false);
-        if (a.prof && tid == 0) atomicAdd(&a.prof[6], (unsigned long long)(clock64() - tp0)); }
         // ---- this batch: its triangles are written one batch later (it stays in its slot), or right away ----
         if (sparse && list_ready) {
             if (tid == 0) {
@@ -1176,6 +1201,12 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // batch's have had a whole batch's time -- else it is PARKED (staging slot, 9 floats per triangle, placed later).
         // Then the per-triangle work list in LDS, one lane per triangle. ----
         const bool sparse_next = !flush_only && !emit_cur;   // this batch becomes the waiting one
+        // ---- parked batches are older than anything here: their predecessors have long published, place them (and make room
+        // for what this round may park: the waiting batch, this batch) ----
+        { const long long tp0 = a.prof ? clock64() : 0;
+        if (flush_only && pq_count > 0 && tid < 64) pre_pend = lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin);
+        place_parked(pre_pend, false, (emit_cur ? 1 : 0) + (dq_slot >= 0 ? 1 : 0));
+        if (a.prof && tid == 0) atomicAdd(&a.prof[6], (unsigned long long)(clock64() - tp0)); }
         // (two copies of this code, one per kind of batch, rather than one loop over both: the rows' sign strings and offsets
         // that only a list built in passes needs would otherwise stay in registers through the waiting batch's emission)
         auto emit_stage = [&](auto is_dq_tag) {
@@ -1206,7 +1237,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 }
             }
             __syncthreads();
-            const unsigned long long base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
+            const unsigned long long base = uni64(reinterpret_cast<unsigned long long *>(bcast + 2)[0]);
             const bool parking = base == MESH_NOT_READY;
             const bool fits = parking || (base != ~0ull && base + (unsigned long long)e_total <= a.out_cap);
             const int park_slot = (pq_head + pq_count) % MESH_PARK_DEPTH;   // (the FIFO has room: a full one was waited for above)
@@ -1253,8 +1284,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 SDF_PROF(3);
                 double *dst0 = a.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
                 float *park0 = my_park + ((size_t)park_slot * (size_t)a.park_cap + (size_t)lo) * 9;
-                for (int t = tid; t < ecn; t += BLOCK) {
-                    const unsigned e = lst[t];
+                const bool staged = is_dq && a.stage_off > 0 && !parking;   // (uniform)
+                for (int t0 = tid & ~63; t0 < ecn; t0 += BLOCK) {   // (whole waves: the transposition below is wave-wide)
+                    const int t = t0 + (tid & 63);
+                    const bool live = t < ecn;
+                    const unsigned e = lst[live ? t : ecn - 1];
                     const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
                     const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
                     float o[9];
@@ -1268,7 +1302,31 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         mc_vertex_view(vw, i0, i1, i2, tt3[1], o + 3);
                         mc_vertex_view(vw, i0, i1, i2, tt3[2], o + 6);
                     }
-                    if (parking || a.compact) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
+                    if (staged) {
+                        // through LDS: lane l holds triangle t0 + l (9 floats); afterwards lane l stores coordinates 64 k + l,
+                        // k = 0 .. 8, of the wave's 576: consecutive lanes, consecutive addresses.  Coordinate c belongs to axis
+                        // c % 3 and 64 % 3 == 1: the axis of a lane's k-th coordinate is (l + k) % 3.
+                        float *stg = reinterpret_cast<float *>(smem + a.stage_off) + (tid >> 6) * (MESH_STAGE_BYTES / 4);
+                        const int ln = tid & 63;
+                        if (live) { SDF_UNROLL for (int q = 0; q < 9; q++) stg[ln * 9 + q] = o[q]; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const int nval = min(64, ecn - t0) * 9;
+                        const int a0 = ln % 3;
+                        const double s_[3] = {a0 == 0 ? sc0 : (a0 == 1 ? sc1 : sc2), a0 == 0 ? sc1 : (a0 == 1 ? sc2 : sc0), a0 == 0 ? sc2 : (a0 == 1 ? sc0 : sc1)};
+                        const double o_[3] = {a0 == 0 ? of0 : (a0 == 1 ? of1 : of2), a0 == 0 ? of1 : (a0 == 1 ? of2 : of0), a0 == 0 ? of2 : (a0 == 1 ? of0 : of1)};
+                        if (a.compact) {
+                            float *dstw = reinterpret_cast<float *>(a.out) + (base + (unsigned long long)(lo + t0)) * 9ull;
+                            SDF_UNROLL for (int k = 0; k < 9; k++) { const int c = 64 * k + ln; if (c < nval) dstw[c] = stg[c]; }
+                        } else {
+                            double *dstw = dst0 + (size_t)t0 * 9;
+                            SDF_UNROLL for (int k = 0; k < 9; k++) { const int c = 64 * k + ln; if (c < nval) SDF_SOUP_STORE(dstw + c, (double)stg[c] * s_[k % 3] + o_[k % 3]); }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();   // (the area is rewritten by the wave's next 64 triangles)
+                    } else if (!live) {
+                    } else if (parking || a.compact) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
                         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
                         float *dst = parking ? park0 + (size_t)t * 9
                                              : reinterpret_cast<float *>(a.out) + (base + (unsigned long long)lo + (unsigned long long)t) * 9ull;
@@ -1296,7 +1354,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (finished) break;
     }
     SDF_FRESH();
-    place_parked(pq_count > 0 && tid < 64 ? lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin) : 0ull, true);
+    place_parked(pq_count > 0 && tid < 64 ? lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin) : 0ull, true, 0);
     SDF_PROF(5);
     if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x + 2] = wall_clock64();
     if (tid == 0) {

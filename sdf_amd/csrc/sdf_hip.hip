@@ -1035,11 +1035,19 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     a.bits_off = (int)bits_off;
     const size_t list_cap = std::min<size_t>((c->lds_max - list_off) / 4, 16384);
     a.list_off = (int)list_off; a.list_cap = (int)list_cap;
+    const size_t lds = list_off + list_cap * 4;
     // two slots of sparse tiles share the dense tile's region (deferred emission, k_mesh); a slot has to hold its header,
     // some samples and the cell table of the per-cell counting -- else every tile stays dense
-    a.slot_bytes = c->defer && !a.twopass && a.cull ? (int)(((bits_off - MESH_LDS_VOL) / 2) & ~(size_t)15) : 0;
-    if (a.slot_bytes < MESH_SLOT_HDR + 2048 + 8192) a.slot_bytes = 0;
-    const size_t lds = list_off + list_cap * 4;
+    // -- and behind them, up to the end of LDS, the area through which a waiting batch's triangles are transposed (it lies
+    // over the sign bits and the work area, which are idle then)
+    a.slot_bytes = 0; a.stage_off = 0;
+    if (c->defer && !a.twopass && a.cull && lds > MESH_LDS_VOL + 16 * MESH_STAGE_BYTES) {
+        const size_t slot = ((lds - MESH_LDS_VOL - 16 * MESH_STAGE_BYTES) / 2) & ~(size_t)15;
+        if (slot >= MESH_SLOT_HDR + 2048 + 8192 && MESH_LDS_VOL + 2 * slot <= bits_off) {
+            a.slot_bytes = (int)slot;
+            a.stage_off = (int)(MESH_LDS_VOL + 2 * slot);
+        }
+    }
     // the first register-file variant that holds the tape's slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (2,4), 4 = (4,4), 5 = (8,8)
     static const uint32_t kFile[6][2] = {{1, 1}, {2, 2}, {4, 2}, {2, 4}, {4, 4}, {8, 8}};
     const uint32_t np = std::max(t->n_p, 1u), nd = std::max(t->n_d, 1u);
