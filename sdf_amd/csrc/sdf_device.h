@@ -330,9 +330,8 @@ __device__ __forceinline__ unsigned long long lookback_prefetch(const unsigned l
 // batch publishes its inclusive prefix a whole batch after its count, so ~ two items per workgroup -- 500 words -- carry
 // only a count at any time, and one window per round trip made the walk eight dependent trips to the coherent level
 // (6 k cycles per batch).  The lanes add up what they see; ONE wave reduction at the end.
-template <int NF = 1>   // NF: prefetched windows in first[] (lookback_prefetch of w, w - 64, ...)
 __device__ __forceinline__ unsigned long long ordered_base(unsigned long long *status, int w, int w_begin, unsigned long long total,
-                                                           unsigned max_spins, const unsigned long long *first) {
+                                                           unsigned max_spins, unsigned long long first) {
     const int lane = threadIdx.x & 63;
     if (w == w_begin) return 0;
     unsigned long long acc = 0;   // this lane's share of the exclusive prefix
@@ -341,11 +340,9 @@ __device__ __forceinline__ unsigned long long ordered_base(unsigned long long *s
     for (unsigned spins = 0; spins < max_spins;) {   // (only waiting counts as a spin, walking back does not)
         constexpr int NW = 4;
         unsigned long long sw[NW];
-        const int nwin = use_first ? NF : NW;
-        if (use_first) {
-#pragma unroll
-            for (int k = 0; k < NF; k++) sw[k] = first[k];
-        } else {
+        const int nwin = use_first ? 1 : NW;
+        if (use_first) sw[0] = first;
+        else {
 #pragma unroll
             for (int k = 0; k < NW; k++) {
                 const int j = idx - 64 * k - lane;
@@ -452,11 +449,10 @@ struct TileTasks {
 // CULL_COLINFO: per COLUMN (u0, u1) of units one word, `listed u2 (17 bits) | index of the column's first listed unit << 17`:
 // with it k_mesh finds a sample of a listed unit in a tile that stores ONLY the listed units (TileView, sparse form)
 enum { CULL_UNIT_CAP = 3072, CULL_ULIST = 8, CULL_SSTATE = CULL_ULIST + 2 * CULL_UNIT_CAP, CULL_COLINFO = CULL_SSTATE + 4096,
-       CULL_AXES = CULL_COLINFO + 1160,      // the tile's 3 x 33 axis values (float64), so that k_mesh needs ONE round trip per batch
-       CULL_RECORD = CULL_AXES + 792,
+       CULL_RECORD = CULL_COLINFO + 1160,
        CULL_MSTATE = CULL_RECORD, CULL_GSTATE = CULL_MSTATE + 64, CULL_ELIST = CULL_GSTATE + 512, CULL_PACC = CULL_ELIST + 1024,
        CULL_SCRATCH = CULL_PACC + 64 };
-static_assert(CULL_RECORD % 8 == 0 && CULL_SSTATE % 8 == 0 && CULL_COLINFO % 8 == 0 && CULL_AXES % 8 == 0, "the record is copied in words; its state rows are read as u64");
+static_assert(CULL_RECORD % 8 == 0 && CULL_SSTATE % 8 == 0 && CULL_COLINFO % 8 == 0, "the record is copied in words; its state rows are read as u64");
 // sample `lane` of task `task` of a culled tile (units: the record's list); false: no such sample (ix, iy, iz are valid
 // indices all the same)
 __device__ __forceinline__ bool cull_sample(const unsigned short *units, int task, int lane, int lx, int ly, int lz, int &ix, int &iy, int &iz) {
@@ -695,8 +691,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             const bool block = must || pq_count > MESH_PARK_DEPTH - need;
             if (tid < 64) {
                 const unsigned long long pre = first ? pre_pend : lookback_prefetch(a.status, pend_w, work_begin);
-                const unsigned long long excl = ordered_base<1>(a.status, pend_w, work_begin, (unsigned long long)pend_total,
-                                                                block ? MESH_SPIN_FOREVER : a.park_spins, &pre);
+                const unsigned long long excl = ordered_base(a.status, pend_w, work_begin, (unsigned long long)pend_total,
+                                                             block ? MESH_SPIN_FOREVER : a.park_spins, pre);
                 if (tid == 0) {
                     if (excl != MESH_NOT_READY) settle(pend_w, excl, (unsigned long long)pend_total);
                     reinterpret_cast<unsigned long long *>(bcast + 4)[0] = excl;
@@ -808,21 +804,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // ---- what kind of tile?  (the header word of k_cull's record: a uniform load) ----
         bool flush_only = finished;   // this round only writes the waiting batch
         int b = 0, ntl_cull = -1;     // listed tasks of a culled tile (-1: not culled)
-        constexpr int RW = 1024 / BLOCK;
-        unsigned r_ul[2 * RW], r_ss[RW], r_ci = 0, r_ax = 0;   // k_cull's record of the batch on its way into LDS
         bool sparse = false;
         if (!finished) {
-            // ONE round trip behind the work item: the batch index, the header of k_cull's record AND the record itself
-            // (units, sub-group states, column words, axes: fixed places, so the loads do not wait for the header)
-            const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
-            const int b_v = a.worklist[w];
-            const unsigned n0_v = a.cull ? rec[0] : 0xFFFFu;
-            if (a.cull) {
-                SDF_UNROLL for (int k = 0; k < 2 * RW; k++) { const int i = tid + k * BLOCK; r_ul[k] = i < CULL_SSTATE / 4 ? rec[i] : 0u; }
-                SDF_UNROLL for (int k = 0; k < RW; k++) r_ss[k] = rec[CULL_SSTATE / 4 + tid + k * BLOCK];
-                r_ci = tid < 289 ? rec[CULL_COLINFO / 4 + tid] : 0u;
-                r_ax = tid < 198 ? rec[CULL_AXES / 4 + tid] : 0u;
-            }
+            const int b_v = a.worklist[w];                                        // (both loads in flight before either is waited for)
+            const unsigned n0_v = a.cull ? reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[0] : 0xFFFFu;
             b = uni(b_v);
             const unsigned n0 = (unsigned)uni((int)n0_v) & 0xFFFFu;
             if (n0 != 0xFFFFu) ntl_cull = (int)((n0 + 7u) >> 3);
@@ -845,25 +830,22 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         int total = 0, c1 = 1;
         float inv_c1 = 1.0f;
         bool list_ready = false, emit_cur = false;
-        unsigned long long pre_own = 0, pre_pend = 0, pre_dq[4] = {0, 0, 0, 0};
+        unsigned long long pre_own = 0, pre_dq = 0, pre_pend = 0;
         if (!flush_only) {
         // k_cull's record of the batch (cull_tasks) travels next to the axes: units and sub-group states into the work area
         // (idle until the cells of a dense tile are listed), the column words into the batch's slot
         if (culled) {
+            const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
             const int nwords = (CULL_ULIST + 16 * ntl_cull + 3) >> 2;
-            SDF_UNROLL for (int k = 0; k < 2 * RW; k++) { const int i = tid + k * BLOCK; if (i < nwords) wlist[i] = r_ul[k]; }
-            SDF_UNROLL for (int k = 0; k < RW; k++) wlist[CULL_SSTATE / 4 + tid + k * BLOCK] = r_ss[k];
-            if (sparse && tid < 289) reinterpret_cast<unsigned *>(cs + MESH_SLOT_COLINFO)[tid] = r_ci;
+            for (int i = tid; i < nwords; i += BLOCK) wlist[i] = rec[i];
+            for (int i = tid; i < 1024; i += BLOCK) wlist[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
+            if (sparse) for (int i = tid; i < 289; i += BLOCK) reinterpret_cast<unsigned *>(cs + MESH_SLOT_COLINFO)[i] = rec[CULL_COLINFO / 4 + i];
         }
         int ox, oy, oz;
         batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-        if (a.cull) {   // (k_cull left the tile's axes in its record, whether it culled the tile or not)
-            if (tid < 198) reinterpret_cast<unsigned *>(axes)[tid] = r_ax;
-        } else {
-            if (tid < lx) axes[tid] = g.X[ox + tid];
-            else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
-            else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
-        }
+        if (tid < lx) axes[tid] = g.X[ox + tid];
+        else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
+        else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
         __syncthreads();
         SDF_PROF(0);
 
@@ -976,10 +958,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // parked one -- so that the answers arrive while the cells are counted)
         if (tid < 64 && !TWOPASS) {
             if (!sparse) pre_own = lookback_prefetch(a.status, w, work_begin);   // (a sparse tile's batch waits a round: asked for then)
-            if (dq_slot >= 0) {   // (four windows: ~ 500 predecessors carry only a count while their own batches wait, see ordered_base)
-                const int dw = uni(reinterpret_cast<const int *>(slot_base(dq_slot) + 48)[0]);
-                SDF_UNROLL for (int k = 0; k < 4; k++) pre_dq[k] = lookback_prefetch(a.status, dw - 64 * k, work_begin);
-            }
+            if (dq_slot >= 0) pre_dq = lookback_prefetch(a.status, reinterpret_cast<const int *>(slot_base(dq_slot) + 48)[0], work_begin);
             if (pq_count > 0) pre_pend = lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin);
         }
         const int c0 = lx - 1, c2 = lz - 1;
@@ -1249,13 +1228,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             const bool may_park = a.park && e_total <= a.park_cap;
             const bool block = !may_park || (is_dq && finished);   // (at the end of the list there is nothing else to do but wait)
             if (tid < 64) {
-                unsigned long long excl;
-                const unsigned spins = block ? MESH_SPIN_FOREVER : a.park_spins;
-                if (is_dq && !flush_only) excl = ordered_base<4>(a.status, e_w, work_begin, (unsigned long long)e_total, spins, pre_dq);
-                else {
-                    const unsigned long long pre = (is_dq || sparse) ? lookback_prefetch(a.status, e_w, work_begin) : pre_own;
-                    excl = ordered_base<1>(a.status, e_w, work_begin, (unsigned long long)e_total, spins, &pre);
-                }
+                const unsigned long long pre = is_dq ? (flush_only ? lookback_prefetch(a.status, e_w, work_begin) : pre_dq)
+                                                     : (sparse ? lookback_prefetch(a.status, e_w, work_begin) : pre_own);
+                const unsigned long long excl = ordered_base(a.status, e_w, work_begin, (unsigned long long)e_total, block ? MESH_SPIN_FOREVER : a.park_spins, pre);
                 if (tid == 0) {
                     if (excl != MESH_NOT_READY) settle(e_w, excl, (unsigned long long)e_total);
                     reinterpret_cast<unsigned long long *>(bcast + 2)[0] = excl;

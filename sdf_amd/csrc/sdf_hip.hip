@@ -285,8 +285,7 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
         const unsigned *src = reinterpret_cast<const unsigned *>(scratch);
         const int nwords = ntl < 0 ? 1 : (CULL_ULIST + 16 * ntl + 3) >> 2;
         for (int i = tid; i < nwords; i += CB) rec[i] = src[i];
-        if (ntl >= 0) for (int i = tid; i < (CULL_AXES - CULL_SSTATE) / 4; i += CB) rec[CULL_SSTATE / 4 + i] = src[CULL_SSTATE / 4 + i];   // sub-group states + column words
-        for (int i = tid; i < 198; i += CB) rec[CULL_AXES / 4 + i] = reinterpret_cast<const unsigned *>(axes)[i];   // (always: k_mesh takes the tile's axes from here)
+        if (ntl >= 0) for (int i = tid; i < (CULL_RECORD - CULL_SSTATE) / 4; i += CB) rec[CULL_SSTATE / 4 + i] = src[CULL_SSTATE / 4 + i];   // sub-group states + column words
     }
     // ---- every work item of the tail of the list leaves its cost estimate for k_mesh, which hands the tail out by
     // descending cost (MeshArgs::order) ----
