@@ -630,10 +630,11 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
 //   [0, 64)        the batch as the emission needs it later: offset[3], scale[3] (double), work item, triangles, tasks
 //   [64, 1232)     k_cull's column words (TileView::colinfo)
 //   [1232, ..)     64 floats per listed task (eight units of 2^3 samples), then the batch's triangle list
-//   behind the two slots, up to the end of LDS (over the sign bits and the work area, both idle by then): per wave 64 x 9
-//   floats through which the triangles of a waiting batch are transposed, so that consecutive lanes store consecutive
-//   coordinates of the soup (whole cache lines per store instruction instead of 72-byte strides)
-enum { MESH_SLOT_HDR = 1232, MESH_SLOT_COLINFO = 64, MESH_STAGE_BYTES = 64 * 9 * 4 };
+//   between the two slots and the sign bits: per wave 32 x 9 floats through which the triangles of a waiting batch are
+//   transposed, so that consecutive lanes store consecutive coordinates of the soup (whole cache lines per store
+//   instruction instead of 72-byte strides).  The sign bits and the work area behind it stay free during that emission:
+//   the LAST wave of the workgroup uses the time to take the next work item and bring its record and axes in (k_mesh).
+enum { MESH_SLOT_HDR = 1232, MESH_SLOT_COLINFO = 64, MESH_STAGE_BYTES = 32 * 9 * 4 };   // (a wave transposes its 64 triangles in two halves)
 
 template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK, bool TWOPASS = false>
 __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
@@ -761,11 +762,28 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     int dq_slot = -1;          // the slot of the counted batch whose triangles are still to be written (-1: none)
     bool carry = false;        // the work item in `w` was taken in the previous round (which only wrote the waiting batch)
     int w = 0;
+    // The next work item, taken EARLY: while the other waves write the waiting batch's triangles, the last wave draws the
+    // next item from the counter and brings what the round after needs -- batch index, header, k_cull's record, the
+    // tile's axes -- into LDS (bcast[8..11], the work area, `axes`: all idle then).  Taking an item, its header and its
+    // record were three dependent round trips to device memory at the top of every round (13 k cycles of 76 k per batch
+    // at 512^3, SDF_MESH_PROF); now they run under the emission.  Items are still handed out in order of the counter, a
+    // workgroup merely holds its next one a little earlier; items of the cost-ordered tail are drawn but not loaded (their
+    // rank decides which batch the draw stands for).
+    bool nx_valid = false;     // bcast[8] holds the counter value of the next item (drawn by the last round)
+    bool have = false;         // ... and its batch index / header are in bcast[9..10], record and axes in LDS
     for (;;) {
         SDF_FRESH();
         dq_slot = uni(dq_slot); pq_head = uni(pq_head); pq_count = uni(pq_count);   // (uniform by construction)
         if (!carry) {
-            if (tid == 0) { const int idx = (int)atomicAdd(&a.ctr->work_counter, 1u); bcast[0] = work_begin + idx; bcast[1] = idx; }
+            if (nx_valid) {   // (uniform) drawn during the last round's emission; visible since that round's last barrier
+                if (tid == 0) { const int idx = bcast[8]; bcast[0] = work_begin + idx; bcast[1] = idx; }
+                have = uni(bcast[11]) != 0;
+            } else {
+                if (tid == 0) { const int idx = (int)atomicAdd(&a.ctr->work_counter, 1u); bcast[0] = work_begin + idx; bcast[1] = idx; }
+                have = false;
+            }
+            nx_valid = false;
+            SDF_PROF(42);
             __syncthreads();
             w = bcast[0];
             // Items are handed out in list order, so that the predecessors of a batch are always held by running
@@ -777,7 +795,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             // workgroups, hence some workgroup is always free to take the item everybody waits for.
             {
                 const int n_work = work_end - work_begin, tail = min(a.tail, n_work), r = bcast[1] - (n_work - tail);
-                if (a.order && r >= 0 && r < tail) {   // (uniform)
+                if (a.order && r >= 0 && r < tail && !have) {   // (uniform; an item that came with its record is not of the tail)
                     int *cost = reinterpret_cast<int *>(wlist), *rnk = cost + 256;   // (the work area is idle here)
                     for (int i = tid; i < 256; i += BLOCK) { cost[i] = i < tail ? a.order[i] : -1; rnk[i] = 0; }
                     __syncthreads();
@@ -797,6 +815,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
         }
         w = uni(w);
+        SDF_PROF(43);
         carry = false;
         const bool finished = w >= work_end;
         if (finished && a.prof && tid == 0 && a.prof[64 + 4 * blockIdx.x + 1] == 0) a.prof[64 + 4 * blockIdx.x + 1] = wall_clock64();
@@ -806,8 +825,13 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         int b = 0, ntl_cull = -1;     // listed tasks of a culled tile (-1: not culled)
         bool sparse = false;
         if (!finished) {
-            const int b_v = a.worklist[w];                                        // (both loads in flight before either is waited for)
-            const unsigned n0_v = a.cull ? reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[0] : 0xFFFFu;
+            int b_v;
+            unsigned n0_v;
+            if (have) { b_v = bcast[9]; n0_v = (unsigned)bcast[10]; }
+            else {
+                b_v = a.worklist[w];                                                  // (both loads in flight before either is waited for)
+                n0_v = a.cull ? reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[0] : 0xFFFFu;
+            }
             b = uni(b_v);
             const unsigned n0 = (unsigned)uni((int)n0_v) & 0xFFFFu;
             if (n0 != 0xFFFFu) ntl_cull = (int)((n0 + 7u) >> 3);
@@ -815,6 +839,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             if (!sparse && dq_slot >= 0) { flush_only = true; carry = true; }   // a dense tile takes the slots' region
         }
         const bool culled = ntl_cull >= 0;
+        SDF_PROF(44);
         const int cur_slot = dq_slot == 0 ? 1 : 0;
         // the current batch: where its samples, its cell table / triangle list live
         unsigned char *cs = slot_base(sparse ? cur_slot : 0);
@@ -834,18 +859,22 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (!flush_only) {
         // k_cull's record of the batch (cull_tasks) travels next to the axes: units and sub-group states into the work area
         // (idle until the cells of a dense tile are listed), the column words into the batch's slot
-        if (culled) {
-            const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
-            const int nwords = (CULL_ULIST + 16 * ntl_cull + 3) >> 2;
-            for (int i = tid; i < nwords; i += BLOCK) wlist[i] = rec[i];
-            for (int i = tid; i < 1024; i += BLOCK) wlist[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
-            if (sparse) for (int i = tid; i < 289; i += BLOCK) reinterpret_cast<unsigned *>(cs + MESH_SLOT_COLINFO)[i] = rec[CULL_COLINFO / 4 + i];
-        }
         int ox, oy, oz;
         batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-        if (tid < lx) axes[tid] = g.X[ox + tid];
-        else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
-        else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
+        if (have) {   // (uniform) record and axes came in during the last round's emission; the column words wait in the work area
+            if (sparse) for (int i = tid; i < 289; i += BLOCK) reinterpret_cast<unsigned *>(cs + MESH_SLOT_COLINFO)[i] = wlist[CULL_COLINFO / 4 + i];
+        } else {
+            if (culled) {
+                const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
+                const int nwords = (CULL_ULIST + 16 * ntl_cull + 3) >> 2;
+                for (int i = tid; i < nwords; i += BLOCK) wlist[i] = rec[i];
+                for (int i = tid; i < 1024; i += BLOCK) wlist[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
+                if (sparse) for (int i = tid; i < 289; i += BLOCK) reinterpret_cast<unsigned *>(cs + MESH_SLOT_COLINFO)[i] = rec[CULL_COLINFO / 4 + i];
+            }
+            if (tid < lx) axes[tid] = g.X[ox + tid];
+            else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
+            else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
+        }
         __syncthreads();
         SDF_PROF(0);
 
@@ -1007,6 +1036,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             ncells += tot;
         }
         ncells = uni(ncells);
+        SDF_PROF(45);
         // ---- 2b. ONE THREAD PER SURFACE CELL (up to MESH_CELL_CHUNKS * BLOCK of them).  The row's thread only
         // SCATTERS its cells -- (row, column) into a table at the cell's running index, a few
         // ALU instructions and one LDS write each, nothing to wait for; then thread s takes cell s: looks up its
@@ -1070,6 +1100,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 per_cell = false;
             }
         }
+        SDF_PROF(46);
         SDF_UNROLL for (int k = 0; k < RPT; k++) { row_tris[k] = 0; row_off[k] = 0; }
         if (!list_ready) {
             // ---- 2c. per-row counting: a thread owns the i2-rows of cells (i0, i1) = row tid + k * BLOCK ----
@@ -1207,6 +1238,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (flush_only && pq_count > 0 && tid < 64) pre_pend = lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin);
         place_parked(pre_pend, false, (emit_cur ? 1 : 0) + (dq_slot >= 0 ? 1 : 0));
         if (a.prof && tid == 0) atomicAdd(&a.prof[6], (unsigned long long)(clock64() - tp0)); }
+        SDF_PROF(47);
         // (two copies of this code, one per kind of batch, rather than one loop over both: the rows' sign strings and offsets
         // that only a list built in passes needs would otherwise stay in registers through the waiting batch's emission)
         auto emit_stage = [&](auto is_dq_tag) {
@@ -1234,10 +1266,45 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (tid == 0) {
                     if (excl != MESH_NOT_READY) settle(e_w, excl, (unsigned long long)e_total);
                     reinterpret_cast<unsigned long long *>(bcast + 2)[0] = excl;
+                    bcast[12] = 0;   // (the waiting batch's triangles are handed to the waves in chunks of 64: below)
                 }
             }
             __syncthreads();
+            // ---- the last wave takes the next work item while the others start on the triangles (see `nx_valid` above) ----
+            const bool prefetch = is_dq && !finished && !carry && a.stage_off > 0;   // (uniform; `carry`: the next item is in hand already)
+            if (prefetch && tid >= BLOCK - 64) {
+                const int ln = tid & 63;
+                int idx = 0;
+                if (ln == 0) idx = (int)atomicAdd(&a.ctr->work_counter, 1u);
+                idx = uni(idx);
+                const int nw_ = work_begin + idx;
+                const int n_work = work_end - work_begin, tail = min(a.tail, n_work);
+                const bool in_tail = a.order && idx >= n_work - tail;
+                int loaded = 0, nb_ = 0;
+                unsigned nn0 = 0xFFFFu;
+                if (nw_ < work_end && !in_tail) {   // (wave-uniform)
+                    const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)nw_ * CULL_RECORD);
+                    const int nbv = a.worklist[nw_];
+                    const unsigned n0v = a.cull ? rec[0] : 0xFFFFu;
+                    nb_ = uni(nbv);
+                    nn0 = (unsigned)uni((int)n0v) & 0xFFFFu;
+                    int nox, noy, noz, nlx, nly, nlz;
+                    batch_origin(g, nb_, nox, noy, noz, nlx, nly, nlz);
+                    if (ln < nlx) axes[ln] = g.X[nox + ln];                       // (the waiting batch's transform sits in its slot)
+                    if (ln < nly) axes[33 + ln] = g.Y[noy + ln];
+                    if (ln < nlz) axes[66 + ln] = g.Z[noz + ln];
+                    if (nn0 != 0xFFFFu) {
+                        const int nwords = (int)((CULL_ULIST + 2u * ((nn0 + 7u) & ~7u) + 3u) >> 2);
+                        for (int i = ln; i < nwords; i += 64) wlist[i] = rec[i];
+                        for (int i = ln; i < (CULL_RECORD - CULL_SSTATE) / 4; i += 64) wlist[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];   // states + column words
+                    }
+                    loaded = 1;
+                }
+                if (ln == 0) { bcast[8] = idx; bcast[9] = nb_; bcast[10] = (int)nn0; bcast[11] = loaded; }
+            }
+            if (prefetch) nx_valid = true;
             const unsigned long long base = uni64(reinterpret_cast<unsigned long long *>(bcast + 2)[0]);
+            SDF_PROF(48);
             const bool parking = base == MESH_NOT_READY;
             const bool fits = parking || (base != ~0ull && base + (unsigned long long)e_total <= a.out_cap);
             const int park_slot = (pq_head + pq_count) % MESH_PARK_DEPTH;   // (the FIFO has room: a full one was waited for above)
@@ -1285,7 +1352,15 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 double *dst0 = a.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
                 float *park0 = my_park + ((size_t)park_slot * (size_t)a.park_cap + (size_t)lo) * 9;
                 const bool staged = is_dq && a.stage_off > 0 && !parking;   // (uniform)
-                for (int t0 = tid & ~63; t0 < ecn; t0 += BLOCK) {   // (whole waves: the transposition below is wave-wide)
+                // (whole waves: the transposition below is wave-wide.  The waiting batch's triangles go to the waves in chunks of 64
+                // as they come for them -- the last wave joins late, it has taken the next work item first)
+                for (int t0 = tid & ~63;; t0 += BLOCK) {
+                    if (is_dq) {
+                        int ch = 0;
+                        if ((tid & 63) == 0) ch = atomicAdd(&bcast[12], 1);
+                        t0 = 64 * uni(ch);
+                    }
+                    if (t0 >= ecn) break;
                     const int t = t0 + (tid & 63);
                     const bool live = t < ecn;
                     const unsigned e = lst[live ? t : ecn - 1];
@@ -1308,23 +1383,26 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         // c % 3 and 64 % 3 == 1: the axis of a lane's k-th coordinate is (l + k) % 3.
                         float *stg = reinterpret_cast<float *>(smem + a.stage_off) + (tid >> 6) * (MESH_STAGE_BYTES / 4);
                         const int ln = tid & 63;
-                        if (live) { SDF_UNROLL for (int q = 0; q < 9; q++) stg[ln * 9 + q] = o[q]; }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const int nval = min(64, ecn - t0) * 9;
                         const int a0 = ln % 3;
                         const double s_[3] = {a0 == 0 ? sc0 : (a0 == 1 ? sc1 : sc2), a0 == 0 ? sc1 : (a0 == 1 ? sc2 : sc0), a0 == 0 ? sc2 : (a0 == 1 ? sc0 : sc1)};
                         const double o_[3] = {a0 == 0 ? of0 : (a0 == 1 ? of1 : of2), a0 == 0 ? of1 : (a0 == 1 ? of2 : of0), a0 == 0 ? of2 : (a0 == 1 ? of0 : of1)};
-                        if (a.compact) {
-                            float *dstw = reinterpret_cast<float *>(a.out) + (base + (unsigned long long)(lo + t0)) * 9ull;
-                            SDF_UNROLL for (int k = 0; k < 9; k++) { const int c = 64 * k + ln; if (c < nval) dstw[c] = stg[c]; }
-                        } else {
-                            double *dstw = dst0 + (size_t)t0 * 9;
-                            SDF_UNROLL for (int k = 0; k < 9; k++) { const int c = 64 * k + ln; if (c < nval) SDF_SOUP_STORE(dstw + c, (double)stg[c] * s_[k % 3] + o_[k % 3]); }
+                        SDF_UNROLL
+                        for (int h = 0; h < 2; h++) {   // the wave's 64 triangles in two halves of 32 (288 coordinates = 4.5 per lane)
+                            if (live && (ln >> 5) == h) { SDF_UNROLL for (int q = 0; q < 9; q++) stg[(ln & 31) * 9 + q] = o[q]; }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const int nval = min(32, ecn - t0 - 32 * h) * 9;   // (<= 0: nothing)
+                            if (a.compact) {
+                                float *dstw = reinterpret_cast<float *>(a.out) + (base + (unsigned long long)(lo + t0 + 32 * h)) * 9ull;
+                                SDF_UNROLL for (int k = 0; k < 5; k++) { const int c = 64 * k + ln; if (c < nval) dstw[c] = stg[c]; }
+                            } else {
+                                double *dstw = dst0 + (size_t)(t0 + 32 * h) * 9;
+                                SDF_UNROLL for (int k = 0; k < 5; k++) { const int c = 64 * k + ln; if (c < nval) SDF_SOUP_STORE(dstw + c, (double)stg[c] * s_[k % 3] + o_[k % 3]); }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();   // (the area is rewritten by the next half)
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();   // (the area is rewritten by the wave's next 64 triangles)
                     } else if (!live) {
                     } else if (parking || a.compact) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
                         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -1351,6 +1429,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (emit_cur) emit_stage(std::integral_constant<bool, false>());       // (uniform)
         if (dq_slot >= 0) emit_stage(std::integral_constant<bool, true>());    // (uniform)
         dq_slot = sparse_next ? cur_slot : -1;
+        SDF_PROF(49);
         if (finished) break;
     }
     SDF_FRESH();

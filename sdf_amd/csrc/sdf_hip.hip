@@ -1038,12 +1038,12 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     const size_t lds = list_off + list_cap * 4;
     // two slots of sparse tiles share the dense tile's region (deferred emission, k_mesh); a slot has to hold its header,
     // some samples and the cell table of the per-cell counting -- else every tile stays dense
-    // -- and behind them, up to the end of LDS, the area through which a waiting batch's triangles are transposed (it lies
-    // over the sign bits and the work area, which are idle then)
+    // -- and between them and the sign bits the area through which a waiting batch's triangles are transposed (the sign bits
+    // and the work area stay free: the next work item's record arrives there meanwhile)
     a.slot_bytes = 0; a.stage_off = 0;
-    if (c->defer && !a.twopass && a.cull && lds > MESH_LDS_VOL + 16 * MESH_STAGE_BYTES) {
-        const size_t slot = ((lds - MESH_LDS_VOL - 16 * MESH_STAGE_BYTES) / 2) & ~(size_t)15;
-        if (slot >= MESH_SLOT_HDR + 2048 + 8192 && MESH_LDS_VOL + 2 * slot <= bits_off) {
+    if (c->defer && !a.twopass && a.cull && bits_off > MESH_LDS_VOL + 16 * MESH_STAGE_BYTES) {
+        const size_t slot = ((bits_off - MESH_LDS_VOL - 16 * MESH_STAGE_BYTES) / 2) & ~(size_t)15;
+        if (slot >= MESH_SLOT_HDR + 2048 + 8192 && list_cap * 4 >= CULL_RECORD) {
             a.slot_bytes = (int)slot;
             a.stage_off = (int)(MESH_LDS_VOL + 2 * slot);
         }
@@ -1437,6 +1437,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                     pc[16], pc[17], pc[18], pc[19], pc[23], pc[22], pc[20], pc[21]);
             fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu\n", pc[24], pc[25]);
             fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu\n", pc[8], pc[9], pc[10], pc[11]);
+            fprintf(stderr, "[k_mesh prof] fine: atomic %llu barrier+rank %llu header %llu | rows %llu cells %llu | placing %llu look-back %llu | round end %llu\n",
+                    pc[42], pc[43], pc[44], pc[45], pc[46], pc[47], pc[48], pc[49]);
             fprintf(stderr, "[k_mesh prof] %.3f ms; cycles/WG-sum: grab %llu sample %llu count %llu (of which placing the parked batch %llu) list %llu emit %llu tail %llu; %llu batches parked, %llu written one batch later from their slot\n",
                     ms, pc[0], pc[1], pc[2], pc[6], pc[3], pc[4], pc[5], pc[7], pc[12]);
         }
