@@ -1347,7 +1347,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                             if (pos >= 0 && pos < ecn) lst[pos] = e | (unsigned)j;
                     }
                 }
-                __syncthreads();
+                if (!is_dq) __syncthreads();   // (the list rebuilt above; a waiting batch's list has been in its slot for a round --
+                                               // and the last wave, busy with the next work item, must not be waited for here)
                 SDF_PROF(3);
                 double *dst0 = a.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
                 float *park0 = my_park + ((size_t)park_slot * (size_t)a.park_cap + (size_t)lo) * 9;
@@ -1368,9 +1369,13 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
                     float o[9];
                     if (e & 4096u) {
-                        float c8[8];
+                        // (the out-of-line call gets an array of its OWN: `o` handed to it would have to live in scratch memory
+                        // for every triangle, not only the ambiguous ones -- 36 bytes written and read back per triangle,
+                        // r04h: a quarter of the kernel's write traffic)
+                        float c8[8], oa[9];
                         vw.cell(i0, i1, i2, c8);
-                        mc33_triangle(c8, 4, 2, i0, i1, i2, a.mc->mc33, j, o);
+                        mc33_triangle(c8, 4, 2, i0, i1, i2, a.mc->mc33, j, oa);
+                        SDF_UNROLL for (int q = 0; q < 9; q++) o[q] = oa[q];
                     } else {
                         const signed char *tt3 = tri_tab + cfg * 16 + 3 * j;
                         mc_vertex_view(vw, i0, i1, i2, tt3[0], o);
