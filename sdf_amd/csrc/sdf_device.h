@@ -445,10 +445,12 @@ struct TileTasks {
 // of its own in front of k_mesh: inside k_mesh the interval pass would run on half the waves of a workgroup that holds a
 // whole CU, and its registers would compete with the interpreter's.
 // record / scratch: [0] u16 unit count | CULL_ULIST: units | CULL_SSTATE: 16^3 sub-group states (0 unknown, 1 positive,
-// 2 negative) || scratch only, from CULL_RECORD: box states (64 B), group states (512 B), the groups to evaluate (512 u16)
+// 2 negative), TWO BITS each: word h0 * 16 + h1 holds the 16 states along h2 | CULL_COLINFO || scratch only, from CULL_RECORD:
+// box states (64 B), group states (512 B), the groups to evaluate (512 u16); the sub-group states as BYTES while the levels
+// run lie over the unit list (CULL_SBYTES: packed into the record before the units are listed)
 // CULL_COLINFO: per COLUMN (u0, u1) of units one word, `listed u2 (17 bits) | index of the column's first listed unit << 17`:
 // with it k_mesh finds a sample of a listed unit in a tile that stores ONLY the listed units (TileView, sparse form)
-enum { CULL_UNIT_CAP = 3072, CULL_ULIST = 8, CULL_SSTATE = CULL_ULIST + 2 * CULL_UNIT_CAP, CULL_COLINFO = CULL_SSTATE + 4096,
+enum { CULL_UNIT_CAP = 3072, CULL_ULIST = 8, CULL_SBYTES = CULL_ULIST, CULL_SSTATE = CULL_ULIST + 2 * CULL_UNIT_CAP, CULL_COLINFO = CULL_SSTATE + 1024,
        CULL_RECORD = CULL_COLINFO + 1160,
        CULL_MSTATE = CULL_RECORD, CULL_GSTATE = CULL_MSTATE + 64, CULL_ELIST = CULL_GSTATE + 512, CULL_PACC = CULL_ELIST + 1024,
        CULL_SCRATCH = CULL_PACC + 64 };
@@ -478,7 +480,8 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
     const int per_pass = min(BLOCK, ia_bytes / ((6 * ia_np + 2 * ia_nd) * 8)) & ~63;
     if (c0 <= 0 || c1 <= 0 || c2 <= 0 || per_pass < 64) return -1;
     unsigned short *ulist = reinterpret_cast<unsigned short *>(scratch + CULL_ULIST);
-    unsigned char *sstate = scratch + CULL_SSTATE;   // per sub-group of 2^3 cells, [h0][h1][h2], 16 per axis
+    unsigned char *sstate = scratch + CULL_SBYTES;   // per sub-group of 2^3 cells, [h0][h1][h2], 16 per axis (a byte each, over the unit list)
+    static_assert(2 * CULL_UNIT_CAP >= 4096, "the byte states lie over the unit list");
     unsigned char *mstate = scratch + CULL_MSTATE;   // per box of 8^3 cells
     unsigned char *gstate = scratch + CULL_GSTATE;   // per group of 4^3 cells
     unsigned short *elist = reinterpret_cast<unsigned short *>(scratch + CULL_ELIST);   // up to 512 groups: to evaluate, then the undecided ones
@@ -568,10 +571,11 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
     for (int r = tid; r < 256; r += BLOCK) {
         const unsigned long long lo8 = *reinterpret_cast<const unsigned long long *>(sstate + 16 * r);
         const unsigned long long hi8 = *reinterpret_cast<const unsigned long long *>(sstate + 16 * r + 8);
-        unsigned m = 0;
-        SDF_UNROLL for (int k = 0; k < 8; k++) m |= ((lo8 >> (8 * k)) & 255ull) == 0ull ? 1u << k : 0u;
-        SDF_UNROLL for (int k = 0; k < 8; k++) m |= ((hi8 >> (8 * k)) & 255ull) == 0ull ? 256u << k : 0u;
+        unsigned m = 0, pk = 0;
+        SDF_UNROLL for (int k = 0; k < 8; k++) { m |= ((lo8 >> (8 * k)) & 255ull) == 0ull ? 1u << k : 0u; pk |= (unsigned)((lo8 >> (8 * k)) & 3ull) << (2 * k); }
+        SDF_UNROLL for (int k = 0; k < 8; k++) { m |= ((hi8 >> (8 * k)) & 255ull) == 0ull ? 256u << k : 0u; pk |= (unsigned)((hi8 >> (8 * k)) & 3ull) << (2 * k + 16); }
         ub[r] = (unsigned short)m;
+        reinterpret_cast<unsigned *>(scratch + CULL_SSTATE)[r] = pk;   // the record's form: two bits per sub-group
     }
     __syncthreads();
     // one thread per COLUMN (u0, u1) of units: unit u2 of the column is listed iff one of the sub-groups {u0 - 1, u0} x
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
                 const int nwords = (CULL_ULIST + 16 * ntl_cull + 3) >> 2;
                 for (int i = tid; i < nwords; i += BLOCK) wlist[i] = rec[i];
-                for (int i = tid; i < 1024; i += BLOCK) wlist[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
+                for (int i = tid; i < 256; i += BLOCK) wlist[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
                 if (sparse) for (int i = tid; i < 289; i += BLOCK) reinterpret_cast<unsigned *>(cs + MESH_SLOT_COLINFO)[i] = rec[CULL_COLINFO / 4 + i];
             }
             if (tid < lx) axes[tid] = g.X[ox + tid];
@@ -895,7 +899,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         long long tsub = a.prof ? clock64() : 0;
 #define SDF_SUBPROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tsub)); tsub = tn; } } while (0)
         const unsigned short *units = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(wlist) + CULL_ULIST);
-        const unsigned char *sstate = reinterpret_cast<const unsigned char *>(wlist) + CULL_SSTATE;
+        const unsigned *sstate = wlist + CULL_SSTATE / 4;   // 16 x 16 words of 16 two-bit states
         int ntl = tt.ntask;
         if (culled) {
             ntl = ntl_cull;
@@ -909,18 +913,17 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;   // (+2: the row extraction reads one word ahead)
             __syncthreads();
             // <cull-sign-fill>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
-            const int hlast = (c2 - 1) >> 1;                                // the last sub-group along z owns the boundary sample too
-            for (int r = tid; r < lx * ly; r += BLOCK) {                    // a thread per row of lz samples along z
+            // a thread per row of lz samples along z.  Sub-group h of the row owns samples 2 h and 2 h + 1 (the last one, hlast,
+            // the boundary sample c2 too): its state sits at bits 2 h, 2 h + 1 of the row's word, "positive" = 01, so the
+            // samples' bits are the positive states' low bits doubled.
+            const int hlast = (c2 - 1) >> 1;
+            for (int r = tid; r < lx * ly; r += BLOCK) {
                 const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
-                const unsigned char *row = sstate + ((min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)) * 16;
-                const unsigned long long st8[2] = {*reinterpret_cast<const unsigned long long *>(row), *reinterpret_cast<const unsigned long long *>(row + 8)};
-                unsigned long long rowmask = 0ull;
-                SDF_UNROLL
-                for (int hq = 0; hq < 16; hq++) {
-                    const int hi = hq == hlast ? c2 : 2 * hq + 1;           // samples 2 hq .. hi
-                    if (hq <= hlast && ((st8[hq >> 3] >> (8 * (hq & 7))) & 255ull) == 1ull)
-                        rowmask |= ((2ull << hi) - 1ull) & ~((1ull << (2 * hq)) - 1ull);
-                }
+                const unsigned st = sstate[(min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)];
+                const unsigned pos = st & ~(st >> 1) & 0x55555555u;
+                unsigned long long rowmask = (unsigned long long)(pos | (pos << 1));
+                if ((pos >> (2 * hlast)) & 1u) rowmask |= 1ull << c2;
+                rowmask &= (2ull << c2) - 1ull;                                 // (sub-groups beyond the tile count as decided: not here)
                 if (rowmask) {
                     const int o = r * lz, sh = o & 63;
                     atomicOr(&bits[o >> 6], rowmask << sh);

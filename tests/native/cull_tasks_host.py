@@ -113,7 +113,7 @@ def generate(path):
     fill_fn = '''
 static inline int fast_div(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
 static inline void atomicOr(unsigned long long *p, unsigned long long v) { *p |= v; }
-extern "C" int cull_sign_fill_host(const unsigned char *sstate, int lx, int ly, int lz, unsigned long long *bits) {
+extern "C" int cull_sign_fill_host(const unsigned *sstate, int lx, int ly, int lz, unsigned long long *bits) {
     constexpr int BLOCK = 1024;
     const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
     for (int tid = 0; tid < BLOCK; tid++) {

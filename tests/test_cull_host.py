@@ -91,7 +91,8 @@ def _run(cull_lib, t, ax, block, levels=3):
     assert rc == 0
     n = int(rec[:2].view(np.uint16)[0])
     units = rec[ulist_off:ulist_off + 2 * cap].view(np.uint16)
-    sstate = rec[sstate_off:sstate_off + 4096].reshape(16, 16, 16)
+    packed = rec[sstate_off:sstate_off + 1024].view(np.uint32)            # two bits per sub-group, 16 along h2 per word
+    sstate = ((packed[:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3).astype(np.uint8).reshape(16, 16, 16)
     return ntl.value, n, units, sstate, rec
 
 
@@ -162,7 +163,9 @@ def test_cull_tasks_on_the_host_match_the_rules(name, samples, kind, levels, lib
     # k_mesh's sign fill: a sample's bit is set iff the sub-group that owns it (min(i, c - 1) >> 1 per axis) is decided positive
     nvox = n[0] * n[1] * n[2]
     bits = np.zeros((nvox + 63) // 64 + 2, np.uint64)
-    ss = np.ascontiguousarray(sstate)
+    lay = (ctypes.c_int * 4)()
+    cull_lib.cull_layout(lay)
+    ss = np.ascontiguousarray(rec[lay[1]:lay[1] + 1024])                  # (the record's packed states, as k_mesh reads them)
     assert cull_lib.cull_sign_fill_host(ss.ctypes.data, n[0], n[1], n[2], bits.ctypes.data) == 0
     got_bits = np.unpackbits(bits.view(np.uint8), bitorder='little')[:nvox].reshape(n).astype(bool)
     cc = [m - 1 for m in n]
