@@ -920,10 +920,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             for (int r = tid; r < lx * ly; r += BLOCK) {
                 const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
                 const unsigned st = sstate[(min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)];
-                const unsigned pos = st & ~(st >> 1) & 0x55555555u;
+                const unsigned pos = st & ~(st >> 1) & 0x55555555u & (unsigned)((4ull << (2 * hlast)) - 1ull);   // (sub-groups beyond the tile count as decided: not here)
                 unsigned long long rowmask = (unsigned long long)(pos | (pos << 1));
                 if ((pos >> (2 * hlast)) & 1u) rowmask |= 1ull << c2;
-                rowmask &= (2ull << c2) - 1ull;                                 // (sub-groups beyond the tile count as decided: not here)
                 if (rowmask) {
                     const int o = r * lz, sh = o & 63;
                     atomicOr(&bits[o >> 6], rowmask << sh);

@@ -226,3 +226,34 @@ def test_a_tile_with_nearly_everything_undecided_is_not_culled(libs, ns):
     assert len(want_units) > 3072
     ntl, cnt, units, sstate, rec = _run(cull_lib, t, ax, 128)
     assert ntl == -1
+
+
+def test_sign_fill_and_units_on_flat_tiles(libs, ns):
+    """tiles with a short axis (lz = 5: two sub-groups along z, the second owning the boundary sample; non-existent
+    sub-groups count as decided and must leave no bit) -- the grid of test_gpu.py::test_edge_cases"""
+    from sdf_amd import core, tape as tape_mod
+    cull_lib, tape_lib = libs
+    f = fixtures.build('ex_example', ns)
+    X, Y, Z, _ = core.grid_axes(((-0.9, -0.4, -0.2), (0.9, 0.5, 0.3)), (0.013, 0.05, 0.11))
+    t = tape_mod.lower(f)
+    lay = (ctypes.c_int * 4)()
+    cull_lib.cull_layout(lay)
+    seen = 0
+    for bx in range(5):
+        ax = [X[32 * bx:32 * bx + 33], Y[0:33], Z[0:33]]
+        n = [len(a) for a in ax]
+        for levels in (2, 3):
+            want_s, want_units = _model(tape_lib, t, ax, levels)
+            ntl, cnt, units, sstate, rec = _run(cull_lib, t, ax, 256, levels)
+            assert cnt != 0xFFFF and np.array_equal(sstate, want_s) and np.array_equal(units[:cnt], want_units)
+            nvox = n[0] * n[1] * n[2]
+            bits = np.zeros((nvox + 63) // 64 + 2, np.uint64)
+            ss = np.ascontiguousarray(rec[lay[1]:lay[1] + 1024])
+            assert cull_lib.cull_sign_fill_host(ss.ctypes.data, n[0], n[1], n[2], bits.ctypes.data) == 0
+            got = np.unpackbits(bits.view(np.uint8), bitorder='little')
+            cc = [m - 1 for m in n]
+            own = [np.minimum(np.arange(n[d]), cc[d] - 1) >> 1 for d in range(3)]
+            assert np.array_equal(got[:nvox].reshape(n).astype(bool), want_s[np.ix_(own[0], own[1], own[2])] == 1)
+            assert not got[nvox:].any()
+            seen += int(cnt > 0)
+    assert seen >= 4
