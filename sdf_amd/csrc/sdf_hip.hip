@@ -313,7 +313,7 @@ __global__ __launch_bounds__(CB) void k_cull(const uint32_t *__restrict__ code, 
 }
 // the variant for tapes without trigonometry and without the rarer leaves: 70 VGPRs without spilling, seven waves per
 // SIMD (the others take 99 - 104; holding them to five or six waves was measured in r02p: no faster)
-__global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_cull_lean(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
+__global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
                                                      const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
@@ -504,7 +504,6 @@ struct sdf_ctx {
     int cull_block = 0;               // SDF_CULL_BLOCK=64 / 128 / 256: threads per work item of k_cull (0: the default of the variant)
     int tail_order = 1;               // SDF_TAIL_ORDER=0: k_mesh takes the whole work list in order
     int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
-    int cull_lds_cap = 1;             // SDF_CULL_LDS_CAP=0: k_cull_lean keeps the interval state of all its threads in LDS (six workgroups per CU instead of seven)
     int defer = 1;                    // SDF_DEFER=0: k_mesh keeps every tile dense and writes (or parks) a batch's triangles right after counting it
     int cull_levels = 0;              // SDF_CULL_LEVELS=2 / 3: interval levels of k_cull (3: + sub-groups of 2^3 cells); 0: by the tape (see generate_impl)
 };
@@ -674,7 +673,6 @@ static int ctx_init(sdf_ctx *c) {
     if (const char *e = getenv("SDF_PRUNE_LIST_MIN")) c->prune_list_min = std::max(atoi(e), 0);
     if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
     if (const char *e = getenv("SDF_DEFER")) c->defer = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("SDF_CULL_LDS_CAP")) c->cull_lds_cap = atoi(e) ? 1 : 0;
     if (const char *e = getenv("SDF_CULL_LEVELS")) c->cull_levels = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
     if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(512 + 4096 * 32)) return 1; }
@@ -1277,15 +1275,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         // 0.364 + 1.52 -> 1.58 + 1.25, weave 2^33 6.6 + 24.2 -> 19.9 + 15.4.  Hence three levels for the lean tapes, two for
         // the others -- which still list units of 2^3 samples instead of r03's cubes of 4^3.
         const int cull_levels = c->cull_levels ? c->cull_levels : (kc == k_cull_lean || kc == k_cull_lean128 ? 3 : 2);
-        // LDS per work item: seven workgroups of 256 threads per CU (every work item of the 512^3 example resident at once:
-        // 1744 <= 1792) need <= 23,400 bytes each; the interval state of 192 threads instead of 256 buys that (the levels
-        // then run 192 boxes per pass) -- as long as at least 128 threads' state fits, else the full block's
-        size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 896 - CULL_SCRATCH);
-        if (kc == k_cull_lean && c->cull_lds_cap) {
-            const size_t per_thread = (size_t)(6 * ia_np + 2 * ia_nd) * 8, room = 23400 - 896 - CULL_SCRATCH;
-            const size_t threads = std::min<size_t>(room / per_thread, (size_t)cull_block) & ~(size_t)63;
-            if (threads >= 128) ia_bytes = threads * per_thread;
-        }
+        // (seven workgroups of 256 threads per CU instead of six -- 72 VGPRs, the interval state of 192 threads in LDS, so that
+        // every work item of the 512^3 example is resident at once -- was measured in r04k: example prepass 0.093 vs 0.091 ms,
+        // pawn 0.402 vs 0.266 ms: the levels then run in more passes.  Not the limit.)
+        const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 896 - CULL_SCRATCH);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
