@@ -521,6 +521,8 @@ struct sdf_tape {
     bool ia_rare = false;                                // ... one of them a leaf of ia_leaf_rare (the k_cull variant that knows them)
     uint32_t n_extern = 0;                               // user closures the tape reads through L_EXTERN leaves (sdf_eval_points_extern_*)
     unsigned long long hint_key = 0, hint_total_tris = 0;   // arena sizing: last call of this tape
+    unsigned long long content_hash = 0;                    // FNV-1a of the code words and the constants' bits: what identifies the MODEL,
+                                                            // on every rank alike and whatever address the tape object lands on (sdf_comm.inc)
 };
 
 struct sdf_mesh {
@@ -771,6 +773,12 @@ int sdf_tape_create(sdf_ctx *c, const uint32_t *code, uint32_t n_words, const do
     struct Guard { sdf_tape *t; ~Guard() { if (t) { const std::string keep = g_err; sdf_tape_destroy(t); g_err = keep; } } } guard{t};
     t->ctx = c; t->n_words = n_words; t->n_consts = n_consts;
     t->full = tape_needs_full(code, n_words, consts);
+    {
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+        mix(code, (size_t)n_words * 4); mix(consts, (size_t)n_consts * 8); mix(&n_p, 4); mix(&n_d, 4);
+        t->content_hash = h;
+    }
     t->ia_complete = true;
     for (uint32_t i = 0; i < n_words; i += 2) {
         t->ia_complete = t->ia_complete && ia_has_form(code[i] & 255u);
@@ -821,7 +829,9 @@ int sdf_tape_set_prune_info(sdf_tape *t, const uint16_t *rstart, const uint16_t 
 int sdf_tape_destroy(sdf_tape *t) {
     if (!t) return 0;
     (void)hipSetDevice(t->ctx->device);
-    (void)stream_wait(t->ctx->stream);
+    // kernels that read the tape may still run on the context's stream, on a call slot's lane or on a communicator's lanes:
+    // wait for the DEVICE (a tape is destroyed once per model, not per call)
+    (void)hipDeviceSynchronize();
     if (t->d_code) (void)hipFree(t->d_code);
     if (t->d_c64) (void)hipFree(t->d_c64);
     if (t->d_c32) (void)hipFree(t->d_c32);

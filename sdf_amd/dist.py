@@ -218,7 +218,22 @@ def _native_comm(eng, td, group):
         td.broadcast_object_list(ids, src=src, group=group)
         if isinstance(ids[0], Exception):
             raise RuntimeError('rank 0 could not draw the communicator ids: %r' % (ids[0],))
-        comm = _COMMS[key] = _engine.Comm(eng, ids[0], r, world)
+        # The creation is collective inside the library (ncclCommInitRank).  A rank whose creation FAILED (a stream, an
+        # event, pinned memory, the RCCL call itself) must not go on alone on the torch path while the others use the
+        # native one: the ranks compare notes and, if any of them failed, all close what they have and fall back together.
+        comm, err = None, None
+        try:
+            comm = _engine.Comm(eng, ids[0], r, world)
+        except Exception as e:
+            err = e
+        made = [None] * world
+        td.all_gather_object(made, (err is None, repr(err)), group=group)
+        bad = ['rank %d: %s' % (i, f[1]) for i, f in enumerate(made) if not f[0]]
+        if bad:
+            if comm is not None:
+                comm.close()
+            raise RuntimeError('communicator not created on every rank: ' + '; '.join(bad))
+        _COMMS[key] = comm
         comm._lane_owner = {}
     return comm
 
@@ -284,6 +299,10 @@ def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=No
         if held is not None:                 # the lane's buffers are about to be reused: finish that step, keep its soup
             t, st, _ = _native_finish(held)
             held.result = (t.clone(), st, None)
+            # (the copy is enqueued on torch's current stream, the next step rewrites the lane's soup on the lane's own
+            # stream: nothing else orders the two)
+            if t.is_cuda:
+                torch.cuda.current_stream(t.device).synchronize()
         step = NativeStep()
         step.comm, step.lane, step.device, step.result = comm, lane, device, None
         step.xch = comm.submit(tape, X, Y, Z, batch_size, sparse, chunks=chunks, lane=lane)
