@@ -52,6 +52,17 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 OTHER_CONFIGS = [('gearlike', 30, 10204096, 24), ('weave', 33, 53943912, 6), ('blobby', 30, 4048520, 24)]
 
 
+# DESIGN.md section 6, arithmetic for 8 GPUs (one GPU's measured stage times / 8 + fixed costs + 36 B per triangle over one xGMI
+# link at ~76 GB/s + the expansion every rank repeats); printed next to the measured stage times of an N > 1 run
+EXPECTED_SCALING = {
+    'example': 'C2 512^3: break-even by construction (~1.0 x at 8 GPUs): the work that divides is ~0.03 ms of a ~0.3 ms step; fixed: skip test, '
+               'all-gather of 13 MB slabs (~0.18 ms on the wire), k_expand of the whole soup on every rank (~0.08 ms)',
+    'gearlike': 'C3 2^30: ~2.3 x at 8 GPUs (1.6 ms -> ~0.7 ms: 46 MB slabs ~0.6 ms on the wire overlap the next step\'s meshing with two lanes)',
+    'weave': 'C4 2^33: ~3.5 x at 8 GPUs (27 ms -> ~8 ms: meshing / 8 ~3.5 ms, 243 MB slab ~3.2 ms on the wire, k_expand ~1.6 ms)',
+    'blobby': 'C5 2^30: ~2 x at 4 GPUs (1.2 ms -> ~0.6 ms)',
+}
+
+
 def build_model(name):
     import sdf_amd as s
     if name == 'example':
@@ -154,6 +165,32 @@ def watchdog(out):
     t.daemon = True
     t.start()
     return t
+
+
+def pipelined_overlap(spans, dev_ms):
+    """With several calls in flight two k_mesh launches -- lanes of their own -- may be resident at once: a k_mesh workgroup
+    holds a whole CU, so the later launch gets the CUs the earlier one leaves, and BOTH launches' first-workgroup-to-last
+    spans stretch (up to 2 x) while the steps complete at the same rate.  That is the spread of `kernel_ms_pipelined`
+    (VERDICT r03, weak 4), not a slow step: per timed step, its span on the device's constant-rate counter and how much
+    of it lies inside the spans of the steps before and after it."""
+    if not spans or not any(b > a for a, b in spans):
+        return None
+    t0 = min(a for a, b in spans if b > a)
+    rows = []
+    for i, (a, b) in enumerate(spans):
+        ov = 0.0
+        for j, (c, d) in enumerate(spans):
+            if j != i and d > c:
+                ov += max(0.0, min(b, d) - max(a, c))
+        rows.append({'start_us': round(a - t0, 1), 'span_ms': round((b - a) * 1e-3, 4), 'shared_with_neighbours_ms': round(ov * 1e-3, 4)})
+    alone = [r['span_ms'] for r in rows if r['shared_with_neighbours_ms'] < 0.02 * r['span_ms']]
+    starts = sorted(r['start_us'] for r in rows)
+    gaps = [b - a for a, b in zip(starts, starts[1:])]
+    return {'steps': rows if len(rows) <= 40 else rows[:40],
+            'span_ms_of_steps_that_ran_alone': stats3(alone) if alone else None,
+            'start_to_start_ms': stats3([g * 1e-3 for g in gaps]) if gaps else None,
+            'note': 'span = first workgroup start to last workgroup end of k_mesh on the device clock; a span overlapped by a neighbour '
+                    'is a launch that shared the CUs, not a slower kernel: the start-to-start interval is the step time'}
 
 
 def stats3(v):
@@ -294,7 +331,7 @@ def main():
         X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** samples_log2)
         trace('bounds and axes ready: %dx%dx%d' % (len(X), len(Y), len(Z)))
         state = {'n': 0}
-        inflight, mesh_ms, exch_ms, dev_ms, sclk = [], [], [], [], []
+        inflight, mesh_ms, exch_ms, dev_ms, sclk, spans = [], [], [], [], [], []
 
         def collect():
             mesh, buf = inflight.pop(0)
@@ -310,6 +347,7 @@ def main():
             st = mesh.stats()
             state['stats'], state['tris'] = st, t
             mesh_ms.append(st['ms_mesh']); dev_ms.append(st['ms_mesh_device']); sclk.append(st['sclk_mhz'])
+            spans.append((st.get('t_mesh_first_us', 0.0), st.get('t_mesh_last_us', 0.0)))
             mesh.close()
 
         def collect_dist():
@@ -365,7 +403,7 @@ def main():
             for _ in range(warmup):
                 one_step()
             sync()
-            del mesh_ms[:], exch_ms[:], dev_ms[:], sclk[:]
+            del mesh_ms[:], exch_ms[:], dev_ms[:], sclk[:], spans[:]
             t0 = time.perf_counter()
             for _ in range(steps):
                 one_step()
@@ -380,7 +418,7 @@ def main():
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt = float(tt.item())
         return {'f': f, 'tape': tape, 'X': X, 'Y': Y, 'Z': Z, 'dt': dt, 'mesh_ms': list(mesh_ms), 'exch_ms': list(exch_ms),
-                'dev_ms': list(dev_ms), 'sclk': list(sclk), 'state': state, 'grid_voxels': len(X) * len(Y) * len(Z)}
+                'dev_ms': list(dev_ms), 'sclk': list(sclk), 'spans': list(spans), 'state': state, 'grid_voxels': len(X) * len(Y) * len(Z)}
 
     DEPTH = 1 if args.sync else (max(1, min(args.inflight, 4)) if world == 1 else 2)
     # N > 1: a rank that dies or stalls leaves the others inside a collective for ever.  The headline measurement of a healthy
@@ -497,6 +535,15 @@ def main():
                      'device_ms': ({'prepass': round(float(s2['ms_prepass']), 4), 'mesh': round(float(np.median(r['mesh_ms'])), 4)} if world == 1 else
                                    {'mesh': round(float(np.mean(r['mesh_ms'])), 4), 'exchange': round(float(np.mean([e[0] for e in r['exch_ms']])), 4),
                                     'expand': round(float(np.mean([e[1] for e in r['exch_ms']])), 4), 'slab_bytes': s2.get('slab_bytes')})}
+                if world == 1:      # the config's own roofline line: k_mesh (+ k_emit2 for two-pass jobs) against the soup's bytes
+                    km = float(np.median(r['mesh_ms']))
+                    o['roofline'] = {'kernel': 'k_mesh (+ k_scan_items + k_emit2 where the tape takes the two-pass scheme)', 'kernel_ms': round(km, 4),
+                                     'algorithmic_bytes_72B': 72 * t2, 'achieved_GBps_72B': round(72e-6 * t2 / km, 1) if km > 0 else None,
+                                     'frac_72B': round(72e-6 * t2 / km / HBM_PEAK_GBS, 5) if km > 0 else None,
+                                     'frac_36B': round(36e-6 * t2 / km / HBM_PEAK_GBS, 5) if km > 0 else None,
+                                     'interpreted_voxel_share': round(float(s2.get('n_sampled_voxels', 0)) / max(float(s2['n_eval_voxels']), 1.0), 4)}
+                else:               # what DESIGN.md section 6 expects of this config on N GPUs (arithmetic, next to the measured stage times)
+                    o['expected_scaling_note'] = EXPECTED_SCALING.get(model)
                 gold = os.path.join(ROOT, 'tests', 'golden', 'full_c5_blobby_s30.npz')
                 if model == 'blobby' and rank == 0 and os.path.exists(gold) and not args.no_check:
                     o['soup_sha256_equals_reference'] = bool(soup_sha(r['state']['soup'], t2) == bytes(np.load(gold)['sha256']).hex())
@@ -542,15 +589,19 @@ def main():
     # HBM traffic of k_mesh per launch from the PMC passes of tools/profile.sh (separate rocprofv3
     # --pmc runs of this same command; FETCH_SIZE/WRITE_SIZE corrected as MI355X_MICROARCH.md says,
     # see tools/summarize_prof.py); the newest committed summary is used
-    traffic = traffic_src = None
+    traffic = traffic_src = stale_src = None
     if args.model == 'example' and args.samples_log2 == 27 and world == 1 and args.precision == 'f64':
         import glob
         for prof in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')), reverse=True):
             try:                          # (the newest summary of THIS workload: same algorithmic bytes per launch)
                 rec = json.load(open(prof))
                 if abs(float(rec.get('algorithmic_bytes_per_launch') or 0) - alg_bytes) <= 1e-3 * alg_bytes:
-                    traffic = rec.get('hbm_bytes_per_launch')
-                    traffic_src = os.path.basename(prof)
+                    # (only a summary taken on THIS source: the kernels' sources are hashed into it, tools/summarize_prof.py)
+                    if rec.get('source_id') == engine.source_id():
+                        traffic = rec.get('hbm_bytes_per_launch')
+                        traffic_src = os.path.basename(prof)
+                    elif stale_src is None:
+                        stale_src = '%s (source_id %s, this build %s)' % (os.path.basename(prof), rec.get('source_id'), engine.source_id())
             except Exception:
                 traffic = None
             if traffic:
@@ -559,13 +610,20 @@ def main():
         'kernel': 'k_mesh<%s>' % ('double' if args.precision == 'f64' else 'float'),
         'bound': 'hbm', 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
-        'traffic_source': ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured '
-                           'in this run)' % traffic_src) if traffic_src else None,
+        # the two ways of counting the soup: 72 B per triangle (float64, what the reference's generate() returns and this
+        # kernel writes: `frac` above) and SURVEY.md 8(d)'s 36 B per triangle (a float32 soup)
+        'frac_72B': round(achieved / HBM_PEAK_GBS, 6), 'frac_36B': round(0.5 * achieved / HBM_PEAK_GBS, 6),
+        'traffic_over_algorithmic': round(traffic / alg_bytes, 3) if traffic else None,
+        'source_id': engine.source_id(),
+        'traffic_source': ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this source_id, committed; '
+                           'not re-measured in this run)' % traffic_src) if traffic_src
+                          else ('none for this source: the newest committed summary is stale -- %s' % stale_src if stale_src else None),
         'kernel_ms_source': ('median of the HIP-event times around k_mesh over the isolated synchronous calls of this run '
                              '(`isolated_calls`: min / median / max, and the same kernel by its own device clock)') if world == 1
                             else 'HIP events on the exchange lane: prepass + k_mesh of this rank\'s shard (mean over the timed steps)',
         'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': round(k_ms, 4),
         'kernel_ms_pipelined': stats3(mesh_ms) if world == 1 else None,
+        'pipelined': pipelined_overlap(res['spans'], res['dev_ms']) if world == 1 else None,
         'kernel_ms_device_clock_pipelined': stats3(res['dev_ms']) if world == 1 and res['dev_ms'] else None,
         'note': 'path is VALU/latency bound by construction (SURVEY 8d): see valu',
         'valu': {'eval_voxels_per_launch': eval_vox, 'interpreted_voxels_per_launch': sampled_vox,

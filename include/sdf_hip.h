@@ -57,6 +57,8 @@ typedef struct sdf_stats {
     double ms_mesh_device;      /* the sample+march kernel by the device's own constant-rate counter: first workgroup's
                                  * start to last workgroup's end (no HIP event, no host in the measurement)        */
     double sclk_mhz;            /* shader clock that kernel ran at (its cycle counter against the constant one)    */
+    double t_mesh_first_us;     /* when that kernel's first workgroup started / its last one ended, microseconds on the */
+    double t_mesh_last_us;      /* device's constant-rate counter: calls in flight can be laid on ONE time axis          */
 } sdf_stats;
 
 int sdf_abi_version(void);

@@ -1114,6 +1114,8 @@ static void finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb
     // the kernel's own clock readings: 100 MHz ticks between the first workgroup's start and the last one's end
     m->st.ms_mesh_device = (h.t_first_inv && h.t_last > ~h.t_first_inv) ? (double)(h.t_last - ~h.t_first_inv) * 1e-5 : 0.0;
     m->st.sclk_mhz = h.clk_ticks ? (double)h.clk_cycles / (double)h.clk_ticks * 100.0 : 0.0;
+    m->st.t_mesh_first_us = h.t_first_inv ? (double)(~h.t_first_inv) * 0.01 : 0.0;
+    m->st.t_mesh_last_us = (double)h.t_last * 0.01;
     m->pruned = pruning;
     m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);

@@ -48,6 +48,7 @@ class SdfStats(ctypes.Structure):
         ('ms_prepass', ctypes.c_double), ('ms_mesh', ctypes.c_double), ('ms_emit', ctypes.c_double),
         ('ms_total', ctypes.c_double), ('n_pruned_instrs', _c_i64), ('n_batch_instrs', _c_i64),
         ('n_sampled_voxels', _c_i64), ('ms_mesh_device', ctypes.c_double), ('sclk_mhz', ctypes.c_double),
+        ('t_mesh_first_us', ctypes.c_double), ('t_mesh_last_us', ctypes.c_double),
     ]
 
 
@@ -134,6 +135,19 @@ ABI = {
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
 ABI_VERSION = 6
+
+
+def source_id():
+    """sha256 (16 hex digits) over the kernels' sources, sdf_amd/csrc/*.{h,hip,inc,sh}: what a committed rocprofv3 summary
+    was taken on (tools/summarize_prof.py writes it, bench.py only quotes a summary whose id is this build's)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+    for f in sorted(glob.glob(os.path.join(d, '*'))):
+        if os.path.isfile(f) and f.rsplit('.', 1)[-1] in ('h', 'hip', 'inc', 'sh'):
+            h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 _lib = None
 _lib_lock = threading.Lock()

@@ -98,6 +98,10 @@ def main():
         out['write_calibration_factor'] = cal
         out['hbm_bytes_per_launch'] = hbm
         out['algorithmic_bytes_per_launch'] = 72.0 * tris if tris else None
+    # which source the counters were taken on: bench.py quotes a summary only for the build it belongs to
+    sys.path.insert(0, ROOT)
+    from sdf_amd import engine as _engine
+    out['source_id'] = _engine.source_id()
     json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_pmc.json' % tag), 'w'), indent=1, sort_keys=True)
     print('\n'.join(md))
     print(json.dumps({k: out.get(k) for k in ('dominant_kernel', 'hbm_bytes_per_launch', 'algorithmic_bytes_per_launch',
