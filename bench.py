@@ -551,6 +551,20 @@ def main():
                 gold = os.path.join(ROOT, 'tests', 'golden', 'full_c5_blobby_s30.npz')
                 if model == 'blobby' and rank == 0 and os.path.exists(gold) and not args.no_check:
                     o['soup_sha256_equals_reference'] = bool(soup_sha(r['state']['soup'], t2) == bytes(np.load(gold)['sha256']).hex())
+                # every 997th triangle of the REFERENCE's soup at this size (tests/golden/full_*.npz, tools/make_golden_full.py)
+                # against the same triangles of the soup this run left on the device: positions, not only the count
+                gold = {'gearlike': 'full_c3_gearlike_s30.npz', 'blobby': 'full_c5_blobby_s30.npz'}.get(model)
+                gold = os.path.join(ROOT, 'tests', 'golden', gold) if gold else None
+                if gold and rank == 0 and os.path.exists(gold) and not args.no_check and r['state'].get('soup') is not None:
+                    gd = np.load(gold)
+                    stride, ref_tris = int(gd['sample_stride']), gd['sample_tris']
+                    if int(gd['ntri']) == t2:
+                        mine = r['state']['soup'][:9 * t2].view(t2, 3, 3)[::stride].cpu().numpy()
+                        extent = float(np.ptp(np.asarray(gd['bounds']), axis=0).max())
+                        dev = float(np.abs(mine - ref_tris).max()) / extent if mine.shape == ref_tris.shape else None
+                        o['reference_sampled_triangles'] = {'n': int(len(ref_tris)), 'stride': stride, 'max_abs_dev_over_extent': dev,
+                                                            'bit_equal_share': round(float((mine == ref_tris).mean()), 6) if dev is not None else None,
+                                                            'within_1e-5': bool(dev is not None and dev <= 1e-5)}
                 others.append(o)
                 del r
             except Exception as e:          # (reported, never fatal for the headline line)

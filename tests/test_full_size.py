@@ -174,8 +174,8 @@ def test_full_size_exchange_emulated_ranks(tag, n, chunks, passes, ns, eng):
 @pytest.mark.timeout(1800)
 def test_c4_weave_at_2_33_sampled_batches_match_oracle(ns, oracle_lib, eng):
     """BASELINE config 4 at its real size on one GPU: the batch classification of every sampled batch and
-    the triangles of >= 500 surviving batches (first, last, strided through the work list) equal the
-    oracle's; the interval passes (79 % of the instructions pruned here) on and off give the same soup"""
+    the triangles of >= 5 % of the surviving batches (first, last, a seeded random draw from the work list) equal
+    the oracle's; the interval passes (79 % of the instructions pruned here) on and off give the same soup"""
     f = fixtures.build('ex_weave', ns)
     b = np.load(os.path.join(GOLDEN, 'bounds.npz'))['ex_weave']
     bounds = tuple(map(tuple, b))
@@ -191,18 +191,25 @@ def test_c4_weave_at_2_33_sampled_batches_match_oracle(ns, oracle_lib, eng):
         assert offs[-1] == st['triangles']
         surv = np.flatnonzero(kinds != 0)
         assert len(surv) == 37872
-        pick = np.unique(np.concatenate([surv[:8], surv[-8:], surv[::71]]))
-        assert len(pick) >= 500
+        # >= 5 % of the surviving batches, drawn by a SEEDED SHUFFLE (a stride can alias the weave's period), + the ends
+        # of the list; the oracle meshes them one by one on the host's cores (ctypes releases the GIL)
+        rng = np.random.default_rng(20260922)
+        pick = np.unique(np.concatenate([surv[:8], surv[-8:], rng.permutation(surv)[:len(surv) // 20 + 1]]))
+        assert len(pick) >= 0.05 * len(surv)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def oracle_batch(bi):
+            return oracle_lib.generate(f, X, Y, Z, 32, True, batch_range=(int(bi), int(bi) + 1))
         n_equal = n_coord = 0
-        for bi in pick:
-            o = oracle_lib.generate(f, X, Y, Z, 32, True, batch_range=(int(bi), int(bi) + 1))
-            assert o.kinds[bi] == kinds[bi], bi
-            got = m.points_range(offs[bi], offs[bi + 1] - offs[bi])
-            assert got.shape == o.points.shape, bi
-            if len(got):
-                assert np.abs(got - o.points).max() <= 1e-5 * extent, bi
-                n_equal += int((got == o.points).sum()); n_coord += got.size
-        assert n_coord > 5e6 and n_equal > 0.999 * n_coord
+        with ThreadPoolExecutor(max_workers=max(1, min(32, (os.cpu_count() or 2) - 1))) as pool:
+            for bi, o in zip(pick, pool.map(oracle_batch, pick)):
+                assert o.kinds[bi] == kinds[bi], bi
+                got = m.points_range(offs[bi], offs[bi + 1] - offs[bi])
+                assert got.shape == o.points.shape, bi
+                if len(got):
+                    assert np.abs(got - o.points).max() <= 1e-5 * extent, bi
+                    n_equal += int((got == o.points).sum()); n_coord += got.size
+        assert n_coord > 2e7 and n_equal > 0.999 * n_coord
         # skipped batches in between: the oracle's skip test agrees on a strided sample of ALL batches
         for bi in range(0, 266256, 2663):
             o = oracle_lib.generate(f, X, Y, Z, 32, True, batch_range=(bi, bi + 1))

@@ -73,8 +73,11 @@ def test_float32_mode_is_close(ns, golden_values, eng):
 @pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 22), ('ex_blobby', 2 ** 21), ('ex_gearlike', 2 ** 21)])
 def test_float32_envelope(name, samples, ns, eng):
     """the float32 mode's soup against the float64 one (bench.py's SECONDARY field `f32_envelope`, tools/f32envelope.py at
-    the BASELINE sizes): the tolerance north_star states for floating point is 1e-5 relative.  Vertices, not positions in
-    the soup, are compared: a sample whose sign differs between the modes re-triangulates the cells around one grid vertex"""
+    the BASELINE sizes).  The mode is a DIAGNOSTIC: it is NOT within north_star's 1e-5 at its maximum (3.1e-5 at C2, 1.2e-4
+    at C3), and this test asserts what is measured, not that tolerance: equal skip verdicts, (nearly)
+    equal triangle counts, >= 99.99 % of the vertices within 1e-5 x extent, the 99.99th percentile within 1e-5, the maximum
+    within one cell diagonal.  Vertices, not positions in the soup, are compared: a sample whose sign differs between the
+    modes re-triangulates the cells around one grid vertex."""
     import bench
     f = fixtures.build(name, ns)
     X, Y, Z, _ = core.grid_axes(tuple(map(tuple, BOUNDS[name])), samples=samples)
