@@ -55,10 +55,10 @@ OTHER_CONFIGS = [('gearlike', 30, 10204096, 24), ('weave', 33, 53943912, 6), ('b
 # DESIGN.md section 6, arithmetic for 8 GPUs (one GPU's measured stage times / 8 + fixed costs + 36 B per triangle over one xGMI
 # link at ~76 GB/s + the expansion every rank repeats); printed next to the measured stage times of an N > 1 run
 EXPECTED_SCALING = {
-    'example': 'C2 512^3: break-even by construction (~1.0 x at 8 GPUs): the work that divides is ~0.03 ms of a ~0.3 ms step; fixed: skip test, '
-               'all-gather of 13 MB slabs (~0.18 ms on the wire), k_expand of the whole soup on every rank (~0.08 ms)',
-    'gearlike': 'C3 2^30: ~2.3 x at 8 GPUs (1.6 ms -> ~0.7 ms: 46 MB slabs ~0.6 ms on the wire overlap the next step\'s meshing with two lanes)',
-    'weave': 'C4 2^33: ~3.5 x at 8 GPUs (27 ms -> ~8 ms: meshing / 8 ~3.5 ms, 243 MB slab ~3.2 ms on the wire, k_expand ~1.6 ms)',
+    'example': 'C2 512^3: break-even by construction (~1.0 - 1.3 x at 8 GPUs): the work that divides is ~0.03 ms of a ~0.3 ms step; fixed: skip test, '
+               'all-gather of 6 MB slabs (~0.08 ms on the wire), k_expand of the whole soup on every rank (~0.08 ms)',
+    'gearlike': 'C3 2^30: ~2.5 x at 8 GPUs (1.6 ms -> ~0.6 ms: 21 MB slabs ~0.3 ms on the wire overlap the next step\'s meshing with two lanes)',
+    'weave': 'C4 2^33: ~4 x at 8 GPUs (27 ms -> ~6.5 ms: meshing / 8 ~3.5 ms, 115 MB slab ~1.5 ms on the wire, k_expand ~1.6 ms)',
     'blobby': 'C5 2^30: ~2 x at 4 GPUs (1.2 ms -> ~0.6 ms)',
 }
 
@@ -595,8 +595,8 @@ def main():
     shard_tris = int(st.get('n_triangles', tris)) if world == 1 else int(max(st.get('per_rank_triangles', [tris])))
     # fused design: the kernel's only HBM product is the ordered float64 soup, 9 doubles = 72 B per
     # triangle (SURVEY 8d counts 36 B for a float32 soup; the reference's soup is float64); the ranks of an
-    # N-GPU job write the 36-byte slab form instead
-    alg_bytes = (72.0 if world == 1 else 36.0) * shard_tris
+    # N-GPU job write the 16-byte slab records instead (csrc/sdf_slab.h)
+    alg_bytes = (72.0 if world == 1 else 16.0) * shard_tris
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     plain, special = tape.tape.flop_estimate()
     eval_vox = int(st['n_eval_voxels']) if world == 1 else int(st['n_eval_voxels'] // world)

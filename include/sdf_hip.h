@@ -194,12 +194,15 @@ int sdf_mesh_wait(sdf_mesh *mesh, int *emitted);
 /* Multi-GPU exchange (north_star: "batches shard naturally over the 8 GPUs of one node with an RCCL all-gather of
  * triangle buffers"; the reference itself has no distributed path).  A rank meshes its shard of the surviving-batch
  * work list into a SLAB of fixed capacity in caller-owned device memory -- header (counts, statistics, overflow
- * flag), per-work-item triangle prefix and transform, and the triangles in marching cubes' local float32 form
- * (36 bytes each instead of the 72 of the float64 soup) -- the caller all-gathers the equal-sized slabs of all
+ * flag), per-work-item triangle prefix and transform, and the triangles as 16-BYTE records (the three along-edge float32
+ * of marching cubes' local coordinates bit for bit + one word for the cell and the edges; a triangle with a vertex inside
+ * a cell keeps its nine floats in a small raw area: sdf_amd/csrc/sdf_slab.h, restated in sdf_amd/slabcodec.py) instead of
+ * the 72 bytes of the float64 soup -- the caller all-gathers the equal-sized slabs of all
  * ranks in ONE collective, and sdf_expand_slabs writes the ordered float64 soup from the gathered slabs (given in
  * final order) on every rank.  Everything is only ENQUEUED on the context's stream; the caller reads the 128-byte
  * headers (int64[16]: n_tris, n_items, overflow, n_empty, n_nonempty, n_eval, n_ambiguous, n_sampled, n_pruned,
- * n_work_total, ...) once at the end; overflow != 0 anywhere: repeat with larger capacities. */
+ * n_work_total, n_raw, need_tris, ...) once at the end; overflow != 0 anywhere: repeat with capacities >= the largest
+ * n_items and max(n_tris, need_tris). */
 size_t sdf_slab_bytes(int64_t cap_items, int64_t cap_tris);
 int sdf_generate_compact_async(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
                                int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,

@@ -27,6 +27,7 @@
 #include "sdf_interp.h"
 #include "sdf_mc33.h"
 #include "sdf_interval.h"
+#include "sdf_slab.h"
 
 namespace sdfk {
 
@@ -53,11 +54,12 @@ struct MeshCounters {   // zeroed before every k_mesh run
     // workgroup 0 saw between its start and its end on both counters (shader cycles / 100 MHz ticks = the shader clock
     // the kernel actually ran at)
     unsigned long long t_first_inv, t_last, clk_cycles, clk_ticks;
+    unsigned long long n_raw;         // compact output: triangles that went to the slab's raw area (sdf_slab.h)
     // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
     // and this shard's slice of it, so k_mesh can start without a host round trip
     int nwork, work_begin, work_end, pad_;
 };
-enum { MESH_COUNTERS_RESET_BYTES = 104 };   // the part of MeshCounters cleared before every k_mesh run
+enum { MESH_COUNTERS_RESET_BYTES = 112 };   // the part of MeshCounters cleared before every k_mesh run
 
 struct GridDesc {
     const double *X, *Y, *Z;   // device copies of the np.arange axes
@@ -91,9 +93,13 @@ struct MeshArgs {
     // compact output (multi-GPU exchange, sdf_generate_compact_async): `out` then holds 9 FLOAT32 per triangle in the
     // batch's local voxel coordinates (what marching cubes itself produces, 36 bytes instead of 72) and xf[] the
     // per-work-item transform (offset[3], scale[3], indexed by w - work_begin) that k_expand applies after the gather
+    // (since r04 a triangle of the compact form is a 16-byte record, sdf_slab.h Tri16; the few that do not have the shape
+    // go to the slab's raw area: `raw`, nine floats each, handed out by the counter n_raw)
     int compact;
     double *xf;
     int xf_cap;
+    float *raw;
+    long long raw_cap;
     // two-pass meshing (k_mesh = sample + classify, k_scan_items, k_emit2 = triangles): per work item a descriptor,
     // per surface cell a 36-byte record (cell, configuration, its 8 corner samples), per triangle a 4-byte entry
     // (record << 4 | triangle of the cell) -- handed out from two arenas by atomic cursors, in any order
@@ -279,6 +285,21 @@ __device__ __forceinline__ void mc_vertex_view(const TileView &vw, int i0, int i
     const float vlo = vw.at(x, y, z), vhi = vw.at(x + (axis == 0 ? 1 : 0), y + (axis == 1 ? 1 : 0), z + (axis == 2 ? 1 : 0));
     const float pf = mc_edge_pos((double)vlo, (double)vhi, (double)(axis == 0 ? i0 : (axis == 1 ? i1 : i2)));
     o[0] = axis == 0 ? pf : (float)x; o[1] = axis == 1 ? pf : (float)y; o[2] = axis == 2 ? pf : (float)z;
+}
+
+// compact output: triangle number `pos` of the shard's slab from its nine local floats
+__device__ __forceinline__ void store_tri16(const MeshArgs &a, unsigned long long pos, const float *o) {
+    Tri16 r;
+    if (__builtin_expect(!slab_encode16(o, r), 0)) {
+        const unsigned long long idx = atomicAdd(&a.ctr->n_raw, 1ull);
+        if (idx < (unsigned long long)a.raw_cap) {
+            float *dst = a.raw + idx * 9ull;
+            for (int q = 0; q < 9; q++) dst[q] = o[q];
+        }
+        r.code = TRI16_RAW; r.f[0] = __uint_as_float((unsigned)idx); r.f[1] = 0.0f; r.f[2] = 0.0f;
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<u4 *>(a.out)[pos] = u4{r.code, __float_as_uint(r.f[0]), __float_as_uint(r.f[1]), __float_as_uint(r.f[2])};
 }
 
 // ---- ordered allocation: exclusive prefix of the triangle counts over the work list -----------
@@ -722,12 +743,11 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 const int n9 = pend_total * 9;
                 const double sc[3] = {psc0, psc1, psc2}, of[3] = {pof0, pof1, pof2};
                 constexpr int U = 8;
-                if (a.compact) {   // (uniform) the soup keeps the local float32 form: a plain copy
-                    float *dstf = reinterpret_cast<float *>(a.out) + pbase * 9ull;
-                    for (int e0 = tid; e0 < n9; e0 += BLOCK * U) {
-                        float f[U];
-                        SDF_UNROLL for (int k = 0; k < U; k++) f[k] = src[min(e0 + k * BLOCK, n9 - 1)];
-                        SDF_UNROLL for (int k = 0; k < U; k++) if (e0 + k * BLOCK < n9) dstf[e0 + k * BLOCK] = f[k];
+                if (a.compact) {   // (uniform) the slab takes 16-byte records: a lane per parked triangle
+                    for (int t = tid; t < pend_total; t += BLOCK) {
+                        float f[9];
+                        SDF_UNROLL for (int q = 0; q < 9; q++) f[q] = src[(size_t)t * 9 + q];
+                        store_tri16(a, pbase + (unsigned long long)t, f);
                     }
                 } else
                 for (int e0 = tid; e0 < n9; e0 += BLOCK * U) {
@@ -1384,7 +1404,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         mc_vertex_view(vw, i0, i1, i2, tt3[1], o + 3);
                         mc_vertex_view(vw, i0, i1, i2, tt3[2], o + 6);
                     }
-                    if (staged) {
+                    if (a.compact && !parking) {   // (uniform) the exchange's 16-byte record, straight from the registers
+                        if (live) store_tri16(a, base + (unsigned long long)(lo + t), o);
+                    } else if (staged) {
                         // through LDS: lane l holds triangle t0 + l (9 floats); afterwards lane l stores coordinates 64 k + l,
                         // k = 0 .. 8, of the wave's 576: consecutive lanes, consecutive addresses.  Coordinate c belongs to axis
                         // c % 3 and 64 % 3 == 1: the axis of a lane's k-th coordinate is (l + k) % 3.
@@ -1400,21 +1422,15 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                             __builtin_amdgcn_wave_barrier();
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                             const int nval = min(32, ecn - t0 - 32 * h) * 9;   // (<= 0: nothing)
-                            if (a.compact) {
-                                float *dstw = reinterpret_cast<float *>(a.out) + (base + (unsigned long long)(lo + t0 + 32 * h)) * 9ull;
-                                SDF_UNROLL for (int k = 0; k < 5; k++) { const int c = 64 * k + ln; if (c < nval) dstw[c] = stg[c]; }
-                            } else {
-                                double *dstw = dst0 + (size_t)(t0 + 32 * h) * 9;
-                                SDF_UNROLL for (int k = 0; k < 5; k++) { const int c = 64 * k + ln; if (c < nval) SDF_SOUP_STORE(dstw + c, (double)stg[c] * s_[k % 3] + o_[k % 3]); }
-                            }
+                            double *dstw = dst0 + (size_t)(t0 + 32 * h) * 9;
+                            SDF_UNROLL for (int k = 0; k < 5; k++) { const int c = 64 * k + ln; if (c < nval) SDF_SOUP_STORE(dstw + c, (double)stg[c] * s_[k % 3] + o_[k % 3]); }
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             __builtin_amdgcn_wave_barrier();   // (the area is rewritten by the next half)
                         }
                     } else if (!live) {
-                    } else if (parking || a.compact) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
+                    } else if (parking) {   // 36 bytes per lane: two 16-byte stores (4-byte aligned) and one of 4
                         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                        float *dst = parking ? park0 + (size_t)t * 9
-                                             : reinterpret_cast<float *>(a.out) + (base + (unsigned long long)lo + (unsigned long long)t) * 9ull;
+                        float *dst = park0 + (size_t)t * 9;
                         *reinterpret_cast<f4u *>(dst) = f4u{o[0], o[1], o[2], o[3]};
                         *reinterpret_cast<f4u *>(dst + 4) = f4u{o[4], o[5], o[6], o[7]};
                         dst[8] = o[8];

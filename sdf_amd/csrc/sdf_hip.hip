@@ -1334,13 +1334,14 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     float ms = 0;
     for (int attempt = 0;; attempt++) {
         MeshArgs a;
-        a.compact = 0; a.xf = nullptr; a.xf_cap = 0;
+        a.compact = 0; a.xf = nullptr; a.xf_cap = 0; a.raw = nullptr; a.raw_cap = 0;
         a.twopass = 0; a.desc = nullptr; a.cells = nullptr; a.tlist = nullptr; a.cells_cap = a.tlist_cap = 0; a.block_item = nullptr;
         a.order = tail_order ? (const int *)m->order.p : nullptr; a.tail = tail_order ? tail_max : 0;
         if (compact) {
             const SlabLayout L(slab_items, cap_out);
             a.out = reinterpret_cast<double *>((unsigned char *)d_out + L.tris_off); a.out_cap = (unsigned long long)cap_out;
             a.compact = 1; a.xf = reinterpret_cast<double *>((unsigned char *)d_out + L.xf_off);
+            a.raw = reinterpret_cast<float *>((unsigned char *)d_out + L.raw_off); a.raw_cap = L.raw_cap;
             a.xf_cap = (int)std::min<int64_t>(slab_items, 0x7fffffff);
         } else if (to_caller) {
             a.out = (double *)d_out; a.out_cap = (unsigned long long)cap_out;

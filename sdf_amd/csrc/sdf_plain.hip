@@ -297,9 +297,8 @@ __global__ __launch_bounds__(256) void k_emit2(MeshArgs a) {
     __syncthreads();
     const int n9 = nt * 9;
     const unsigned long long at = T0 * 9ull;                  // (a multiple of 9: coordinate e of the workgroup belongs to axis e % 3)
-    if (a.compact) {
-        float *dst = reinterpret_cast<float *>(a.out) + at;
-        for (int e = tid; e < n9; e += 256) dst[e] = tri[e];
+    if (a.compact) {   // the exchange's 16-byte record (sdf_slab.h)
+        if (tid < nt) store_tri16(a, T0 + (unsigned long long)tid, tri + tid * 9);
     } else {
         double *dst = a.out + at;
         for (int e = tid; e < n9; e += 256) {
@@ -350,7 +349,11 @@ __global__ __launch_bounds__(256) void k_pack_slab(const MeshCounters *__restric
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         SlabHeader h = {};
         h.n_tris = (long long)ctr->total; h.n_items = n_items;
-        h.overflow = (long long)ctr->overflow | (n_items > cap_items ? 4 : 0) | ((long long)ctr->total > cap_tris ? 1 : 0);
+        h.n_raw = (long long)ctr->n_raw;
+        const bool raw_over = h.n_raw > L.raw_cap;
+        h.need_tris = raw_over ? (h.n_raw > h.n_tris / SLAB_RAW_DIV ? h.n_raw * SLAB_RAW_DIV : h.n_tris) : h.n_tris;
+        if (h.need_tris < h.n_tris) h.need_tris = h.n_tris;
+        h.overflow = (long long)ctr->overflow | (n_items > cap_items ? 4 : 0) | ((long long)ctr->total > cap_tris ? 1 : 0) | (raw_over ? 8 : 0);
         h.n_empty = ctr->n_empty; h.n_nonempty = ctr->n_nonempty; h.n_eval = (long long)ctr->n_eval;
         h.n_ambiguous = (long long)ctr->n_ambiguous; h.n_sampled = (long long)ctr->n_sampled; h.n_pruned = (long long)ctr->n_pruned;
         h.n_work_total = ctr->nwork;
@@ -422,9 +425,17 @@ __global__ __launch_bounds__(256) void k_expand(SlabPtrs slabs, int n_slabs, lon
         const unsigned long long t = T - sbase[s];
         const int i = item_of(s, t, lo, hi);
         const double *xf = reinterpret_cast<const double *>(sp[s] + L.xf_off) + (size_t)i * 6;
-        const float *src = reinterpret_cast<const float *>(sp[s] + L.tris_off) + t * 9ull;
+        const Tri16 rec = reinterpret_cast<const Tri16 *>(sp[s] + L.tris_off)[t];
         SDF_UNROLL for (int q = 0; q < 6; q++) xfs[tid * 6 + q] = xf[q];
-        SDF_UNROLL for (int q = 0; q < 9; q++) tri[tid * 9 + q] = src[q];
+        float o9[9];
+        if (rec.code & TRI16_RAW) {   // (rare: a vertex inside a cell) the nine floats wait in the slab's raw area
+            const unsigned long long ri = (unsigned long long)__float_as_uint(rec.f[0]);
+            const float *src = reinterpret_cast<const float *>(sp[s] + L.raw_off) + (ri < (unsigned long long)L.raw_cap ? ri : 0ull) * 9ull;
+            SDF_UNROLL for (int q = 0; q < 9; q++) o9[q] = src[q];
+        } else {
+            slab_decode16(rec, o9);
+        }
+        SDF_UNROLL for (int q = 0; q < 9; q++) tri[tid * 9 + q] = o9[q];
     }
     __syncthreads();
     double *dst = out + T0 * 9ull;

@@ -37,7 +37,7 @@ import numpy as np
 
 HEADER_WORDS = 16          # int64 words at the head of a slab (include/sdf_hip.h)
 MAX_SLABS = 64             # slabs one sdf_expand_slabs call takes
-H_TRIS, H_ITEMS, H_OVERFLOW, H_EMPTY, H_NONEMPTY, H_EVAL, H_AMBIGUOUS, H_SAMPLED, H_PRUNED, H_WORK = range(10)
+H_TRIS, H_ITEMS, H_OVERFLOW, H_EMPTY, H_NONEMPTY, H_EVAL, H_AMBIGUOUS, H_SAMPLED, H_PRUNED, H_WORK, H_RAW, H_NEED_TRIS = range(12)
 
 _HINTS = weakref.WeakKeyDictionary()      # tape object -> {job key: (cap_items, cap_tris, total_tris)}
 _STREAMS = {}                             # device index -> {lane: the torch stream exchange steps of that lane run on}
@@ -399,7 +399,8 @@ def collect_sharded(st):
             m.close()
     st.meshes = []
     total = int(heads[:, H_TRIS].sum())
-    need_items, need_tris = int(heads[:, H_ITEMS].max()), int(heads[:, H_TRIS].max())
+    # (device slabs: a raw area that was too small asks for the triangle capacity that comes with a larger one, csrc/sdf_slab.h)
+    need_items, need_tris = int(heads[:, H_ITEMS].max()), int(max(heads[:, H_TRIS].max(), heads[:, H_NEED_TRIS].max()))
     if (heads[:, H_OVERFLOW] & 2).any():
         raise RuntimeError('sdf_amd.dist: a rank reported a look-back timeout')
     ok = not heads[:, H_OVERFLOW].any() and need_items <= cap_items and need_tris <= cap_tris and total <= st.out_cap

@@ -1146,27 +1146,39 @@ def test_slab_exchange_emulated_ranks(name, samples, ns, eng):
 
 
 def _synthetic_slabs(eng, rng, n, cap_items, cap_tris, sizes_of):
-    """n slabs in the layout of include/sdf_hip.h (header | prefix words | transforms | local float32 triangles) written
-    by NumPy, and the float64 soup `points * scale + offset` (reference sdf/core.py:58-60) they expand to"""
+    """n slabs in the layout of csrc/sdf_slab.h (header | prefix words | transforms | 16-byte triangle records | raw area)
+    written by NumPy (sdf_amd/slabcodec.py), and the float64 soup `points * scale + offset` (reference sdf/core.py:58-60)
+    they expand to.  The triangles have marching cubes' shape (vertices on the edges of one cell); ~ 1 % do not (a vertex
+    inside a cell) and travel raw"""
+    from sdf_amd import slabcodec as sc
     sb = eng.slab_bytes(cap_items, cap_tris)
+    L = sc.layout(cap_items, cap_tris)
+    assert L['bytes'] == sb
     host = np.zeros((n, sb), np.uint8)
-    prefix_off = 128
-    xf_off = prefix_off + cap_items * 8
-    tris_off = (xf_off + cap_items * 48 + 15) & ~15
     want = [np.zeros((0, 9))]
     for s in range(n):
         sizes = sizes_of(s)
         ni, nt = len(sizes), int(sizes.sum())
         assert ni <= cap_items and nt <= cap_tris
-        head = np.zeros(16, np.int64)
-        head[0], head[1] = nt, ni
-        host[s, :128] = head.view(np.uint8)
-        host[s, prefix_off:prefix_off + ni * 8] = (np.cumsum(sizes).astype(np.uint64) | np.uint64(2 << 62)).view(np.uint8)
+        host[s, L['prefix_off']:L['prefix_off'] + ni * 8] = (np.cumsum(sizes).astype(np.uint64) | np.uint64(2 << 62)).view(np.uint8)
         xf = rng.uniform(-1, 1, (ni, 6))
         xf[:, 3:] = rng.uniform(0.01, 0.02, (ni, 3))
-        host[s, xf_off:xf_off + ni * 48] = xf.reshape(-1).view(np.uint8)
-        tri = rng.uniform(0, 32, (nt, 9)).astype(np.float32)
-        host[s, tris_off:tris_off + nt * 36] = tri.reshape(-1).view(np.uint8)
+        host[s, L['xf_off']:L['xf_off'] + ni * 48] = xf.reshape(-1).view(np.uint8)
+        c = rng.integers(0, 32, (nt, 3))
+        tri = np.zeros((nt, 3, 3), np.float32)
+        rows = np.arange(nt)
+        for k in range(3):
+            v = (c + rng.integers(0, 2, (nt, 3))).astype(np.float32)
+            frac = rng.integers(0, 3, nt)
+            v[rows, frac] = (c[rows, frac] + rng.random(nt)).astype(np.float32)
+            tri[:, k, :] = v
+        tri = tri.reshape(nt, 9)
+        inside = rng.random(nt) < 0.01
+        tri[inside] = rng.uniform(0, 32, (int(inside.sum()), 9)).astype(np.float32)
+        n_raw = sc.write_triangles(host[s], cap_items, cap_tris, tri)
+        head = np.zeros(16, np.int64)
+        head[0], head[1], head[10], head[11] = nt, ni, n_raw, nt
+        host[s, :128] = head.view(np.uint8)
         item = np.repeat(np.arange(ni), sizes)
         want.append(tri.astype(np.float64) * np.tile(xf[item, 3:], 3) + np.tile(xf[item, :3], 3))
     return host, np.concatenate(want)
