@@ -281,6 +281,10 @@ int sdf_mesh_emit_stl_host(sdf_mesh *mesh, void *h_out);
  * sdf_mesh_weld_fetch copies them out: h_points = n_unique x 3 float64 in lexicographic order,
  * h_cells = T x 3 int64, the unique-row index of every soup row. */
 int sdf_mesh_weld(sdf_mesh *mesh, int64_t *n_unique);
+/* A mesh handle over a float64 soup that ALREADY sits in device memory (n_tris x 9 doubles, e.g. the gathered soup of a
+ * multi-GPU step): sdf_mesh_emit_stl_host / sdf_mesh_weld / sdf_mesh_emit_host* then work on it like on a soup the
+ * library generated.  The memory stays the caller's (alive and complete until the handle is destroyed). */
+int sdf_mesh_adopt_soup(sdf_ctx *ctx, const void *d_soup, int64_t n_tris, sdf_mesh **out);
 int sdf_mesh_weld_fetch(sdf_mesh *mesh, double *h_points, int64_t *h_cells);
 /* Pinned host memory for the results above: copies into it run at the link rate (fresh pageable memory:
  * ~10 GB/s).  Blocks are recycled through a small free list inside the library (pinning is slow), so

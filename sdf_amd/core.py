@@ -116,7 +116,23 @@ def generate(
 
     records = welded = None
     if dist.world_size() > 1:
-        points, stats = dist.generate_sharded(eng, tape, X, Y, Z, batch_size, sparse)
+        soup, stats = dist.generate_sharded_device(eng, tape, X, Y, Z, batch_size, sparse)
+        if (_stl or _weld) and getattr(soup, 'is_cuda', False) and hasattr(eng, 'adopt_soup'):
+            # the gathered soup stays on the device: STL records / the weld are made there, as for one GPU
+            import torch
+            torch.cuda.current_stream(soup.device).synchronize()
+            mesh = eng.adopt_soup(soup.data_ptr(), soup.numel() // 9)
+            try:
+                if _stl:
+                    records = mesh.stl_records()
+                else:
+                    welded = mesh.weld()
+                points = np.empty((3 * mesh.n_triangles, 0))     # only its length is used below
+            finally:
+                mesh.close()
+            del soup
+        else:
+            points = soup.cpu().numpy().reshape(-1, 3)
     else:
         mesh = eng.generate(tape, X, Y, Z, batch_size, sparse)
         try:

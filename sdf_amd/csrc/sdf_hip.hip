@@ -1846,6 +1846,17 @@ int sdf_mesh_batch_offsets(sdf_mesh *m, int64_t *h_out) {
     return 0;
 }
 
+int sdf_mesh_adopt_soup(sdf_ctx *c, const void *d_soup, int64_t n_tris, sdf_mesh **out) {
+    if (!c || !out || n_tris < 0 || (n_tris > 0 && !d_soup)) return fail("sdf_mesh_adopt_soup: NULL argument or negative count");
+    *out = nullptr;
+    sdf_mesh *m = new sdf_mesh();
+    m->ctx = c;
+    m->emitted_to = const_cast<void *>(d_soup);
+    m->st.n_triangles = n_tris;
+    *out = m;
+    return 0;
+}
+
 int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_emit_stl_host: NULL argument");
     MESH_READY(m);

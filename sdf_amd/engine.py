@@ -126,6 +126,7 @@ ABI = {
     'sdf_mesh_emit_host_range': (ctypes.c_int, [_vp, _c_i64, _c_i64, _f64p]),
     'sdf_mesh_batch_offsets': (ctypes.c_int, [_vp, ctypes.POINTER(_c_i64)]),
     'sdf_mesh_emit_stl_host': (ctypes.c_int, [_vp, _vp]),
+    'sdf_mesh_adopt_soup': (ctypes.c_int, [_vp, _vp, _c_i64, ctypes.POINTER(_vp)]),
     'sdf_mesh_weld': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     'sdf_mesh_weld_fetch': (ctypes.c_int, [_vp, _f64p, ctypes.POINTER(ctypes.c_int64)]),
     'sdf_host_alloc': (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
@@ -676,6 +677,14 @@ class Engine:
         m._tape = dt
         m.emitted = None
         return m
+
+    def adopt_soup(self, device_ptr, n_triangles):
+        """a Mesh over a float64 soup that already sits in device memory (n_triangles x 9 doubles, the caller's: it must
+        stay alive and complete while the Mesh is used): STL records, weld and host copies then run on it like on a soup
+        the library generated -- the gathered soup of a multi-GPU step"""
+        h = _vp()
+        _check(self.lib, self.lib.sdf_mesh_adopt_soup(self.ctx, _vp(int(device_ptr)), int(n_triangles), ctypes.byref(h)))
+        return Mesh(self, h)
 
     def expand_slabs(self, slab_ptrs, cap_items, cap_tris, out_ptr, out_cap):
         """gathered slabs (device pointers, final order) -> ordered float64 soup at out_ptr (enqueue only)"""

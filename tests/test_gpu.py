@@ -759,6 +759,33 @@ def test_weld_handles_signed_zeros_and_empty(ns, eng):
     assert pts.shape == (0, 3) and cells.shape == (0, 3)
 
 
+def test_adopted_soup_gives_the_same_stl_records_and_weld(ns, eng):
+    """sdf_mesh_adopt_soup: a float64 soup that already sits in device memory (the gathered soup of a multi-GPU step, here a
+    copy of a single-GPU one) gets STL records and the weld from the same device kernels (core.generate with world > 1)"""
+    import torch
+    f = fixtures.build('ex_example', ns)
+    X, Y, Z, _ = core.grid_axes(core._estimate_bounds(f), samples=2 ** 20)
+    m = eng.generate(f, X, Y, Z, 32, True)
+    t = m.n_triangles
+    buf = torch.empty(9 * t, dtype=torch.float64, device='cuda:0')
+    m.emit_device(buf.data_ptr())
+    eng.synchronize()
+    rec, (pts, cells), soup = m.stl_records().copy(), m.weld(), m.points()
+    m.close()
+    a = eng.adopt_soup(buf.data_ptr(), t)
+    try:
+        assert a.n_triangles == t
+        assert np.array_equal(a.stl_records(), rec)
+        pts2, cells2 = a.weld()
+        assert np.array_equal(pts2, pts) and np.array_equal(cells2, cells)
+        assert np.array_equal(a.points(), soup)
+    finally:
+        a.close()
+    e = eng.adopt_soup(0, 0)           # an empty soup
+    assert e.n_triangles == 0 and len(e.stl_records()) == 0
+    e.close()
+
+
 # ---- calls in flight: sdf_generate_to_device_async / sdf_mesh_wait ----
 
 def test_async_generate_matches_sync(ns, eng):
