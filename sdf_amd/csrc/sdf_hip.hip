@@ -261,17 +261,28 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     // (one workgroup per BATCH is launched -- the host does not know the length of the work list -- and the surplus ones
     // leave here.  Striding over the list with a grid sized for the compute units was measured in r02: the loop costs the
     // kernel 10 - 20 % (example 60 -> 70 us, gearlike 2^30 prepass 0.36 -> 0.43 ms), the empty workgroups nothing.)
+    // (the grid's pointers and sizes out of the kernel-argument segment NOW, next to the counters' load: the compiler
+    // fetches a by-value struct's fields where they are first used, i.e. one dependent scalar-memory trip at a time)
+    asm volatile("" :: "s"(g.X), "s"(g.Y), "s"(g.Z), "s"(g.nx), "s"(g.ny), "s"(g.nz), "s"(g.nby), "s"(g.nbz), "s"(g.bs));
     const int w = ctr->work_begin + (int)blockIdx.x;
     if (w >= ctr->work_end) return;
+    long long t_ctr = 0, t_b = 0;
+    if (prof) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_ctr) : "s"(w) : "memory");
     const int b = __builtin_amdgcn_readfirstlane(worklist[w]);   // (uniform: the tape is then read with scalar loads)
+    if (prof) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b) : "s"(b) : "memory");
     int ox, oy, oz, lx, ly, lz;
     batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-    for (int i = tid; i < 99; i += CB) {
-        if (i < 33) { if (i < lx) axes[i] = g.X[ox + i]; }
-        else if (i < 66) { if (i - 33 < ly) axes[i] = g.Y[oy + i - 33]; }
-        else if (i - 66 < lz) axes[i] = g.Z[oz + i - 66];
+    long long t_org = 0;
+    if (prof) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_org) : "s"(ox), "s"(oy), "s"(oz), "s"(lx) : "memory");
+    for (int i = tid; i < 99; i += CB) {   // (ONE load per lane whatever the axis: three branches were three loads in a row for the first wave)
+        const int ax = i < 33 ? 0 : (i < 66 ? 1 : 2), k = i - 33 * ax;
+        const double *src = ax == 0 ? g.X + ox : (ax == 1 ? g.Y + oy : g.Z + oz);
+        if (k < (ax == 0 ? lx : (ax == 1 ? ly : lz))) axes[i] = src[k];
     }
+    long long t_ax = 0, t_bar = 0;
+    if (prof) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_ax) : "s"(b) : "memory");
     __syncthreads();
+    if (prof) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_bar) : "s"(b) : "memory");
     const uint32_t *wcode = code + (size_t)b * (size_t)tape_stride * 2;
     const int n_instr_w = tape_stride ? (int)reinterpret_cast<const unsigned long long *>(wcode)[tape_stride - 1] : n_instr;
     long long tstart1 = 0;   // (profiling: the clock once the work item, its axes and the length of its tape have arrived)
@@ -297,6 +308,11 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
         const unsigned *pacc = reinterpret_cast<const unsigned *>(scratch + CULL_PACC);
         atomicAdd(&prof[32 + (ntl < 0 ? 9 : min(ntl >> 6, 8))], 1ull);   // histogram of the listed tasks per work item, bins of 64
         atomicAdd(&prof[16], (unsigned long long)(tstart1 - tstart));
+        atomicAdd(&prof[26], (unsigned long long)(t_ctr - tstart));      // ... of which: until the shard's range is known
+        atomicAdd(&prof[27], (unsigned long long)(t_b - t_ctr));         // ... until the batch index is
+        atomicAdd(&prof[28], (unsigned long long)(t_ax - t_org));        // ... until this wave's axis values are in LDS
+        atomicAdd(&prof[30], (unsigned long long)(t_org - t_b));         // ... (before that: the batch's origin from its index)
+        atomicAdd(&prof[29], (unsigned long long)(t_bar - t_ax));        // ... its wait at the barrier (the workgroup's other waves)
         atomicAdd(&prof[21], (unsigned long long)(clock64() - tw));
         for (int k = 1; k < 10; k++) if (k != 5) atomicAdd(&prof[16 + k], (unsigned long long)pacc[k]);
     }
@@ -1451,7 +1467,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                     pc[32], pc[33], pc[34], pc[35], pc[36], pc[37], pc[38], pc[39], pc[40], pc[41]);
             fprintf(stderr, "[k_cull prof] cycles of thread 0, summed over the workgroups: start %llu boxes %llu list %llu groups %llu (%llu passes, %llu groups) tasks %llu record %llu\n",
                     pc[16], pc[17], pc[18], pc[19], pc[23], pc[22], pc[20], pc[21]);
-            fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu\n", pc[24], pc[25]);
+            fprintf(stderr, "[k_cull prof] task listing: which tasks %llu, scans %llu; start: range %llu batch %llu origin %llu axes %llu barrier %llu (rest: tape length)\n", pc[24], pc[25], pc[26], pc[27], pc[30], pc[28], pc[29]);
             fprintf(stderr, "[k_mesh prof] sampling: intervals %llu task list %llu interpreter %llu sign bits %llu\n", pc[8], pc[9], pc[10], pc[11]);
             fprintf(stderr, "[k_mesh prof] fine: atomic %llu barrier+rank %llu header %llu | rows %llu cells %llu | placing %llu look-back %llu | round end %llu\n",
                     pc[42], pc[43], pc[44], pc[45], pc[46], pc[47], pc[48], pc[49]);
