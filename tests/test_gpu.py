@@ -1402,6 +1402,42 @@ def test_tail_of_the_work_list_by_cost_or_in_order_same_soup(name, samples, ns, 
     assert res[(samples, 0, 0)][3]['triangles'] > 1000
 
 
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 24), ('ex_example', 1500000), ('ex_blobby', 2 ** 23), ('ex_gearlike', 2 ** 22),
+                                          ('ex_weave', 2 ** 22), ('ex_knurling', 2 ** 21), ('ex_pawn', 2 ** 22)])
+def test_sparse_tiles_deferred_emission_and_interval_levels_same_soup(name, samples, ns, eng):
+    """the one-kernel scheme's choices -- sparse tiles + deferred emission or dense tiles + parking (sdf_ctx_set_defer), two or
+    three interval levels in k_cull (sdf_ctx_set_cull_levels; by default the tape decides) -- give the same soup, the same
+    per-batch offsets and verdicts bit for bit, on regular and ragged grids, one call at a time and with the tail of the work
+    list in order; fewer samples go through the interpreter with three levels than with two"""
+    f = fixtures.build(name, ns)
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, BOUNDS[name])), samples=samples)
+    res = {}
+    try:
+        eng.set_twopass(0)
+        for defer in (1, 0):
+            for levels in (0, 2, 3):
+                eng.set_defer(defer); eng.set_cull_levels(levels)
+                m = eng.generate(f, X, Y, Z, 32, True)
+                res[(defer, levels)] = (m.points(), m.kinds(), m.batch_offsets(), m.stats())
+                m.close()
+        eng.set_defer(1); eng.set_cull_levels(0); eng.set_tail_order(0)
+        m = eng.generate(f, X, Y, Z, 32, True)
+        res[(1, -1)] = (m.points(), m.kinds(), m.batch_offsets(), m.stats())
+        m.close()
+    finally:
+        eng.set_twopass(-1); eng.set_defer(1); eng.set_cull_levels(0); eng.set_tail_order(1)
+    ref = res[(0, 2)]
+    assert ref[3]['triangles'] > 1000
+    for key, r in res.items():
+        assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2]), key
+        for k in ('triangles', 'skipped', 'empty', 'nonempty', 'n_eval_voxels', 'n_ambiguous_cells', 'n_pruned_instrs'):
+            assert r[3][k] == ref[3][k], (key, k)
+    for defer in (1, 0):
+        assert res[(defer, 3)][3]['n_sampled_voxels'] < res[(defer, 2)][3]['n_sampled_voxels']
+        assert res[(defer, 0)][3]['n_sampled_voxels'] in (res[(defer, 2)][3]['n_sampled_voxels'], res[(defer, 3)][3]['n_sampled_voxels'])
+    assert res[(1, 3)][3]['n_sampled_voxels'] == res[(0, 3)][3]['n_sampled_voxels']
+
+
 def test_no_parking_and_tail_by_cost_do_not_wait_for_each_other():
     """With parking off (SDF_PARK=0) EVERY batch waits for its predecessors' counts before it emits -- the case the
     bound `tail <= workgroups - 1` on the reordered tail of the work list is there for ("The end of the
