@@ -271,7 +271,7 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE configs 3 - 5 section')
     ap.add_argument('--no-f32-envelope', action='store_true', help='skip the secondary float32 section')
     ap.add_argument('--sync', action='store_true', help='one step in flight: every call synchronises before the next is submitted')
-    ap.add_argument('--inflight', type=int, default=4, help='steps in flight on a single GPU (each on a lane of its own; at most 4)')
+    ap.add_argument('--inflight', type=int, default=6, help='steps in flight on a single GPU (each on a lane of its own; at most 8)')
     ap.add_argument('--chunks', type=int, default=None, help='N > 1: shards per rank and step (default 1: one all-gather per step)')
     args = ap.parse_args()
 
@@ -387,11 +387,11 @@ def main():
                 td.barrier()
                 torch.cuda.synchronize()
 
-        # set-up, not a step (every rank alike): each of the context's four call slots allocates its k_mesh park slots on
-        # first use (1.2 GB, ~35 - 50 ms each; the slots rotate, so the FOURTH step of a process would still pay that inside
+        # set-up, not a step (every rank alike): each of the context's eight call slots allocates its k_mesh park slots on
+        # first use (1.2 GB, ~35 - 50 ms each; the slots rotate, so the EIGHTH step of a process would still pay that inside
         # a timed region that starts after three warm-up steps), output buffers that are too small are replaced (N = 1),
         # the lanes' slabs and soup shrink from the first step's upper bounds to what the job needs (N > 1)
-        for _ in range(max(depth + 1, 5)):
+        for _ in range(max(depth + 1, 9)):      # (eight call slots rotate: every one of them has been used once before anything is timed)
             one_step()
         sync()
         # (like timeit: no cyclic garbage collection inside the timed region.  With torch imported a full collection takes
@@ -420,7 +420,7 @@ def main():
         return {'f': f, 'tape': tape, 'X': X, 'Y': Y, 'Z': Z, 'dt': dt, 'mesh_ms': list(mesh_ms), 'exch_ms': list(exch_ms),
                 'dev_ms': list(dev_ms), 'sclk': list(sclk), 'spans': list(spans), 'state': state, 'grid_voxels': len(X) * len(Y) * len(Z)}
 
-    DEPTH = 1 if args.sync else (max(1, min(args.inflight, 4)) if world == 1 else 2)
+    DEPTH = 1 if args.sync else (max(1, min(args.inflight, 8)) if world == 1 else 2)
     # N > 1: a rank that dies or stalls leaves the others inside a collective for ever.  The headline measurement of a healthy
     # job takes seconds; if it has not come back after SDF_BENCH_HEADLINE_TIMEOUT_S (default 900) every rank says so and
     # exits instead of holding its GPU until somebody kills the job.

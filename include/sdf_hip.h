@@ -181,8 +181,8 @@ int sdf_generate_to_device(sdf_tape *tape, const double *X, int nx, const double
                            int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,
                            void *d_out, int64_t cap_tris, int *emitted, sdf_mesh **out);
 /* The same without the host synchronisation: the call is enqueued on the context's stream and the mesh
- * is returned "in flight"; sdf_mesh_wait (or any function that reads the mesh) collects it.  Up to 4
- * calls of one context may be in flight (a fifth waits for the oldest); give each its own d_out.  This
+ * is returned "in flight"; sdf_mesh_wait (or any function that reads the mesh) collects it.  Up to 8
+ * calls of one context may be in flight (a ninth waits for the oldest); give each its own d_out.  This
  * is how a caller that meshes many jobs back to back (bench.py) keeps the device busy while the host
  * prepares the next submission; the reference has no counterpart (its generate() is synchronous).
  * sdf_mesh_wait: *emitted as for sdf_generate_to_device (0: the soup did not fit d_out, the call was

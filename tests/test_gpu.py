@@ -798,10 +798,10 @@ def test_async_generate_matches_sync(ns, eng):
     for model, ax in ((f, A), (g, B)):
         m = eng.generate(model, ax, ax, ax, 32, True)
         want.append((m.points(), m.kinds(), m.stats())); m.close()
-    bufs = [torch.empty(9 * (1 << 20), dtype=torch.float64, device='cuda:0') for _ in range(6)]
-    # six calls in flight on one context (more than it has slots), two models alternating
+    bufs = [torch.empty(9 * (1 << 20), dtype=torch.float64, device='cuda:0') for _ in range(10)]
+    # ten calls in flight on one context (more than its eight slots), two models alternating
     meshes = [eng.generate((f, g)[i % 2], (A, B)[i % 2], (A, B)[i % 2], (A, B)[i % 2], 32, True,
-                           out_ptr=bufs[i].data_ptr(), out_cap=bufs[i].numel() // 9, wait=False) for i in range(6)]
+                           out_ptr=bufs[i].data_ptr(), out_cap=bufs[i].numel() // 9, wait=False) for i in range(10)]
     for i, m in reversed(list(enumerate(meshes))):          # collected out of order
         assert m.wait() is True
         p0, k0, s0 = want[i % 2]
@@ -829,30 +829,30 @@ def test_async_generate_matches_sync(ns, eng):
 
 
 def test_async_calls_beyond_the_slot_count_keep_their_own_results(ns, eng):
-    """seven calls in flight on the context's four call slots, every one a DIFFERENT job (three models on
-    seven grids), collected out of order, with synchronous calls in between: a call that needs the slot of
+    """eleven calls in flight on the context's eight call slots, every one a DIFFERENT job (three models on
+    eleven grids), collected out of order, with synchronous calls in between: a call that needs the slot of
     an uncollected one collects that mesh first, so every mesh reports its own counters"""
     import torch
     models = [fixtures.build(n, ns) for n in ('ex_example', 'ex_blobby', 'torus')]
     jobs = []
-    for i in range(7):
+    for i in range(11):
         model = models[i % 3]
         half = (1.2, 4.4, 1.4)[i % 3]
-        ax = np.arange(-half, half, 2 * half / (96 + 16 * i))
+        ax = np.arange(-half, half, 2 * half / (96 + 12 * i))
         jobs.append((model, ax))
     want = []
     for model, ax in jobs:
         m = eng.generate(model, ax, ax, ax, 32, True)
         want.append((m.points(), m.kinds(), m.stats())); m.close()
-    assert len({w[2]['triangles'] for w in want}) == 7          # pairwise different results
-    bufs = [torch.empty(9 * (1 << 20), dtype=torch.float64, device='cuda:0') for _ in range(7)]
+    assert len({w[2]['triangles'] for w in want}) == 11         # pairwise different results
+    bufs = [torch.empty(9 * (1 << 20), dtype=torch.float64, device='cuda:0') for _ in range(11)]
     meshes = []
     for i, (model, ax) in enumerate(jobs):
         meshes.append(eng.generate(model, ax, ax, ax, 32, True, out_ptr=bufs[i].data_ptr(), out_cap=bufs[i].numel() // 9, wait=False))
-        if i == 4:      # a synchronous call while five are in flight: it must not take a held slot's staging
+        if i == 8:      # a synchronous call while nine are in flight: it must not take a held slot's staging
             m = eng.generate(jobs[0][0], jobs[0][1], jobs[0][1], jobs[0][1], 32, True)
             assert m.n_triangles == want[0][2]['triangles']; m.close()
-    for i in (3, 0, 6, 1, 5, 2, 4):
+    for i in (3, 0, 6, 10, 1, 8, 5, 2, 9, 4, 7):
         m = meshes[i]
         assert m.wait() is True
         p0, k0, s0 = want[i]
