@@ -1,24 +1,25 @@
 // sdf_device.h -- device-side structures and the fused sample+march kernel template (gfx950).
 //
-//   k_mesh   THE hot kernel: persistent workgroups (one per CU: the tile owns most of the CU's
-//            160 KiB LDS) pull surviving batches from the ordered work list.  Per batch:
-//              1. sample   the (<=33)^3 tile through the tape interpreter (NS samples per lane,
-//                          float64 or float32), cast to float32 like skimage's volume cast, and
-//                          store it in LDS -- the field never touches HBM
-//                          (reference `_worker`, sdf/core.py:50-52)
-//              2. count    one thread per (i0, i1) row of cells walks i2, builds the 8-bit sign
-//                          configuration from LDS and sums triangles per row; a block-wide
-//                          wave-shuffle prefix scan turns the row counts into offsets
-//              3. compact  surface cells expand into a per-triangle work list in LDS
-//                          (cell, configuration, triangle-in-cell), in skimage's emission order
-//              4. emit     one lane per TRIANGLE: three edge interpolations from the LDS tile, the
-//                          float64 world transform `points * scale + offset` (core.py:58-60) and
-//                          72 contiguous bytes per lane straight into the ORDERED output soup.
-//                          The batch's place in the soup is the exclusive prefix of the triangle
-//                          counts of all earlier work items, obtained without a second pass by a
-//                          decoupled look-back over per-item status words (work items are handed
-//                          out in order, so every predecessor is already being worked on)
-//            (reference `_marching_cubes`, sdf/core.py:16-18, 54)
+//   k_mesh   THE hot kernel: persistent workgroups (one per CU) pull surviving batches from the ordered work list.
+//            Per round, for batch k:
+//              1. sample   the units of 2^3 samples k_cull listed (cull_tasks) through the tape interpreter (two tasks of
+//                          64 samples per wave and pass, float64 or float32), cast to float32 like skimage's volume cast,
+//                          into a SPARSE tile in LDS (TileView: only the listed units; a tile that is not culled stays
+//                          dense) -- the field never touches HBM (reference `_worker`, sdf/core.py:50-52); the sign bits
+//                          of everything else come from the interval pass's sub-group states
+//              2. count    one thread per (i0, i1) row of cells builds the row's surface-cell mask from the sign-bit
+//                          volume; one thread per surface cell its triangles (Lewiner's tests where the configuration is
+//                          ambiguous); two block scans number cells and triangles in skimage's emission order; the count
+//                          is published (status[w])
+//              3. wait     the batch stays in one of two LDS slots while the workgroup samples batch k + 1
+//              4. emit     batch k - 1, one round later: a decoupled look-back over the status words gives its place in the
+//                          soup (work items are handed out in order, so every predecessor is held by a running workgroup);
+//                          one lane per TRIANGLE: three edge interpolations, the float64 world transform
+//                          `points * scale + offset` (core.py:58-60), transposed through LDS so that consecutive lanes
+//                          store consecutive coordinates -- meanwhile the last wave draws the next work item and brings
+//                          its record and axes in
+//            (reference `_marching_cubes`, sdf/core.py:16-18, 54).  What cannot wait -- dense tiles, lists that do not fit,
+//            a waiting batch whose predecessors are still not done -- is written at once or parked (r03's scheme).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -139,15 +139,25 @@ ABI_VERSION = 6
 
 
 def source_id():
-    """sha256 (16 hex digits) over the kernels' sources, sdf_amd/csrc/*.{h,hip,inc,sh}: what a committed rocprofv3 summary
-    was taken on (tools/summarize_prof.py writes it, bench.py only quotes a summary whose id is this build's)"""
+    """sha256 (16 hex digits) over the kernels' sources, sdf_amd/csrc/*.{h,hip,inc,sh}, WITHOUT their comments and blank
+    lines: what a committed rocprofv3 summary was taken on (tools/summarize_prof.py writes it, bench.py only quotes a
+    summary whose id is this build's).  Editing a comment does not make a profile stale; editing code does."""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
     for f in sorted(glob.glob(os.path.join(d, '*'))):
-        if os.path.isfile(f) and f.rsplit('.', 1)[-1] in ('h', 'hip', 'inc', 'sh'):
-            h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+        ext = f.rsplit('.', 1)[-1]
+        if os.path.isfile(f) and ext in ('h', 'hip', 'inc', 'sh'):
+            text = open(f, encoding='utf-8', errors='replace').read()
+            if ext == 'sh':
+                text = re.sub(r'(?m)^\s*#(?!!).*$', '', text)
+            else:
+                text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+                text = re.sub(r'//[^\n]*', '', text)
+            text = '\n'.join(ln.rstrip() for ln in text.split('\n') if ln.strip())
+            h.update(os.path.basename(f).encode()); h.update(text.encode())
     return h.hexdigest()[:16]
 
 _lib = None
