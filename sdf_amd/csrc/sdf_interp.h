@@ -58,6 +58,14 @@ SDF_OUTLINE float o_pow2(float x) { return powf(2.0f, x); }
 SDF_OUTLINE void o_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
 struct SinCos64 { double s, c; };    // (returned in registers: out-parameters of an outlined function live in scratch memory)
 SDF_OUTLINE SinCos64 o_sincos64(double x) { SinCos64 r; sincos(x, &r.s, &r.c); return r; }
+// circular_array's polar form for one float64 point (reference sdf/d3.py:381-383): .s = hypot(x, y), .c = atan2(y, x) mod da (NumPy's floored modulo)
+SDF_OUTLINE SinCos64 o_circ_polar64(double x, double y, double da) {
+    SinCos64 r; r.s = hypot(x, y);
+    const double a = atan2(y, x);
+    double m = fmod(a, da);
+    if (da != 0.0) { if (m != 0.0) { if ((da < 0.0) != (m < 0.0)) m += da; } else m = copysign(0.0, da); }   // (s_mod)
+    r.c = m; return r;
+}
 
 // sin and cos of a float64 angle, INLINE and branch-free: what `circular_array` runs twice per child evaluation
 // (reference sdf/d3.py:379-392 -- weave at 2^33: 36 of them per sample before pruning), and twist / bend.  The ocml
@@ -807,34 +815,55 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
             x = nx; y = ny; } goto next;
         // circular_array (d3.py:379-392): d = hypot(x, y), a = arctan2(y, x) % da, then the child at
         // (cos(a - delta) * d, sin(a - delta) * d, z) for delta = da and delta = 0.  In float64 the same two points are
-        // reached by ROTATING (x, y): with k = floor(arctan2(y, x) / da) -- the exact floor, i.e. the sector NumPy's floored
-        // modulo puts the point in -- (cos(a - delta) d, sin(a - delta) d) is (x, y) turned by -(k da + delta).  CIRC_PREP
-        // needs the angle only for k (one inline atan2, an exact remainder test, sin / cos of k * da carried with its
-        // rounding error) and no hypot / fmod; CIRC_SET is four products with the host's cos / sin of delta (c[1], c[2];
-        // delta = 0: the saved point itself).  Against the reference's own expression order (glibc) the coordinates differ
-        // by <= 4 ulp of d (3e7 random and near-boundary points; the ocml / glibc form differed by as much), the
-        // sector agrees except within ~1e-16 rad of a boundary, where any two libm's disagree.  c[1] (PREP) / c[3] (SET)
-        // say whether the lowering found 0 < da < 7 (else, and in float32, the polar form below).
+        // reached by ROTATING (x, y): with k = floor(arctan2(y, x) / da) -- the sector NumPy's floored modulo puts the point
+        // in -- (cos(a - delta) d, sin(a - delta) d) is (x, y) turned by -(k da + delta).  CIRC_PREP leaves the point turned by
+        // -k da in the saved-point slot (found by a binary search of rotations, below: no atan2, no hypot, no fmod, no sin /
+        // cos); CIRC_SET is four products with the host's cos / sin of delta (c[1], c[2]; delta = 0: the saved point
+        // itself).  c[1] == 2 (PREP) / c[3] != 0 (SET) say that the lowering found pi / 4096 <= da <= pi (else, and in
+        // float32, the polar form).  (r03 found k with an inline atan2 and the rotation with an inline sincos of k da:
+        // ~200 vector instructions per sample, a quarter of weave's interpreter time.)
         L_CIRC_PREP: if constexpr (FULL) {
             bool polar = true;
             if constexpr (sizeof(T) == 8) {
-                if (c[1] != T(0)) {   // (uniform)
+                if (c[1] == T(2)) {   // (uniform) the sector by a binary search of rotations: no atan2, no sin / cos
+                    // With phi = the point's angle mirrored into [0, pi] (y -> |y|), turn the point back by 2^m da for
+                    // m = M .. 0 whenever it stays on the counter-clockwise side (ry >= 0): afterwards it has been turned
+                    // by -floor(phi / da) da and its angle r lies in [0, da).  For y >= 0 that is the wanted point; for
+                    // y < 0 the angle is -phi = -(k' + 1) da + (da - r): mirror back and turn forward by da (r = 0: mirror
+                    // only).  Against the reference's own expression order: <= 7e-16 of the radius over 4e6 random and
+                    // near-boundary points for 2 .. 100 sectors (tools/circ_sector_check.py), the sector equal except within
+                    // ~1e-16 rad of a boundary, like the atan2 form before it; ~60 vector instructions per sample instead
+                    // of ~200 (r04: weave 2^33, gearlike 2^30).
                     polar = false;
-                    const double da = c[0];
+                    const int nst = (int)c[2];
                     V xr, yr;
                     SDF_UNROLL
                     for (int i = 0; i < NS; i++) {
-                        const double a = atan2_64(y.v[i], x.v[i]);
-                        double k = floor(a / da);
-                        const double rem = fma(-k, da, a);                 // (its sign is exact: the fma rounds once)
-                        k = rem < 0.0 ? k - 1.0 : (rem >= da ? k + 1.0 : k);
-                        const double th = k * da;
-                        double sn, cs;
-                        sincos64_dd(th, fma(k, da, -th), sn, cs);
-                        xr.v[i] = x.v[i] * cs + y.v[i] * sn;
-                        yr.v[i] = y.v[i] * cs - x.v[i] * sn;
+                        const bool neg = __builtin_signbit(y.v[i]);
+                        double qx = x.v[i], qy = neg ? -y.v[i] : y.v[i];
+                        for (int m = nst - 1; m >= 0; m--) {     // (uniform trip count; the constants are scalar loads)
+                            const double cm = c[3 + 2 * m], sm = c[4 + 2 * m];
+                            const double rx = qx * cm + qy * sm, ry = qy * cm - qx * sm;
+                            const bool acc = ry >= 0.0;
+                            qx = acc ? rx : qx; qy = acc ? ry : qy;
+                        }
+                        const double ux = qx, uy = -qy, c0 = c[3], s0 = c[4];
+                        const bool fwd = qy != 0.0;
+                        const double nx = fwd ? ux * c0 - uy * s0 : ux, ny = fwd ? ux * s0 + uy * c0 : uy;
+                        xr.v[i] = neg ? nx : qx;
+                        yr.v[i] = neg ? ny : qy;
                     }
                     PSET(sa, xr, yr, z);
+                }
+            }
+            if constexpr (sizeof(T) == 8) {
+                // (any other da -- one sector, or thousands -- takes the reference's polar form, out of line: ONE call site, so
+                // that the search above keeps the machine state in registers)
+                if (__builtin_expect(polar, 0)) {
+                    V d, a;
+                    SDF_UNROLL for (int i = 0; i < NS; i++) { const SinCos64 r = o_circ_polar64((double)x.v[i], (double)y.v[i], (double)c[0]); d.v[i] = (T)r.s; a.v[i] = (T)r.c; }
+                    PSET(sa, d, a, z);
+                    polar = false;
                 }
             }
             if (polar) PSET(sa, m_hypot(x, y), np_mod(m_atan2(y, x), c[0]), z); } goto next;

@@ -26,6 +26,8 @@ The constant at ``const_off`` is K (always reserved); leaf parameters follow it.
 """
 from array import array
 
+import math
+
 import numpy as np
 
 from . import dn
@@ -311,11 +313,27 @@ class _Lowering:
             return d
         if op == 'circular_array':
             s = self.palloc()
-            # (behind da / delta: what the float64 interpreter's rotation form needs -- cos / sin of delta and whether
-            # 0 < da < 7 holds, csrc/sdf_interp.h L_CIRC_PREP; the interval forms and the float32 path read c[0] only)
+            # (behind da / delta: what the float64 interpreter's rotation form needs -- the search's rotations, cos / sin of
+            # delta -- and whether it applies (pi / 4096 <= da <= pi: 2 .. 8192 sectors), csrc/sdf_interp.h L_CIRC_PREP; the
+            # interval forms and the float32 path read c[0] only)
             da = float(n.params[0])
-            rot = 1.0 if 0.0 < da < 7.0 else 0.0
-            self.emit('CIRC_PREP', a=s, consts=[da, rot])
+            rot = 1.0 if (0.0 < da <= math.pi and da >= math.pi / 4096.0) else 0.0     # (else: the reference's polar form, PREP and SET alike)
+            # Since r04 the float64 interpreter finds the sector WITHOUT atan2 / sincos: the point is turned back by 2^m da,
+            # m = M .. 0 (2^M da <= pi < 2^(M+1) da), whenever that leaves it on the counter-clockwise side -- a binary search
+            # of k = floor(angle / da) whose by-product is the point turned by -k da, which is all CIRC_SET needs.  The
+            # rotations' cos / sin are constants of the instruction: c[2] = M + 1, then (cos, sin)(2^m da) for m = 0 .. M.
+            prep = [da, 0.0]
+            if rot:
+                M = int(math.floor(math.log2(math.pi / da)))
+                while (2.0 ** (M + 1)) * da <= math.pi:
+                    M += 1
+                while (2.0 ** M) * da > math.pi:
+                    M -= 1
+                prep = [da, 2.0, float(M + 1)]
+                for m in range(M + 1):
+                    ang = (2.0 ** m) * da            # (exact: a power of two times da)
+                    prep += [math.cos(ang), math.sin(ang)]
+            self.emit('CIRC_PREP', a=s, consts=prep)
             self.chain.append(self.here())
             self.emit('CIRC_SET', a=s, consts=[da, float(np.cos(da)), float(np.sin(da)), rot])
             self.value(n.children[0], dim)
