@@ -58,7 +58,7 @@ EXPECTED_SCALING = {
     'example': 'C2 512^3: break-even by construction (~1.0 - 1.3 x at 8 GPUs): the work that divides is ~0.03 ms of a ~0.3 ms step; fixed: skip test, '
                'all-gather of 6 MB slabs (~0.08 ms on the wire), k_expand of the whole soup on every rank (~0.08 ms)',
     'gearlike': 'C3 2^30: ~2.5 x at 8 GPUs (1.6 ms -> ~0.6 ms: 21 MB slabs ~0.3 ms on the wire overlap the next step\'s meshing with two lanes)',
-    'weave': 'C4 2^33: ~4 x at 8 GPUs (27 ms -> ~6.5 ms: meshing / 8 ~3.5 ms, 115 MB slab ~1.5 ms on the wire, k_expand ~1.6 ms)',
+    'weave': 'C4 2^33: ~4 x at 8 GPUs (24 ms -> ~6 ms: meshing / 8 ~3 ms, 115 MB slab ~1.5 ms on the wire, k_expand ~1.6 ms)',
     'blobby': 'C5 2^30: ~2 x at 4 GPUs (1.2 ms -> ~0.6 ms)',
 }
 
