@@ -408,13 +408,13 @@ def collect_sharded(st):
         if st.attempt >= 5:
             raise RuntimeError('sdf_amd.dist: slab capacities did not converge')
         X, Y, Z, batch_size, sparse, chunks = st.args
-        caps = (max(cap_items, need_items + need_items // 8 + 16), max(cap_tris, need_tris + need_tris // 8 + 1024), total)
+        caps = (max(cap_items, need_items + need_items // 8 + 16), max(cap_tris, need_tris + need_tris // 64 + 1024), total)
         if on_gpu:
             st.outer.wait_stream(st.stream)
         return collect_sharded(submit_sharded(st.eng, st.tape, X, Y, Z, batch_size, sparse, st.device, st.group, chunks, st.lane,
                                               _caps=caps, _attempt=st.attempt + 1))
     # capacities for the next call of this job: what this one needed, with some slack
-    _hints_for(st.tape)[st.key] = (need_items + need_items // 8 + 16, need_tris + need_tris // 8 + 1024, total)
+    _hints_for(st.tape)[st.key] = (need_items + need_items // 8 + 16, need_tris + need_tris // 64 + 1024, total)
     soup = st.out[:total * 9]
     if on_gpu:
         st.outer.wait_stream(st.stream)           # whatever the caller enqueues next sees the soup
@@ -429,7 +429,7 @@ def collect_sharded(st):
         'n_sampled_voxels': int(heads[:, H_SAMPLED].sum()), 'n_pruned_instrs': int(heads[:, H_PRUNED].sum()),
         'triangles': total, 'n_triangles': total, 'per_rank_triangles': [int(c) for c in per_rank],
         'n_grid_voxels': len(st.args[0]) * len(st.args[1]) * len(st.args[2]), 'n_retries': st.attempt, 'chunks': C,
-        'slab_bytes': st.sb, 'payload': 'f32 local + per-batch transform' if isinstance(st.codec, DeviceCodec) else 'f64 soup',
+        'slab_bytes': st.sb, 'payload': '16-byte triangle records (local coordinates) + per-batch transform' if isinstance(st.codec, DeviceCodec) else 'f64 soup',
     }
     merged['n_empty'], merged['n_nonempty'] = merged['empty'], merged['nonempty']
     if st.events:      # (the headers' copy has synchronised the step's stream: the events are complete)

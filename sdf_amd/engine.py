@@ -139,7 +139,7 @@ ABI_VERSION = 6
 
 
 def source_id():
-    """sha256 (16 hex digits) over the kernels' sources, sdf_amd/csrc/*.{h,hip,inc,sh}, WITHOUT their comments and blank
+    """sha256 (16 hex digits) over the kernels' sources, sdf_amd/csrc/*.{h,hip,sh}, WITHOUT their comments and blank
     lines: what a committed rocprofv3 summary was taken on (tools/summarize_prof.py writes it, bench.py only quotes a
     summary whose id is this build's).  Editing a comment does not make a profile stale; editing code does."""
     import glob
@@ -149,7 +149,7 @@ def source_id():
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
     for f in sorted(glob.glob(os.path.join(d, '*'))):
         ext = f.rsplit('.', 1)[-1]
-        if os.path.isfile(f) and ext in ('h', 'hip', 'inc', 'sh'):
+        if os.path.isfile(f) and ext in ('h', 'hip', 'sh'):      # (not sdf_comm.inc: the host side of the exchange, no kernel)
             text = open(f, encoding='utf-8', errors='replace').read()
             if ext == 'sh':
                 text = re.sub(r'(?m)^\s*#(?!!).*$', '', text)
@@ -402,7 +402,7 @@ class Exchange:
         d = {k: getattr(st, k) for k, _ in SdfExchangeStats._fields_ if k != 'per_rank_triangles'}
         d['per_rank_triangles'] = [int(v) for v in st.per_rank_triangles[:st.world]]
         d.update(batches=st.n_batches, skipped=st.n_skipped, empty=st.n_empty, nonempty=st.n_nonempty, triangles=st.n_triangles,
-                 payload='f32 local + per-batch transform', exchange='rccl (native)')
+                 payload='16-byte triangle records (local coordinates) + per-batch transform', exchange='rccl (native)')
         return DeviceSoup(self.comm.engine, p.value, n.value, keep=self), d
 
     def close(self):
