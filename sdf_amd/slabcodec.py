@@ -7,7 +7,7 @@ is RAW: its nine floats go to the slab's raw area and the record holds their ind
 import numpy as np
 
 RAW = np.uint32(1 << 31)
-RAW_DIV, RAW_MIN = 32, 256
+RAW_DIV, RAW_MIN = 128, 256
 
 
 def layout(cap_items, cap_tris):

@@ -1175,7 +1175,7 @@ def test_slab_exchange_emulated_ranks(name, samples, ns, eng):
 def _synthetic_slabs(eng, rng, n, cap_items, cap_tris, sizes_of):
     """n slabs in the layout of csrc/sdf_slab.h (header | prefix words | transforms | 16-byte triangle records | raw area)
     written by NumPy (sdf_amd/slabcodec.py), and the float64 soup `points * scale + offset` (reference sdf/core.py:58-60)
-    they expand to.  The triangles have marching cubes' shape (vertices on the edges of one cell); ~ 1 % do not (a vertex
+    they expand to.  The triangles have marching cubes' shape (vertices on the edges of one cell); ~ 0.4 % do not (a vertex
     inside a cell) and travel raw"""
     from sdf_amd import slabcodec as sc
     sb = eng.slab_bytes(cap_items, cap_tris)
@@ -1200,7 +1200,9 @@ def _synthetic_slabs(eng, rng, n, cap_items, cap_tris, sizes_of):
             v[rows, frac] = (c[rows, frac] + rng.random(nt)).astype(np.float32)
             tri[:, k, :] = v
         tri = tri.reshape(nt, 9)
-        inside = rng.random(nt) < 0.01
+        inside = rng.random(nt) < 0.004
+        if nt:
+            inside[int(rng.integers(0, nt))] = True         # (at least one raw triangle per non-empty slab)
         tri[inside] = rng.uniform(0, 32, (int(inside.sum()), 9)).astype(np.float32)
         n_raw = sc.write_triangles(host[s], cap_items, cap_tris, tri)
         head = np.zeros(16, np.int64)
