@@ -391,7 +391,7 @@ def test_sharded_generate_over_rccl_single_rank(driver, ns, eng, monkeypatch):
             soup, st = dist.generate_sharded_device(eng, tape, X, Y, Z, 32, True, device=torch.device('cuda', 0), chunks=chunks)
             torch.cuda.synchronize()
             got = soup.cpu().numpy().reshape(-1, 3)
-            assert st['triangles'] == len(want) // 3 and st['chunks'] == chunks and st['payload'].startswith('f32')
+            assert st['triangles'] == len(want) // 3 and st['chunks'] == chunks and st['payload'].startswith('16-byte')
             assert ('native' in st.get('exchange', '')) == (driver != 'torch')
             assert np.array_equal(got, want)
             assert st['ms_mesh'] > 0 and st['ms_exchange'] >= 0 and st['ms_expand'] > 0
