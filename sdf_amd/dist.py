@@ -19,11 +19,13 @@ call of the same job (first call: an upper bound), and a slab that turns out too
 flagged in its header: every rank sees the same gathered headers, takes the same decision and
 repeats the step with larger slabs.  The host synchronises ONCE per step, to read the headers.
 
-On GPUs the payload is marching cubes' own output, 9 float32 per triangle in the batch's local
-voxel coordinates (36 bytes instead of the 72 of the float64 soup), plus a 56-byte record per
-batch (triangle prefix + `points * scale + offset` transform, reference sdf/core.py:58-60);
-`k_mesh` writes that form directly into the slab and `k_expand` produces the ordered float64
-soup from the gathered slabs on every rank (csrc/sdf_hip.hip).  Engines that return host soups
+On GPUs the payload is marching cubes' own output in the batch's local voxel coordinates as
+16-byte records (the three along-edge float32 bit for bit + one word for the cell and the edges;
+a triangle with a vertex inside a cell travels raw: csrc/sdf_slab.h, restated in slabcodec.py)
+instead of the 72 bytes of the float64 soup, plus a 56-byte record per batch (triangle prefix +
+`points * scale + offset` transform, reference sdf/core.py:58-60); `k_mesh` writes that form
+directly into the slab and `k_expand` produces the ordered float64 soup from the gathered slabs
+on every rank (csrc/sdf_plain.hip).  Engines that return host soups
 (models with user closures, the CPU stand-in of tests/test_dist.py) ship the float64 soup itself
 through the same protocol.
 
@@ -126,7 +128,7 @@ class HostCodec:
 
 
 class DeviceCodec:
-    """slabs written and expanded by the HIP library (compact float32 payload, see the module docstring)"""
+    """slabs written and expanded by the HIP library (16-byte triangle records, see the module docstring)"""
 
     def __init__(self, eng):
         self.eng = eng

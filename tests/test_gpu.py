@@ -476,7 +476,7 @@ def test_bench_two_ranks_on_one_device_exchange_slabs_between_processes(driver, 
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['parity_check'] is True
-    assert rec['config']['triangles'] == 2945152 and rec['exchange']['payload'].startswith('f32')
+    assert rec['config']['triangles'] == 2945152 and rec['exchange']['payload'].startswith('16-byte')
     assert ('native' in rec['exchange']['driver']) == (driver == 'native-mock-rccl')
     assert len(rec['device_ms']['per_rank_mesh']) == 2 and rec['value'] > 0
 
