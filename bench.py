@@ -611,6 +611,7 @@ def main():
     # --pmc runs of this same command; FETCH_SIZE/WRITE_SIZE corrected as MI355X_MICROARCH.md says,
     # see tools/summarize_prof.py); the newest committed summary is used
     traffic = traffic_src = stale_src = None
+    pmc_kernel = {}
     if args.model == 'example' and args.samples_log2 == 27 and world == 1 and args.precision == 'f64':
         import glob
         for prof in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')), reverse=True):
@@ -621,6 +622,7 @@ def main():
                     if rec.get('source_id') == engine.source_id():
                         traffic = rec.get('hbm_bytes_per_launch')
                         traffic_src = os.path.basename(prof)
+                        pmc_kernel = (rec.get('kernels') or {}).get(rec.get('dominant_kernel') or '', {})
                     elif stale_src is None:
                         stale_src = '%s (source_id %s, this build %s)' % (os.path.basename(prof), rec.get('source_id'), engine.source_id())
             except Exception:
@@ -651,7 +653,13 @@ def main():
                  'pruned_instr_fraction': round(st.get('n_pruned_instrs', 0) / st['n_batch_instrs'], 4) if st.get('n_batch_instrs') else None,
                  'flops_per_voxel_est': plain + special,
                  'achieved_tflops_est': round((plain + special) * sampled_vox / (k_ms * 1e-3) / 1e12, 3) if k_ms > 0 else 0,
-                 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS if args.precision == 'f64' else 157.3},
+                 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS if args.precision == 'f64' else 157.3,
+                 # from the committed counters of this source (same summary as `traffic`): vector-ALU wave-instructions per
+                 # launch, and the share of the kernel's SIMD cycles they occupy at 4 cycles each (1024 SIMDs, the shader
+                 # clock the kernel measured itself): how much of k_mesh is instruction issue
+                 'valu_wave_instructions_per_launch': (pmc_kernel.get('SQ_INSTS_VALU') or {}).get('mean'),
+                 'valu_issue_fraction': (round(4.0 * pmc_kernel['SQ_INSTS_VALU']['mean'] / (1024.0 * k_ms * 1e-3 * float(iso['sclk_mhz_in_kernel']['median']) * 1e6), 3)
+                                         if pmc_kernel.get('SQ_INSTS_VALU') and world == 1 and iso and k_ms > 0 and iso['sclk_mhz_in_kernel']['median'] else None)},
     }
 
     # ---- CPU baseline 1: the reference's own path (reference sdf/core.py:84-150, NumPy thread pool + skimage) ----
