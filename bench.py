@@ -554,13 +554,18 @@ def main():
                 gold = os.path.join(ROOT, 'tests', 'golden', 'full_c5_blobby_s30.npz')
                 if model == 'blobby' and rank == 0 and os.path.exists(gold) and not args.no_check:
                     o['soup_sha256_equals_reference'] = bool(soup_sha(r['state']['soup'], t2) == bytes(np.load(gold)['sha256']).hex())
-                # every 997th triangle of the REFERENCE's soup at this size (tests/golden/full_*.npz, tools/make_golden_full.py)
+                # every 997th triangle of the REFERENCE's soup at this size (tests/golden/full_*.npz, tools/make_golden_full.py; weave at
+                # 2**33: every 9973rd, by the reference's per-batch function over all 266,256 batches, tools/make_golden_c4.py)
                 # against the same triangles of the soup this run left on the device: positions, not only the count
-                gold = {'gearlike': 'full_c3_gearlike_s30.npz', 'blobby': 'full_c5_blobby_s30.npz'}.get(model)
+                gold = {'gearlike': 'full_c3_gearlike_s30.npz', 'blobby': 'full_c5_blobby_s30.npz', 'weave': 'full_c4_weave_s33.npz'}.get(model)
                 gold = os.path.join(ROOT, 'tests', 'golden', gold) if gold else None
                 if gold and rank == 0 and os.path.exists(gold) and not args.no_check and r['state'].get('soup') is not None:
                     gd = np.load(gold)
                     stride, ref_tris = int(gd['sample_stride']), gd['sample_tris']
+                    if 'seconds' in gd.files:   # the reference's own time for this configuration, as recorded when the fixture was made (build container, 8 vCPU)
+                        o['reference_cpu'] = {'seconds': round(float(gd['seconds']), 1), 'workers': int(gd['processes']) if 'processes' in gd.files else 1,
+                                              'what': ('sdf.core._worker over generate\'s job list in processes (tools/make_golden_c4.py)' if 'processes' in gd.files
+                                                       else 'sdf.core.generate, workers=1 (tools/make_golden_full.py)')}
                     if int(gd['ntri']) == t2:
                         mine = r['state']['soup'][:9 * t2].view(t2, 3, 3)[::stride].cpu().numpy()
                         extent = float(np.ptp(np.asarray(gd['bounds']), axis=0).max())

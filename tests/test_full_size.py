@@ -10,9 +10,12 @@ the full soup the HIP path is compared with row by row.
 * GPU: HIP soup == oracle soup == reference hash; the same with the interval passes switched off;
   for the libm models (device ocml vs glibc) the north-star tolerance 1e-5 x extent with > 99.9 % of
   the coordinates bit-equal, also against the reference's own sampled triangles.
-* C4 (weave at 2**33, 266 256 batches, ~10 h for the reference): a deterministic sample of >= 500
-  surviving batches is meshed by the oracle one by one and compared with the slices of the HIP soup
-  that `sdf_mesh_batch_offsets` attributes to those batches.
+* C4 (weave at 2**33, 266 256 batches; `generate` itself would take ~10 h and > 20 GB for its list of points): the
+  reference's own per-batch function `_worker` was run over all of `generate`'s jobs in processes (tools/make_golden_c4.py ->
+  full_c4_weave_s33.npz: classification and triangle count of EVERY batch, sha256, every 9973rd triangle) -- the HIP path
+  must reproduce all of it; in addition >= 5 % of the surviving batches (seeded shuffle) are meshed by the oracle one by
+  one and compared with the slices of the HIP soup that `sdf_mesh_batch_offsets` attributes to them.  On the CPU the
+  oracle is held to the same file on the batches that own every 5th of the reference's sampled triangles.
 * The multi-GPU shape of C2 / C3 / C4 / C5 on one device: emulated ranks mesh their shards into exchange slabs and
   `sdf_expand_slabs` must reproduce the reference's (resp. the single-GPU) soup hash.
 """
@@ -50,6 +53,44 @@ def test_oracle_reproduces_reference_soup_at_full_size(tag, ns, oracle_lib):
     assert np.array_equal(o.kinds, d['kinds'])
     assert len(o.points) == 3 * int(d['ntri'])
     assert hashlib.sha256(o.points.tobytes()).digest() == d['sha256'].tobytes()
+
+
+def test_oracle_reproduces_reference_batches_of_c4_weave_at_2_33(ns, oracle_lib):
+    """CPU: the oracle against the reference's full-size run of BASELINE config 4 (full_c4_weave_s33.npz): the skip test on
+    a strided sample of ALL batches; classification, triangle count and the reference's sampled triangle for the batches
+    that own every 5th of its 5 409 sampled triangles"""
+    ref = np.load(os.path.join(GOLDEN, 'full_c4_weave_s33.npz'))
+    f = fixtures.build('ex_weave', ns)
+    bounds = tuple(map(tuple, ref['bounds']))
+    X, Y, Z, _ = core.grid_axes(bounds, ref['step'].tolist())
+    assert (len(X), len(Y), len(Z)) == tuple(ref['shape']) == (4097, 4097, 512)
+    assert np.array_equal(ref['bounds'], np.load(os.path.join(GOLDEN, 'bounds.npz'))['ex_weave'])
+    kinds, tris = ref['kinds'], ref['tris'].astype(np.int64)
+    assert len(kinds) == 266256 and int(ref['ntri']) == int(tris.sum()) == 53943912
+    assert ((kinds == 2) == (tris > 0)).all() and (kinds != 0).sum() == 37872
+    extent = np.ptp(np.array(bounds), axis=0).max()
+    offs = np.concatenate([[0], np.cumsum(tris)])
+    stride = int(ref['sample_stride'])
+    which = np.arange(0, len(ref['sample_tris']), 5)
+    owners = np.searchsorted(offs, which * stride, side='right') - 1
+    from concurrent.futures import ThreadPoolExecutor
+
+    def oracle_batch(bi):
+        return oracle_lib.generate(f, X, Y, Z, 32, True, batch_range=(int(bi), int(bi) + 1))
+    n_equal = n_coord = 0
+    with ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 2)))) as pool:
+        for k, bi, o in zip(which, owners, pool.map(oracle_batch, owners)):
+            assert o.kinds[bi] == kinds[bi] == 2, bi
+            mine = o.points.reshape(-1, 3, 3)
+            assert len(mine) == tris[bi], bi
+            t = mine[k * stride - offs[bi]]
+            assert np.abs(t - ref['sample_tris'][k]).max() <= 1e-5 * extent, bi
+            n_equal += int((t == ref['sample_tris'][k]).sum()); n_coord += 9
+        some = np.arange(0, 266256, 733)
+        for bi, o in zip(some, pool.map(oracle_batch, some)):
+            assert o.kinds[bi] == kinds[bi], bi
+            assert len(o.points) == 3 * tris[bi], bi
+    assert n_equal > 0.999 * n_coord
 
 
 def _close(a, b, extent):
@@ -191,6 +232,18 @@ def test_c4_weave_at_2_33_sampled_batches_match_oracle(ns, oracle_lib, eng):
         assert offs[-1] == st['triangles']
         surv = np.flatnonzero(kinds != 0)
         assert len(surv) == 37872
+        # the REFERENCE at this size: its own per-batch function (`sdf.core._worker`, imported) over all 266,256 batches of
+        # `generate`'s job list, reduced in `generate`'s order (tools/make_golden_c4.py): the classification and the triangle
+        # count of EVERY batch, and every 9973rd triangle of its soup
+        ref = np.load(os.path.join(GOLDEN, 'full_c4_weave_s33.npz'))
+        assert np.array_equal(kinds, ref['kinds'])
+        assert np.array_equal(np.diff(offs).astype(np.int64), ref['tris'].astype(np.int64))
+        assert st['triangles'] == int(ref['ntri'])
+        ref_tris = ref['sample_tris']
+        at = np.arange(0, st['triangles'], int(ref['sample_stride']))
+        assert len(at) == len(ref_tris) > 5000
+        mine = np.stack([m.points_range(int(t), 1).reshape(3, 3) for t in at])
+        _close(mine, ref_tris, extent)
         # >= 5 % of the surviving batches, drawn by a SEEDED SHUFFLE (a stride can alias the weave's period), + the ends
         # of the list; the oracle meshes them one by one on the host's cores (ctypes releases the GIL)
         rng = np.random.default_rng(20260922)
