@@ -32,7 +32,7 @@ from sdf_amd import core
 # models whose tape goes through libm (see tests/test_gpu.py TRIG)
 TRIG = {'ex_gearlike', 'ex_weave', 'ex_knurling'}
 
-FULL = ['c2_example_s27', 'c5_blobby_s30', 'c3_gearlike_s30', 'weave_s24', 'knurling_s27']
+FULL = ['c2_example_s27', 'c5_blobby_s30', 'c3_gearlike_s30', 'weave_s24', 'knurling_s27', 'pawn_s27']
 
 
 def _load(tag):
@@ -45,7 +45,7 @@ def _load(tag):
     return d, str(d['fixture']), bounds, X, Y, Z
 
 
-@pytest.mark.parametrize('tag', ['c2_example_s27', 'c5_blobby_s30'])
+@pytest.mark.parametrize('tag', ['c2_example_s27', 'c5_blobby_s30', 'pawn_s27'])
 def test_oracle_reproduces_reference_soup_at_full_size(tag, ns, oracle_lib):
     d, name, bounds, X, Y, Z = _load(tag)
     f = fixtures.build(name, ns)

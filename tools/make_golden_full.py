@@ -20,12 +20,13 @@ sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402  (imports the reference)
 
 JOBS = [
-    # tag, fixture, samples (BASELINE.json configs; C4 = weave 2**33 is ~10 h on the CPU: 2**24 instead)
+    # tag, fixture, samples (BASELINE.json configs; C4 = weave 2**33 at full size: tools/make_golden_c4.py)
     ('c2_example_s27', 'ex_example', 2 ** 27),
     ('c5_blobby_s30', 'ex_blobby', 2 ** 30),
     ('c3_gearlike_s30', 'ex_gearlike', 2 ** 30),
     ('weave_s24', 'ex_weave', 2 ** 24),
     ('knurling_s27', 'ex_knurling', 2 ** 27),
+    ('pawn_s27', 'ex_pawn', 2 ** 27),
 ]
 STRIDE = 997       # triangles kept: every STRIDE-th (a prime, so the sample walks through all batches)
 
