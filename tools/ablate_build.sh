@@ -3,7 +3,7 @@
 # thread; waves overlap): a scratch copy of sdf_amd/csrc gets tools/ablation_knockouts.patch (emission pieces removed behind
 # -DSDF_ABL_*: results are WRONG on purpose, triangle counts and control flow unchanged), one library per variant lands in
 # ablibs/lib_<name>.so for tools/gpu_abn.sh.  Nothing of this touches the product source.
-#   tools/ablate_build.sh            # base edge at atedge store tritab tritabatedge emitnone
+#   tools/ablate_build.sh            # base edge at atedge store tritab tritabatedge emitnone (run in r04ai / r04aj) + noxf nolist staticchunk (prepared, not run)
 set -eu
 cd "$(dirname "$0")/.."
 S=/tmp/abl
@@ -20,3 +20,7 @@ build store -DSDF_ABL_STORE               # everything computed and staged, no s
 build tritab -DSDF_ABL_TRITAB             # the triangle's three edges by arithmetic instead of three byte loads from the table in device memory
 build tritabatedge -DSDF_ABL_TRITAB -DSDF_ABL_AT -DSDF_ABL_EDGE
 build emitnone -DSDF_ABL_EMITNONE         # the emission loop's body removed (chunk hand-out and barriers stay)
+# prepared for the next round (not yet run on a GPU): what is left of the emission's other half
+build noxf -DSDF_ABL_NOXF                 # soup stores without the float64 scale + offset
+build nolist -DSDF_ABL_NOLIST             # the triangle's list entry by arithmetic instead of the LDS read
+build staticchunk -DSDF_ABL_STATICCHUNK   # a waiting batch's triangles by fixed assignment instead of the atomic hand-out of chunks (a real alternative, results stay right)
