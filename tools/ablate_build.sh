@@ -3,7 +3,7 @@
 # thread; waves overlap): a scratch copy of sdf_amd/csrc gets tools/ablation_knockouts.patch (emission pieces removed behind
 # -DSDF_ABL_*: results are WRONG on purpose, triangle counts and control flow unchanged), one library per variant lands in
 # ablibs/lib_<name>.so for tools/gpu_abn.sh.  Nothing of this touches the product source.
-#   tools/ablate_build.sh            # base edge at atedge store tritab tritabatedge emitnone (run in r04ai / r04aj) + noxf nolist staticchunk (prepared, not run)
+#   tools/ablate_build.sh            # base edge at atedge store tritab tritabatedge emitnone (run in r04ai / r04aj) + noxf nolist staticchunk x2tape x2rows (prepared, not run)
 set -eu
 cd "$(dirname "$0")/.."
 S=/tmp/abl
@@ -24,3 +24,6 @@ build emitnone -DSDF_ABL_EMITNONE         # the emission loop's body removed (ch
 build noxf -DSDF_ABL_NOXF                 # soup stores without the float64 scale + offset
 build nolist -DSDF_ABL_NOLIST             # the triangle's list entry by arithmetic instead of the LDS read
 build staticchunk -DSDF_ABL_STATICCHUNK   # a waiting batch's triangles by fixed assignment instead of the atomic hand-out of chunks (a real alternative, results stay right)
+# doubling instead of removing (results stay RIGHT; the extra time is the piece's cost under real overlap):
+build x2tape -DSDF_ABL_X2_TAPE            # every interpreter pass runs twice
+build x2rows -DSDF_ABL_X2_ROWS            # the per-row surface masks + their block scans (count phase, 2a) run twice

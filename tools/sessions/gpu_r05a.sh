@@ -12,5 +12,5 @@ export TMPDIR=/tmp
 echo "identity (ldstri) rc=$?"; tail -3 $O/t_identity_ldstri.txt | head -1
 ( SDF_HIP_LIB=$PWD/ablibs/lib_ldstri.so timeout 300 python -m pytest tests/test_full_size.py -m gpu -x -q -k "matches_oracle_and_reference and (c2 or c5 or pawn)" ) > $O/t_full_ldstri.txt 2>&1
 echo "full size (ldstri) rc=$?"; tail -1 $O/t_full_ldstri.txt
-timeout 400 bash tools/gpu_abn.sh r05a_ab main ldstri noxf nolist staticchunk emitnone
+timeout 400 bash tools/gpu_abn.sh r05a_ab main ldstri noxf nolist staticchunk emitnone x2tape x2rows
 timeout 300 bash tools/pmc_icache.sh r05a_icache > $O/icache.txt 2>&1; grep -a "k_cull" $O/icache.txt | head -20
