@@ -777,11 +777,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     // belong.  What cannot be deferred -- a tile that is not culled or lists too many units (it takes the whole region:
     // a waiting batch is written first), a batch whose triangle list does not fit -- goes the old way, and so does a
     // deferred batch whose predecessors are STILL not done one batch later (it is parked then; nothing ever waits).
-    // (Taking the NEXT work item early -- thread 0 issuing the atomic and the work-list load behind the sampling phase, so
-    // that their two dependent round trips hide behind counting and emit -- was built and measured in r02: the time
-    // at the top of the loop did not move (it is the barrier and the record / axis loads, not the atomic), and the two
-    // values carried across the phases cost the 2- and 4-slot variants 6 - 9 more spilled registers: k_mesh
-    // 0.288 -> 0.300 ms.  Rejected.)
+    // (Taking the next work item's INDEX early -- thread 0 issuing the atomic and the work-list load behind the sampling
+    // phase -- was built and measured in r02: the time at the top of the loop did not move (it is the record / axis loads,
+    // not the atomic), and the two values carried across the phases cost 6 - 9 more spilled registers: 0.288 -> 0.300 ms.
+    // What does pay is below: a whole WAVE brings the item, its record and its axes into LDS during the emission.)
     const int slot_bytes = TWOPASS ? 0 : a.slot_bytes;
     auto slot_base = [&](int s_) { return smem + MESH_LDS_VOL + (size_t)s_ * (size_t)slot_bytes; };
     int dq_slot = -1;          // the slot of the counted batch whose triangles are still to be written (-1: none)
