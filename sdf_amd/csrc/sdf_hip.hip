@@ -431,7 +431,7 @@ struct DevPool {
     }
     void give(void *p, size_t bytes, int device) {
         std::lock_guard<std::mutex> g(mu);
-        // (four calls in flight x up to twelve buffers each come back at once: a list shorter than that evicts -- hipFree, a
+        // (up to eight calls in flight x up to twelve buffers each come back at once: a list shorter than that evicts -- hipFree, a
         // device synchronisation -- blocks the very next call allocates again)
         if (free_list.size() >= 160) {   // evict the oldest block
             if (g_pool_trace) fprintf(stderr, "[sdf pool] evict %zu bytes (hipFree)\n", free_list.front().bytes);

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_scan_items(const ItemDesc *__restrict_
 // mc33_triangle -- the very functions the one-pass kernel runs on its LDS tile, with the strides of a 2 x 2 x 2 volume),
 // pass the 9 local coordinates through LDS so that consecutive lanes store consecutive coordinates, and write
 // `points * scale + offset` (reference sdf/core.py:58-60) of the triangle's own work item -- or, for the multi-GPU
-// exchange, the local float32 form -- straight to the final place.  The grid covers the soup's CAPACITY (the host does
+// exchange, the 16-byte record of its local float32 form (store_tri16) -- straight to the final place.  The grid covers the soup's CAPACITY (the host does
 // not know the count); workgroups beyond the total leave at once.
 __global__ __launch_bounds__(256) void k_emit2(MeshArgs a) {
     __shared__ float tri[256 * 9];

@@ -321,8 +321,8 @@ def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=No
     else:                       # first call: a shard is a contiguous piece of the work list, at most 1/(world*C) of ALL batches
         cap_items = -(-nb // (world * C)) + 1
         # (triangles: a guess, 4096 per batch of the shard -- 2.4 x what the surviving batches of the BASELINE models
-        # produce, and most batches do not survive -- within 8 GB for gathered slabs (36 B) plus the expanded soup (72 B)
-        # together; a slab that is too small is flagged in its header, the headers carry the exact need, and the step is
+        # produce, and most batches do not survive -- within 8 GB for gathered slabs plus the expanded soup (72 B)
+        # together (budgeted at the 36 B a record took until r04n; it takes 16); a slab that is too small is flagged in its header, the headers carry the exact need, and the step is
         # repeated once with that.  The capacities size the collective: nothing rank-local -- free memory, say -- may
         # enter the formula, every rank must arrive at the same numbers)
         budget = 8 << 30
