@@ -852,6 +852,33 @@ __device__ __forceinline__ Vec<T, NS> run_tape(const uint32_t *__restrict__ code
                         const double nx = fwd ? ux * c0 - uy * s0 : ux, ny = fwd ? ux * s0 + uy * c0 : uy;
                         xr.v[i] = neg ? nx : qx;
                         yr.v[i] = neg ? ny : qy;
+                        // A point ON a coordinate axis (x == 0 or y == 0: whole planes of a grid like np.arange(-1, 1, 0.01))
+                        // has an angle that arctan2 returns EXACTLY (0, +-pi/2, +-pi), and the reference's floored modulo of
+                        // it is exact too -- 0.0 wherever da divides the angle in floating point (4 | count: the quarter
+                        // turns), else a remainder of a few 1e-16 on ONE side of the boundary.  The search above lands within
+                        // 1e-16 rad of that boundary on a side of its own (the accepted quarter turn leaves qy ~ 6e-17, not 0),
+                        // which an asymmetric child turns into a different sector's value (r04 advisor finding).  Such lanes
+                        // take the reference's own expression: A = the exact angle, m = A mod da by an exact remainder
+                        // (fma(-k, da, A) with k corrected to the floor: the remainder of two doubles is a double), the point
+                        // (cos(m) d, sin(m) d) with d = |x| + |y| = hypot exactly.  (wave-uniform branch; no call)
+                        const bool axis = x.v[i] == 0.0 || y.v[i] == 0.0;
+                        if (__builtin_expect(__ballot(axis) != 0ull, 0)) {
+                            const double xa = x.v[i], ya = y.v[i], dda = c[0];
+                            const double A = xa == 0.0 ? (ya == 0.0 ? (__builtin_signbit(xa) ? 3.141592653589793 : 0.0) : 1.5707963267948966)
+                                                       : (__builtin_signbit(xa) ? 3.141592653589793 : 0.0);   // |arctan2(y, x)| on an axis
+                            double k = floor(A / dda);
+                            double rm = fma(-k, dda, A);                       // (the quotient may be one off: the sign tells)
+                            k = rm < 0.0 ? k - 1.0 : (rm >= dda ? k + 1.0 : k);
+                            rm = fma(-k, dda, A);                              // exact: 0 <= A - k da < da is a double
+                            // arctan2 carries y's sign: fmod(-A, da) = -rm, and NumPy's floored modulo adds da to a negative
+                            // remainder (npy_divmod); a zero remainder is +0.0
+                            const double mm = (neg && rm != 0.0) ? dda - rm : rm;
+                            double sn, cs;
+                            sincos64(mm, sn, cs);
+                            const double dd = fabs(xa) + fabs(ya);
+                            xr.v[i] = axis ? cs * dd : xr.v[i];
+                            yr.v[i] = axis ? sn * dd : yr.v[i];
+                        }
                     }
                     PSET(sa, xr, yr, z);
                 }

@@ -1568,8 +1568,8 @@ print('ok', first, f1, f2)
 
 @pytest.mark.parametrize('count', [3, 7, 16, 24, 360])
 def test_circular_array_at_and_around_sector_boundaries(count, ns, oracle_lib, eng):
-    """circular_array in float64 is evaluated in rotation form (csrc/sdf_interp.h L_CIRC_PREP: inline atan2, exact sector
-    index, sin / cos of k * da; CIRC_SET: four products) instead of the reference's hypot / arctan2 %% da / cos, sin
+    """circular_array in float64 is evaluated in rotation form (csrc/sdf_interp.h L_CIRC_PREP: the sector by a binary search
+    of rotations, no atan2 / sin / cos; CIRC_SET: four products) instead of the reference's hypot / arctan2 %% da / cos, sin
     (reference sdf/d3.py:379-392).  The points where the two could part: ON the sector boundaries (angles k * da as exactly
     as float64 has them), one ulp to 1e-9 rad either side, the negative x axis with y = +0 / -0 (arctan2 = +pi / -pi), the
     axis x = y = 0, tiny and huge radii -- tests/golden/circ_boundaries.npz, produced by RUNNING the reference on them
@@ -1590,6 +1590,29 @@ def test_circular_array_at_and_around_sector_boundaries(count, ns, oracle_lib, e
         assert np.array_equal(np.isfinite(v), ok)
         for want in (ref, o):
             assert np.all(np.abs(v[ok] - want[ok]) <= value_tolerance(want[ok], P[ok])), (i, float(np.max(np.abs(v[ok] - want[ok]) / value_tolerance(want[ok], P[ok]))))
+
+
+@pytest.mark.parametrize('count', [2, 3, 4, 7, 8, 12, 16, 24, 100, 360])
+def test_circular_array_on_the_axes_under_asymmetric_children(count, ns, oracle_lib, eng):
+    """Points ON the coordinate axes (x == 0.0 or y == +-0.0 exactly: whole planes of a grid like np.arange(-1, 1, 0.01)):
+    arctan2 is exact there and so is the reference's floored modulo (sdf/d3.py:381-383), i.e. the reference puts such a point
+    into ONE definite sector -- angle 0.0 exactly where da divides the angle in floating point (4 | count) -- and a child that
+    is not symmetric about the x axis tells the sectors apart.  The rotation search alone landed ~6e-17 rad on the other side
+    for y < 0 (round-4 advisor finding; symmetric children hid it); axis lanes now take the reference's expression
+    (csrc/sdf_interp.h L_CIRC_PREP).  Goldens: the unmodified reference on these points, tests/golden/circ_axes.npz
+    (tools/make_golden_circ.py); generic points ride along; the whole model also goes through the meshing kernel's
+    interpreter variants via eval_points' register files."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import make_golden_circ as mgc
+    g = np.load(os.path.join(GOLDEN, 'circ_axes.npz'))
+    P = g['P_%d' % count]
+    for i, f in enumerate(mgc.asym_models(ns, count)):
+        v = eng.eval_points(f, P)
+        ref = g['v_%d_%d' % (count, i)]
+        o = oracle_lib.evaluate(f, P)
+        for want in (ref, o):
+            assert np.all(np.abs(v - want) <= value_tolerance(want, P)), (i, int(np.argmax(np.abs(v - want) / value_tolerance(want, P))), float(np.max(np.abs(v - want) / value_tolerance(want, P))))
 
 
 def _native_exchange_worker(rank, world, port, q, mock, skip_shard, first_cap):

@@ -145,3 +145,22 @@ def test_oracle_matches_reference_on_circular_array_boundaries(ns, oracle_lib):
             ok = np.isfinite(ref)
             assert np.array_equal(np.isfinite(o), ok)
             assert np.all(np.abs(o[ok] - ref[ok]) <= value_tolerance(ref[ok], P[ok])), (count, i)
+
+
+def test_oracle_matches_reference_on_axis_points_under_asymmetric_children(ns, oracle_lib):
+    """tests/golden/circ_axes.npz (tools/make_golden_circ.py, round 5): points ON the coordinate axes -- where arctan2 and
+    the floored modulo are exact, so the reference (sdf/d3.py:379-392) puts each into one definite sector -- and generic
+    points, under children that are NOT symmetric about the x axis, which tell neighbouring sectors apart"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import make_golden_circ as mgc
+    from conftest import value_tolerance
+    g = np.load(os.path.join(GOLDEN, 'circ_axes.npz'))
+    for count in mgc.AXIS_COUNTS:
+        P = g['P_%d' % count]
+        assert np.array_equal(P, mgc.axis_points(count))
+        for i, f in enumerate(mgc.asym_models(ns, count)):
+            ref = g['v_%d_%d' % (count, i)]
+            o = oracle_lib.evaluate(f, P)
+            assert np.all(np.abs(o - ref) <= value_tolerance(ref, P)), (count, i, float(np.max(np.abs(o - ref))))
+

@@ -26,7 +26,17 @@ def search(x, y, da):
     nz = qy != 0.0
     rx = np.where(nz, ux * c0 - uy * s0, ux)
     ry = np.where(nz, ux * s0 + uy * c0, uy)
-    return np.where(neg, rx, qx), np.where(neg, ry, qy)
+    gx, gy = np.where(neg, rx, qx), np.where(neg, ry, qy)
+    # points ON a coordinate axis: the exact angle, its exact floored remainder, the reference's own expression (round 5;
+    # fma(-k, da, A) of the device code is exact, np.fmod is the same number)
+    axis = (x == 0.0) | (y == 0.0)
+    A = np.where(x == 0.0, np.where(y == 0.0, np.where(np.signbit(x), np.pi, 0.0), np.pi / 2), np.where(np.signbit(x), np.pi, 0.0))
+    k = np.floor(A / da)
+    rm = np.fmod(A, da)                       # == A - k da exactly once k is the floor
+    mm = np.where(neg & (rm != 0.0), da - rm, rm)
+    dd = np.abs(x) + np.abs(y)
+    gx = np.where(axis, np.cos(mm) * dd, gx); gy = np.where(axis, np.sin(mm) * dd, gy)
+    return gx, gy
 def reference(x, y, da):      # the reference's polar form (d3.py:379-392), delta = 0 evaluation point
     d = np.hypot(x, y); a = np.arctan2(y, x) % da
     return np.cos(a) * d, np.sin(a) * d
@@ -48,3 +58,16 @@ for count in (2, 3, 5, 7, 12, 16, 18, 24, 100):
     bad = err > 1e-13
     ang_g = np.arctan2(gy, gx)
     print(count, 'max rel err (same sector)', err[~bad].max(), 'sector mismatches', int(bad.sum()), 'residual angle range', ang_g.min(), ang_g.max(), 'da', da)
+
+# points ON the axes: the sector must be the reference's, whatever the count (an asymmetric child tells them apart)
+worst = 0.0
+for count in range(2, 400):
+    da = 2 * np.pi / count
+    r = np.array([1e-9, 0.3, 1.0, 2.0, 1e6])
+    x = np.concatenate([0 * r, 0 * r, -0.0 * r, -0.0 * r, r, r, -r, -r]); y = np.concatenate([r, -r, r, -r, 0 * r, -0.0 * r, 0 * r, -0.0 * r])
+    gx, gy = search(x, y, da)
+    wx, wy = reference(x, y, da)
+    err = np.maximum(np.abs(gx - wx), np.abs(gy - wy)) / np.hypot(x, y)
+    worst = max(worst, err.max())
+    assert err.max() < 1e-15, (count, err.max())
+print('axis points, 2 .. 399 sectors: max rel err', worst)
