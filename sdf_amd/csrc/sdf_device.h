@@ -134,7 +134,8 @@ struct ItemDesc {
 // kernel waiting for a slow predecessor of its oldest parked batch (SDF_MESH_PROF: placing 14.4 of 29.6 G cycles):
 // depth 4: 48.3 ms, 8: 33.6, 16: 27.7, 32: 27.1 ms; the example, gearlike, blobby, pawn do not care, knurling gains 4 %.
 enum { MESH_PARK_DEPTH = 16 };
-enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_PEND = 1184, MESH_LDS_VOL = 1184 + 64 * MESH_PARK_DEPTH };   // PEND: per parked batch 6 doubles + 2 ints
+enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_PEND = 1184, MESH_LDS_TRI = 1184 + 64 * MESH_PARK_DEPTH,
+       MESH_LDS_VOL = MESH_LDS_TRI + 256 * 5 * 2 };   // PEND: per parked batch 6 doubles + 2 ints; TRI: the triangle table, one 16-bit word per (configuration, triangle)
 
 __device__ __forceinline__ void batch_origin(const GridDesc &g, int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {
     // itertools.product(Xs, Ys, Zs): Z fastest (reference sdf/core.py:119)
@@ -681,9 +682,18 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     int tid = threadIdx.x;
 #define SDF_FRESH() asm volatile("" : "+v"(tid))
     const GridDesc g = a.g;
-    const signed char *tri_tab = &a.mc->tri[0][0];
+    // the triangle table in LDS: edge ids e0 | e1 << 4 | e2 << 8 of triangle j of configuration cfg at [5 cfg + j] (a
+    // non-ambiguous configuration has at most 5).  The emission used to fetch them as three byte loads from the 4 KB table in
+    // device memory per triangle: 4.6 % of the kernel by knock-out (r04aj)
+    unsigned short *tri_lds = reinterpret_cast<unsigned short *>(smem + MESH_LDS_TRI);
 
     if (tid < 256) ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
+    if (!TWOPASS)
+        for (int i = tid; i < 256 * 5; i += BLOCK) {
+            const int cfg = i / 5, j = i - 5 * cfg;
+            const signed char *t3 = &a.mc->tri[cfg][3 * j];
+            tri_lds[i] = (unsigned short)(((unsigned)t3[0] & 15u) | (((unsigned)t3[1] & 15u) << 4) | (((unsigned)t3[2] & 15u) << 8));
+        }
 
     const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
     if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x] = wall_clock64();        // (timeline of the workgroup, 100 MHz)
@@ -1399,10 +1409,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         mc33_triangle(c8, 4, 2, i0, i1, i2, a.mc->mc33, j, oa);
                         SDF_UNROLL for (int q = 0; q < 9; q++) o[q] = oa[q];
                     } else {
-                        const signed char *tt3 = tri_tab + cfg * 16 + 3 * j;
-                        mc_vertex_view(vw, i0, i1, i2, tt3[0], o);
-                        mc_vertex_view(vw, i0, i1, i2, tt3[1], o + 3);
-                        mc_vertex_view(vw, i0, i1, i2, tt3[2], o + 6);
+                        const unsigned tt3 = tri_lds[5 * cfg + min(j, 4)];
+                        mc_vertex_view(vw, i0, i1, i2, (int)(tt3 & 15u), o);
+                        mc_vertex_view(vw, i0, i1, i2, (int)((tt3 >> 4) & 15u), o + 3);
+                        mc_vertex_view(vw, i0, i1, i2, (int)(tt3 >> 8), o + 6);
                     }
                     if (a.compact && !parking) {   // (uniform) the exchange's 16-byte record, straight from the registers
                         if (live) store_tri16(a, base + (unsigned long long)(lo + t), o);
