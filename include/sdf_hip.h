@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 6
+#define SDF_ABI_VERSION 7
 
 #define SDF_PRECISION_F64 0 /* parity mode: float64 sampling like the reference's NumPy path */
 #define SDF_PRECISION_F32 1 /* fast mode: float32 sampling */
@@ -88,6 +88,13 @@ int sdf_ctx_set_cull(sdf_ctx *ctx, int enabled);
  * (sample + classify / number the triangles / emit), -1 = the library's choice by the tape's length (default; the
  * environment variable SDF_MESH_TWOPASS sets the initial state).  Results are identical either way. */
 int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
+/* Split meshing (round 5): the meshing pass as TWO kernels of small workgroups, several per compute unit -- k_sample
+ * (`volume = sdf(P)`, reference sdf/core.py:50-52: the tape interpreter, the sampled tiles go to an arena in device memory)
+ * and k_march (`_marching_cubes` + `points * scale + offset`, core.py:54-60: ordered by the same look-back) -- instead of
+ * the one kernel that holds a compute unit with one workgroup and does a batch's phases in turn.  1 = wherever the
+ * interval pass k_cull ran (float64, monotone axes), 0 = never, -1 = the library's choice by the tape (default; the
+ * environment variable SDF_MESH_SPLIT sets the initial state).  Results are identical either way. */
+int sdf_ctx_set_split(sdf_ctx *ctx, int mode);
 /* Inside the one-kernel scheme: 1 (default; SDF_DEFER sets the initial state) = a culled batch keeps only the samples the
  * interval pass listed (a sparse tile) and STAYS in the CU's LDS while the workgroup samples its next batch, so that its
  * triangles are written once, in their final place, when the earlier batches' counts are known; 0 = dense tiles, a

@@ -56,11 +56,16 @@ struct MeshCounters {   // zeroed before every k_mesh run
     // the kernel actually ran at)
     unsigned long long t_first_inv, t_last, clk_cycles, clk_ticks;
     unsigned long long n_raw;         // compact output: triangles that went to the slab's raw area (sdf_slab.h)
+    unsigned int march_counter;       // split meshing (sdf_split.h): the work counter of k_march (work_counter is k_sample's)
+    unsigned int pad0_;
     // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
     // and this shard's slice of it, so k_mesh can start without a host round trip
     int nwork, work_begin, work_end, pad_;
+    // written by k_cull (NOT cleared between meshing retries): bytes / 256 of the tile arena handed out so far (split meshing,
+    // sdf_split.h: every work item's sampled tile gets a place there; the place is word 1 of the item's record)
+    unsigned long long tile_cursor;
 };
-enum { MESH_COUNTERS_RESET_BYTES = 112 };   // the part of MeshCounters cleared before every k_mesh run
+enum { MESH_COUNTERS_RESET_BYTES = 120 };   // the part of MeshCounters cleared before every k_mesh run
 
 struct GridDesc {
     const double *X, *Y, *Z;   // device copies of the np.arange axes
@@ -118,6 +123,10 @@ struct MeshArgs {
     // items do (see k_mesh).
     const int *order;
     int tail;
+    // split meshing (sdf_split.h: k_sample + k_march instead of k_mesh): the arena of sampled tiles, its size in units of
+    // 256 bytes; a work item's place is word 1 of its k_cull record
+    unsigned char *tiles;
+    unsigned long long tiles_cap256;
 };
 enum { MESH_TAIL_MAX = 255 };
 
@@ -290,10 +299,16 @@ __device__ __forceinline__ void mc_vertex_view(const TileView &vw, int i0, int i
 }
 
 // compact output: triangle number `pos` of the shard's slab from its nine local floats
-__device__ __forceinline__ void store_tri16(const MeshArgs &a, unsigned long long pos, const float *o) {
+struct Tri16Sink {                 // where the records go: the slab's record area, its raw area and the raw area's counter
+    double *out;
+    float *raw;
+    long long raw_cap;
+    unsigned long long *n_raw;
+};
+__device__ __forceinline__ void store_tri16(const Tri16Sink &a, unsigned long long pos, const float *o) {
     Tri16 r;
     if (__builtin_expect(!slab_encode16(o, r), 0)) {
-        const unsigned long long idx = atomicAdd(&a.ctr->n_raw, 1ull);
+        const unsigned long long idx = atomicAdd(a.n_raw, 1ull);
         if (idx < (unsigned long long)a.raw_cap) {
             float *dst = a.raw + idx * 9ull;
             for (int q = 0; q < 9; q++) dst[q] = o[q];
@@ -302,6 +317,9 @@ __device__ __forceinline__ void store_tri16(const MeshArgs &a, unsigned long lon
     }
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     reinterpret_cast<u4 *>(a.out)[pos] = u4{r.code, __float_as_uint(r.f[0]), __float_as_uint(r.f[1]), __float_as_uint(r.f[2])};
+}
+__device__ __forceinline__ void store_tri16(const MeshArgs &a, unsigned long long pos, const float *o) {
+    store_tri16(Tri16Sink{a.out, a.raw, a.raw_cap, &a.ctr->n_raw}, pos, o);
 }
 
 // ---- ordered allocation: exclusive prefix of the triangle counts over the work list -----------
