@@ -76,6 +76,22 @@ __global__ __launch_bounds__(256) void k_eval_grid(const uint32_t *__restrict__ 
     out[i] = (double)run_tape1<T, FULL>(code, consts, (T)X[ix], (T)Y[iy], (T)Z[iz]);
 }
 
+// `volume = sdf(P).reshape(...)`, cast to float32 as skimage does (reference sdf/core.py:50-54), for a chunk of whole tiles in
+// device memory: batch_size > 32, whose (batch_size + 1)^3 tile does not fit the LDS of a compute unit (generate_big).  One
+// lane per sample; blockIdx.y = the tile (FieldTile: its place in `vol`, its extents), `org` its first sample per axis.
+template <typename T, bool FULL>
+__global__ __launch_bounds__(256) void k_eval_tiles(const uint32_t *__restrict__ code, const T *__restrict__ consts,
+                                                    const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z,
+                                                    const FieldTile *__restrict__ tiles, const int *__restrict__ org, float *__restrict__ vol) {
+    const FieldTile tl = tiles[blockIdx.y];
+    const long long n = (long long)tl.n0 * tl.n1 * tl.n2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int iz = (int)(i % tl.n2), iy = (int)((i / tl.n2) % tl.n1), ix = (int)(i / ((long long)tl.n2 * tl.n1));
+    const int *o = org + 3 * blockIdx.y;
+    vol[tl.vol_off + i] = (float)run_tape1<T, FULL>(code, consts, (T)X[o[0] + ix], (T)Y[o[1] + iy], (T)Z[o[2] + iz]);
+}
+
 // f(P) for tapes with user closures (L_EXTERN leaves): `dump` writes every leaf's current point for the host
 // to call the closure on, the second pass reads the closures' values (sdf_interp.h ExtIO)
 template <typename T, bool FULL>
@@ -89,20 +105,19 @@ __global__ __launch_bounds__(256) void k_eval_points_ext(const uint32_t *__restr
     if (!dump) out[i] = (double)v;
 }
 
-// `_estimate_bounds` (reference sdf/core.py:62-82) as ONE launch (four workgroups): up to 32 rounds of a 16^3 probe grid
+// `_estimate_bounds` (reference sdf/core.py:62-82) as ONE launch of ONE workgroup: up to 32 rounds of a 16^3 probe grid
 // (np.linspace per axis: lo + i * step, the last sample forced to hi), threshold = |d| / 2, the box of the samples with
 // |f| <= threshold, grown by half a probe cell -- float64 throughout, operation by operation like the reference (and
 // the oracle's restatement).  The host loop it replaces paid a kernel launch, two copies and a synchronisation per
-// round: 3 ms per model, 40 % of a default-resolution `f.save`.  out[0..6) = lo, hi; out[6] = 1 when a round found no
-// sample within its threshold (the reference raises there: `where.max` of an empty array).
+// round: 3 ms per model.  out[0..6) = lo, hi; out[6] = 1 when a round found no sample within its threshold (the
+// reference raises there: `where.max` of an empty array).
+// The rounds are a dependent chain (a round's grid is the previous round's hit box), so what counts is the latency of ONE
+// round.  Until r04 four workgroups shared a round's 4096 probes and met at a barrier in device memory after each: 25 us per
+// round, nearly all of it the barrier (atomics at agent scope, a polling loop, two fences) -- 0.8 ms per model, three times
+// the meshing of 512^3.  One workgroup of 1024 threads takes FOUR probes per lane and needs `__syncthreads` only: ~ 7 us per
+// round (r05).
 template <typename T, bool FULL>
-__global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__restrict__ code, const T *__restrict__ consts, double *__restrict__ out,
-                                                          int *__restrict__ work) {
-    // FOUR workgroups share a round's 4096 probes (one per lane) and keep in lockstep through a counter in device
-    // memory (they are co-resident on any gfx950: four workgroups, 256 compute units); every workgroup carries the
-    // whole state -- the same arithmetic on the same reduced indices -- so nothing but the hit box is exchanged:
-    // work[0] = arrivals at the barrier, work[1 + 6 * round ..] = the round's hit box, as maxima of 16 - index
-    // (lower corner) and index + 1 (upper corner) so that a zeroed buffer is "no hit"
+__global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__restrict__ code, const T *__restrict__ consts, double *__restrict__ out) {
     __shared__ double ax[3][16];
     __shared__ double lo[3], hi[3], d[3], thr, prev;
     __shared__ int box[6], stop;
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__rest
             const double step = (hi[a] - lo[a]) / 15.0;
             ax[a][i] = i == 15 ? hi[a] : lo[a] + (double)i * step;
         }
-        if (tid < 6) box[tid] = 0;
+        if (tid < 6) box[tid] = 0;      // maxima of 16 - index (lower corner) and index + 1 (upper corner): 0 = no hit
         __syncthreads();
         if (tid == 0) {
             for (int a = 0; a < 3; a++) d[a] = ax[a][1] - ax[a][0];
@@ -125,35 +140,24 @@ __global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__rest
             prev = t; thr = t;
         }
         __syncthreads();
-        if (stop) break;                                       // (every workgroup takes the same decision)
-        {
-            const int q = (int)blockIdx.x * 1024 + tid;
+        if (stop) break;
+        int b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+#pragma unroll 1
+        for (int p = 0; p < 4; p++) {
+            const int q = p * 1024 + tid;
             const int i = q >> 8, j = (q >> 4) & 15, k = q & 15;
             const double v = (double)run_tape1<T, FULL>(code, consts, (T)ax[0][i], (T)ax[1][j], (T)ax[2][k]);
             if (fabs(v) <= thr) {
-                atomicMax(&box[0], 16 - i); atomicMax(&box[1], 16 - j); atomicMax(&box[2], 16 - k);
-                atomicMax(&box[3], i + 1); atomicMax(&box[4], j + 1); atomicMax(&box[5], k + 1);
+                b0 = max(b0, 16 - i); b1 = max(b1, 16 - j); b2 = max(b2, 16 - k);
+                b3 = max(b3, i + 1); b4 = max(b4, j + 1); b5 = max(b5, k + 1);
             }
         }
-        __syncthreads();
-        int *slot = work + 1 + 6 * it;
-        if (tid < 6 && box[tid]) atomicMax(&slot[tid], box[tid]);
-        __syncthreads();
-        if (tid == 0) {                                         // the round's barrier over the four workgroups
-            __threadfence();
-            atomicAdd(&work[0], 1);
-            unsigned spins = 0;
-            while (__hip_atomic_load(&work[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4 * (it + 1) && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
-            // (a workgroup that gives up -- the four were not co-resident for seconds: other kernels held the compute
-            // units -- must not go on with a partial hit box: workgroup 0 reports it, the host falls back to its loop)
-            if (spins >= (1u << 26)) stop = 2;
-            __threadfence();
+        if (b3) {
+            atomicMax(&box[0], b0); atomicMax(&box[1], b1); atomicMax(&box[2], b2);
+            atomicMax(&box[3], b3); atomicMax(&box[4], b4); atomicMax(&box[5], b5);
         }
         __syncthreads();
-        if (stop == 2) { if (blockIdx.x == 0 && tid == 0) out[6] = 2.0; return; }
-        if (tid < 6) box[tid] = __hip_atomic_load(&slot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (box[3] == 0) { if (blockIdx.x == 0 && tid == 0) out[6] = 1.0; return; }       // no probe within the threshold
+        if (box[3] == 0) { if (tid == 0) out[6] = 1.0; return; }       // no probe within the threshold
         if (tid < 3) {
             const double l0 = lo[tid];
             const int mn = 16 - box[tid], mx = box[3 + tid] - 1;
@@ -162,10 +166,8 @@ __global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__rest
         }
         __syncthreads();
     }
-    if (blockIdx.x == 0) {
-        if (tid < 3) { out[tid] = lo[tid]; out[3 + tid] = hi[tid]; }
-        if (tid == 0) out[6] = 0.0;
-    }
+    if (tid < 3) { out[tid] = lo[tid]; out[3 + tid] = hi[tid]; }
+    if (tid == 0) out[6] = 0.0;
 }
 
 // reference sdf/core.py:28-43.  9 lanes per batch, 7 batches per wave (lane 63 idles): lane 0 of a batch = centre,
@@ -501,6 +503,7 @@ struct CallSlot {
     hipStream_t stream = nullptr;                                         // the lane asynchronous calls of this slot run on
     DevBuf park;                                                          // ... and its k_mesh staging slots
 };
+#define SDF_BATCH_SIZE_MAX 512   // (513^3 float32 = 540 MB per tile: generate_big takes one tile per submission there)
 #define SDF_PARK_TRIS 8192   // triangles per workgroup staging slot of k_mesh (36 bytes each); larger batches wait instead
                              // (16 slots per workgroup: 1.2 GB per call lane, allocated on a lane's first use; with 4096
                              // per slot weave at 2^33 has batches that cannot park: 30.3 instead of 27.7 ms)
@@ -966,14 +969,11 @@ int sdf_estimate_bounds(sdf_tape *t, double *h_out6, int precision) {
     sdf_ctx *c = t->ctx;
     HIPCHK(set_device(c->device));
     if (c->scratch_out.ensure(2048)) return 1;
-    int *work = reinterpret_cast<int *>((char *)c->scratch_out.p + 64);
-    HIPCHK(hipMemsetAsync(work, 0, (1 + 6 * 32) * sizeof(int), c->stream));
-    LAUNCH_TAPE(k_estimate_bounds, dim3(4), dim3(1024), 0, t, precision, (double *)c->scratch_out.p, work);
+    LAUNCH_TAPE(k_estimate_bounds, dim3(1), dim3(1024), 0, t, precision, (double *)c->scratch_out.p);
     HIPCHK(hipGetLastError());
     double h[7];
     HIPCHK(hipMemcpyAsync(h, c->scratch_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(stream_wait(c->stream));
-    if (h[6] == 2.0) return fail("sdf_estimate_bounds: the probe workgroups did not meet at their barrier (device busy): use the host loop");
     if (h[6] != 0.0) return fail("zero-size array to reduction operation maximum which has no identity");   // (NumPy's words, reference sdf/core.py:80)
     memcpy(h_out6, h, 48);
     return 0;
@@ -1565,6 +1565,132 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     return 0;
 }
 
+// `generate` for batch_size > 32 (reference sdf/core.py:87, 114-119 takes any batch size): the (batch_size + 1)^3 float32 tile
+// of such a batch does not fit the LDS of a compute unit (33^3 = 144 KB of 160 KB does), so the fused kernels do not apply.  The
+// batches go through device memory instead, a chunk of them per submission: k_eval_tiles samples the chunk's tiles into float32
+// volumes (the interpreter, a lane per sample), k_field_rows / k_scan_rows / k_field_emit march them and write
+// `points * scale + offset` into the ordered float64 soup -- the kernels behind sdf_generate_field, with the tape instead of a
+// host callback.  The skip test is k_skip's, the work list k_compact's.  One host synchronisation per chunk: a chunk is
+// >= 2.7e5 samples per batch, the launches are long.  Synchronous; the soup lives in library memory.
+static int generate_big(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
+                        int bs, int sparse, int64_t shard_index, int64_t shard_count, int precision) {
+    sdf_ctx *c = t->ctx;
+    hipStream_t st = c->stream;
+    GridDesc &g = m->g;
+    g.nx = nx; g.ny = ny; g.nz = nz; g.bs = bs;
+    g.nbx = (nx + bs - 1) / bs; g.nby = (ny + bs - 1) / bs; g.nbz = (nz + bs - 1) / bs;
+    const long long nb64 = (long long)g.nbx * g.nby * g.nbz;
+    if (nb64 > 0x7fffffffLL) return fail("sdf_generate: too many batches");
+    const int nb = (int)nb64;
+    m->st.n_batches = nb;
+    m->st.n_grid_voxels = (int64_t)nx * ny * nz;
+    if (nb == 0) return 0;
+    if (m->axes.ensure((size_t)(nx + ny + nz) * 8) || m->kinds.ensure((size_t)nb) || m->worklist.ensure((size_t)nb * 4) ||
+        m->status.ensure((size_t)nb * 8) || m->counters.ensure(sizeof(MeshCounters)))
+        return 1;
+    double *dX = (double *)m->axes.p, *dY = dX + nx, *dZ = dY + ny;
+    g.X = dX; g.Y = dY; g.Z = dZ;
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    HIPCHK(hipMemcpyAsync(dX, X, (size_t)nx * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dY, Y, (size_t)ny * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dZ, Z, (size_t)nz * 8, hipMemcpyHostToDevice, st));
+    if (sparse) { if (enqueue_skip(t, dX, nx, ny, nz, bs, 0, nb, precision, (unsigned char *)m->kinds.p, st)) return 1; }
+    else HIPCHK(hipMemsetAsync(m->kinds.p, 255, (size_t)nb, st));
+    launch_k_compact(dim3(1), dim3(1024), st, (const unsigned char *)m->kinds.p, nb, (int *)m->worklist.p, (MeshCounters *)m->counters.p,
+                     (unsigned long long *)m->status.p, (long long)shard_index, (long long)shard_count);
+    HIPCHK(hipGetLastError());
+    MeshCounters h;
+    HIPCHK(hipMemcpyAsync(&h, m->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIPCHK(stream_wait(st));
+    std::vector<int> work((size_t)std::max(h.nwork, 1));
+    if (h.nwork) HIPCHK(hipMemcpy(work.data(), m->worklist.p, (size_t)h.nwork * 4, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> kinds((size_t)nb);
+    HIPCHK(hipMemcpy(kinds.data(), m->kinds.p, (size_t)nb, hipMemcpyDeviceToHost));
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    m->work_begin = h.work_begin; m->work_end = h.work_end;
+    m->st.n_skipped = nb - h.nwork;
+    m->st.n_work_begin = h.work_begin; m->st.n_work_end = h.work_end;
+
+    const size_t tile_max = (size_t)(bs + 1) * (bs + 1) * (bs + 1);
+    const int slots = (bs * bs + 255) & ~255;                                          // row slots per tile
+    const int CH = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)256 << 20) / (tile_max * 4)));   // batches per submission: <= 256 MB of volumes
+    std::vector<FieldTile> tiles((size_t)CH);
+    std::vector<int> org((size_t)CH * 3);
+    std::vector<unsigned long long> offs((size_t)CH * slots + 1);
+    if (c->field_vol.ensure((size_t)CH * tile_max * 4) || c->field_tiles.ensure(sizeof(FieldTile) * CH + (size_t)CH * 12) ||
+        c->rows.ensure((size_t)CH * slots * 4) || c->rows_off.ensure(((size_t)CH * slots + 1) * 8))
+        return 1;
+    int *d_org = reinterpret_cast<int *>((char *)c->field_tiles.p + sizeof(FieldTile) * CH);
+    unsigned long long total = 0;
+    for (int w0 = h.work_begin; w0 < h.work_end; w0 += CH) {
+        const int nt = std::min(CH, h.work_end - w0);
+        size_t npts = 0, big = 0;
+        for (int j = 0; j < nt; j++) {
+            const int b = work[(size_t)(w0 + j)];
+            const int ibz = b % g.nbz, iby = (b / g.nbz) % g.nby, ibx = b / (g.nbz * g.nby);       // (batch_origin, sdf_device.h)
+            const int ox = ibx * bs, oy = iby * bs, oz = ibz * bs;
+            const int lx = std::min(bs + 1, nx - ox), ly = std::min(bs + 1, ny - oy), lz = std::min(bs + 1, nz - oz);
+            FieldTile &tl = tiles[(size_t)j];
+            tl.vol_off = (long long)npts; tl.n0 = lx; tl.n1 = ly; tl.n2 = lz; tl.pad_ = 0;
+            tl.of[0] = X[ox]; tl.of[1] = Y[oy]; tl.of[2] = Z[oz];
+            tl.sc[0] = lx > 1 ? X[ox + 1] - X[ox] : 0.0; tl.sc[1] = ly > 1 ? Y[oy + 1] - Y[oy] : 0.0; tl.sc[2] = lz > 1 ? Z[oz + 1] - Z[oz] : 0.0;
+            org[(size_t)3 * j] = ox; org[(size_t)3 * j + 1] = oy; org[(size_t)3 * j + 2] = oz;
+            const size_t n = (size_t)lx * ly * lz;
+            npts += n; big = std::max(big, n);
+            m->st.n_eval_voxels += (int64_t)n;
+        }
+        const size_t nslots = (size_t)nt * slots;
+        HIPCHK(hipMemcpyAsync(c->field_tiles.p, tiles.data(), sizeof(FieldTile) * (size_t)nt, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_org, org.data(), (size_t)nt * 12, hipMemcpyHostToDevice, st));
+        LAUNCH_TAPE_ON(st, k_eval_tiles, dim3((unsigned)((big + 255) / 256), (unsigned)nt), dim3(256), 0, t, precision, (const double *)dX,
+                       (const double *)dY, (const double *)dZ, (const FieldTile *)c->field_tiles.p, (const int *)d_org, (float *)c->field_vol.p);
+        launch_k_field_rows(dim3((unsigned)(slots / 256), (unsigned)nt), dim3(256), st, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
+                            (const FieldTile *)c->field_tiles.p, (unsigned *)c->rows.p, slots);
+        unsigned long long *d_total = (unsigned long long *)c->rows_off.p + nslots;
+        launch_k_scan_rows(dim3(1), dim3(1024), st, (const unsigned *)c->rows.p, (long long)nslots, (unsigned long long *)c->rows_off.p, d_total);
+        HIPCHK(hipGetLastError());
+        // (per tile only its first slot's offset and the chunk's total are needed on the host)
+        HIPCHK(hipMemcpy2DAsync(offs.data(), 8, c->rows_off.p, (size_t)slots * 8, 8, (size_t)nt, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&offs[(size_t)nt], d_total, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(stream_wait(st));
+        const unsigned long long chunk_total = offs[(size_t)nt];
+        for (int j = 0; j < nt; j++) {
+            const unsigned long long cnt = offs[(size_t)j + 1] - offs[(size_t)j];
+            kinds[(size_t)work[(size_t)(w0 + j)]] = cnt ? 2 : 1;
+            if (cnt) m->st.n_nonempty++; else m->st.n_empty++;
+        }
+        if (chunk_total) {
+            if ((total + chunk_total) * 72 > m->out.bytes) {       // grow the soup (geometric), keeping what is there
+                DevBuf bigger;
+                if (bigger.ensure(std::max<size_t>((size_t)(total + chunk_total) * 72 * 2, (size_t)1 << 22))) return 1;
+                if (total) HIPCHK(hipMemcpyAsync(bigger.p, m->out.p, (size_t)total * 72, hipMemcpyDeviceToDevice, st));
+                HIPCHK(stream_wait(st));
+                m->out.release();
+                m->out = bigger;
+            }
+            launch_k_field_emit(dim3((unsigned)(slots / 256), (unsigned)nt), dim3(256), st, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
+                                (const FieldTile *)c->field_tiles.p, (const unsigned long long *)c->rows_off.p, (double *)m->out.p, total,
+                                (unsigned long long)(m->out.bytes / 72), slots);
+            HIPCHK(hipGetLastError());
+            HIPCHK(stream_wait(st));   // (the chunk's buffers are refilled next)
+            total += chunk_total;
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev[2], st));
+    m->st.n_triangles = (int64_t)total;
+    m->st.n_sampled_voxels = m->st.n_eval_voxels;
+    m->st.n_batch_instrs = (int64_t)(t->n_words / 2 - 1) * (h.work_end - h.work_begin);
+    // (work items of other shards stay 255 = "other shard", like the fused path)
+    HIPCHK(hipMemcpyAsync(m->kinds.p, kinds.data(), (size_t)nb, hipMemcpyHostToDevice, st));
+    HIPCHK(stream_wait(st));
+    float ms_pre = 0, ms_tot = 0;
+    HIPCHK(hipEventElapsedTime(&ms_pre, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms_tot, c->ev[0], c->ev[2]));
+    m->st.ms_prepass = ms_pre; m->st.ms_total = ms_tot; m->st.ms_mesh = ms_tot - ms_pre;
+    m->emitted_to = nullptr;
+    return 0;
+}
+
 extern "C" {
 
 int sdf_mesh_destroy(sdf_mesh *m);
@@ -1575,7 +1701,9 @@ static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y,
     if (!t || !X || !Y || !Z || !out) return fail("sdf_generate: NULL argument");
     *out = nullptr;
     if (t->n_extern) return fail("sdf_generate: the tape reads user closures (L_EXTERN): mesh it with sdf_generate_field");
-    if (bs < 1 || bs > 32) return fail("sdf_generate: batch_size must be in 1..32 (the (batch_size+1)^3 float32 tile lives in LDS)");
+    if (bs < 1 || bs > SDF_BATCH_SIZE_MAX) return fail("sdf_generate: batch_size must be in 1..512");
+    if (bs > 32 && slab_items >= 0) return fail("sdf_generate_compact: batch_size must be in 1..32 (batches of more than 33^3 samples are not part of the multi-GPU exchange)");
+    if (bs > 32 && d_kinds_in) return fail("sdf_generate_from_kinds: batch_size must be in 1..32");
     if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sdf_generate: bad shard");
     if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_generate: bad precision");
     if (nx < 0 || ny < 0 || nz < 0) return fail("sdf_generate: negative axis length");
@@ -1583,7 +1711,10 @@ static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y,
     HIPCHK(set_device(c->device));
     sdf_mesh *m = new sdf_mesh();
     m->ctx = c;
-    if (generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out, async_mode, slab_items, nullptr, d_kinds_in)) {
+    // (batch_size > 32: through device memory, synchronously, into library memory -- a caller buffer is reported as not filled,
+    // like one that was too small: sdf_mesh_emit_device copies)
+    if (bs > 32 ? generate_big(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision)
+                : generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_out, async_mode, slab_items, nullptr, d_kinds_in)) {
         const std::string keep = g_err;
         sdf_mesh_destroy(m);
         g_err = keep;
@@ -1631,7 +1762,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
                        const double *Z, int nz, int bs, int sparse, int64_t shard_index, int64_t shard_count, sdf_mesh **out) {
     if (!c || !field || !X || !Y || !Z || !out) return fail("sdf_generate_field: NULL argument");
     *out = nullptr;
-    if (bs < 1 || bs > 32) return fail("sdf_generate_field: batch_size must be in 1..32");
+    if (bs < 1 || bs > SDF_BATCH_SIZE_MAX) return fail("sdf_generate_field: batch_size must be in 1..512");
     if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sdf_generate_field: bad shard");
     if (nx < 0 || ny < 0 || nz < 0) return fail("sdf_generate_field: negative axis length");
     HIPCHK(set_device(c->device));
@@ -1657,7 +1788,8 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
         lx = std::min(bs + 1, nx - ox); ly = std::min(bs + 1, ny - oy); lz = std::min(bs + 1, nz - oz);
     };
     const size_t tile_max = (size_t)(bs + 1) * (bs + 1) * (bs + 1);
-    const int CH = 32;                                    // batches per submission
+    const int slots = bs <= 32 ? 1024 : ((bs * bs + 255) & ~255);                      // row slots per tile (k_field_rows)
+    const int CH = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)64 << 20) / tile_max));   // batches per submission (<= 2 GB of pinned points)
     const size_t pts_cap = std::max<size_t>((size_t)CH * tile_max, (size_t)9 << 12);   // points per callback
     if (sdf_host_alloc(pts_cap * 24, &h_pts) || sdf_host_alloc(pts_cap * 8, &h_vals)) return 1;
     double *pts = (double *)h_pts, *vals = (double *)h_vals;
@@ -1703,7 +1835,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
 
     // ---- `_worker` for the shard's batches, CH at a time ----
     std::vector<FieldTile> tiles((size_t)CH);
-    std::vector<unsigned long long> offs((size_t)CH * 1024 + 1);
+    std::vector<unsigned long long> offs((size_t)CH * slots + 1);
     unsigned long long total = 0;
     for (int w0 = w_begin; w0 < w_end; w0 += CH) {
         const int nt = std::min(CH, w_end - w0);
@@ -1725,7 +1857,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
             m->st.n_eval_voxels += (int64_t)lx * ly * lz;
         }
         if (field(user, pts, (int64_t)npts, vals)) return fail("sdf_generate_field: the field callback failed");
-        const size_t nslots = (size_t)nt * 1024;
+        const size_t nslots = (size_t)nt * slots;
         if (c->field_vals.ensure(npts * 8) || c->field_vol.ensure(npts * 4) || c->field_tiles.ensure(sizeof(FieldTile) * CH) ||
             c->rows.ensure(nslots * 4) || c->rows_off.ensure((nslots + 1) * 8))
             return 1;
@@ -1733,8 +1865,8 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
         HIPCHK(hipMemcpyAsync(c->field_tiles.p, tiles.data(), sizeof(FieldTile) * (size_t)nt, hipMemcpyHostToDevice, c->stream));
         launch_k_cast_f32(dim3((unsigned)((npts + 255) / 256)), dim3(256), c->stream, (const double *)c->field_vals.p,
                            (float *)c->field_vol.p, (long long)npts);
-        launch_k_field_rows(dim3(4, (unsigned)nt), dim3(256), c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
-                           (const FieldTile *)c->field_tiles.p, (unsigned *)c->rows.p);
+        launch_k_field_rows(dim3((unsigned)(slots / 256), (unsigned)nt), dim3(256), c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
+                           (const FieldTile *)c->field_tiles.p, (unsigned *)c->rows.p, slots);
         unsigned long long *d_total = (unsigned long long *)c->rows_off.p + nslots;
         launch_k_scan_rows(dim3(1), dim3(1024), c->stream, (const unsigned *)c->rows.p, (long long)nslots,
                            (unsigned long long *)c->rows_off.p, d_total);
@@ -1743,7 +1875,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
         HIPCHK(stream_wait(c->stream));
         const unsigned long long chunk_total = offs[nslots];
         for (int j = 0; j < nt; j++) {
-            const unsigned long long cnt = offs[(size_t)(j + 1) * 1024] - offs[(size_t)j * 1024];
+            const unsigned long long cnt = offs[(size_t)(j + 1) * slots] - offs[(size_t)j * slots];
             kinds[(size_t)work[(size_t)(w0 + j)]] = cnt ? 2 : 1;
             if (cnt) m->st.n_nonempty++; else m->st.n_empty++;
         }
@@ -1756,9 +1888,9 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
                 m->out.release();
                 m->out = bigger;
             }
-            launch_k_field_emit(dim3(4, (unsigned)nt), dim3(256), c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
+            launch_k_field_emit(dim3((unsigned)(slots / 256), (unsigned)nt), dim3(256), c->stream, (const McTables *)c->mc.p, (const float *)c->field_vol.p,
                                (const FieldTile *)c->field_tiles.p, (const unsigned long long *)c->rows_off.p, (double *)m->out.p, total,
-                               (unsigned long long)(m->out.bytes / 72));
+                               (unsigned long long)(m->out.bytes / 72), slots);
             HIPCHK(hipGetLastError());
             HIPCHK(stream_wait(c->stream));   // (the chunk's buffers are refilled next)
             total += chunk_total;

@@ -147,9 +147,9 @@ __device__ __forceinline__ unsigned mc_row_count(const McTables *__restrict__ mc
 }
 
 __global__ __launch_bounds__(256) void k_field_rows(const McTables *__restrict__ mc, const float *__restrict__ vol,
-                                                    const FieldTile *__restrict__ tiles, unsigned int *__restrict__ row_count) {
+                                                    const FieldTile *__restrict__ tiles, unsigned int *__restrict__ row_count, int slots) {
     const FieldTile tl = tiles[blockIdx.y];
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);        // row slot 0..1023
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);        // row slot 0 .. slots - 1 (1024 for tiles of <= 33^3 samples)
     const int c0 = tl.n0 - 1, c1 = tl.n1 - 1, c2 = tl.n2 - 1;
     unsigned cnt = 0;
     if (c0 > 0 && c1 > 0 && c2 > 0 && t < c0 * c1) {
@@ -157,12 +157,12 @@ __global__ __launch_bounds__(256) void k_field_rows(const McTables *__restrict__
         const int s0 = tl.n1 * tl.n2, s1 = tl.n2;
         cnt = mc_row_count(mc, vol + tl.vol_off + (long long)i0 * s0 + (long long)i1 * s1, s0, s1, c2);
     }
-    row_count[(size_t)blockIdx.y * 1024 + t] = cnt;
+    row_count[(size_t)blockIdx.y * (size_t)slots + t] = cnt;
 }
 
 __global__ __launch_bounds__(256) void k_field_emit(const McTables *__restrict__ mc, const float *__restrict__ vol,
                                                     const FieldTile *__restrict__ tiles, const unsigned long long *__restrict__ row_off,
-                                                    double *__restrict__ out, unsigned long long base, unsigned long long cap) {
+                                                    double *__restrict__ out, unsigned long long base, unsigned long long cap, int slots) {
     const FieldTile tl = tiles[blockIdx.y];
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int c0 = tl.n0 - 1, c1 = tl.n1 - 1, c2 = tl.n2 - 1;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_field_emit(const McTables *__restrict__
     const int i0 = t / c1, i1 = t - i0 * c1;
     const int s0 = tl.n1 * tl.n2, s1 = tl.n2;
     const float *row = vol + tl.vol_off + (long long)i0 * s0 + (long long)i1 * s1;
-    unsigned long long k = base + row_off[(size_t)blockIdx.y * 1024 + t];
+    unsigned long long k = base + row_off[(size_t)blockIdx.y * (size_t)slots + t];
     unsigned prev = plane_bits(row, s0, s1);
     for (int i2 = 0; i2 < c2; i2++) {
         const unsigned next = plane_bits(row + i2 + 1, s0, s1);
@@ -490,12 +490,13 @@ void launch_k_mc_emit(dim3 grid, dim3 block, hipStream_t stream, const McTables 
 void launch_k_cast_f32(dim3 grid, dim3 block, hipStream_t stream, const double *in, float *out, long long n) {
     hipLaunchKernelGGL(k_cast_f32, grid, block, 0, stream, in, out, n);
 }
-void launch_k_field_rows(dim3 grid, dim3 block, hipStream_t stream, const McTables *mc, const float *vol, const FieldTile *tiles, unsigned int *row_count) {
-    hipLaunchKernelGGL(k_field_rows, grid, block, 0, stream, mc, vol, tiles, row_count);
+void launch_k_field_rows(dim3 grid, dim3 block, hipStream_t stream, const McTables *mc, const float *vol, const FieldTile *tiles, unsigned int *row_count,
+                         int slots) {
+    hipLaunchKernelGGL(k_field_rows, grid, block, 0, stream, mc, vol, tiles, row_count, slots);
 }
 void launch_k_field_emit(dim3 grid, dim3 block, hipStream_t stream, const McTables *mc, const float *vol, const FieldTile *tiles,
-                         const unsigned long long *row_off, double *out, unsigned long long base, unsigned long long cap) {
-    hipLaunchKernelGGL(k_field_emit, grid, block, 0, stream, mc, vol, tiles, row_off, out, base, cap);
+                         const unsigned long long *row_off, double *out, unsigned long long base, unsigned long long cap, int slots) {
+    hipLaunchKernelGGL(k_field_emit, grid, block, 0, stream, mc, vol, tiles, row_off, out, base, cap, slots);
 }
 void launch_k_scan_items(dim3 grid, dim3 block, hipStream_t stream, const ItemDesc *desc, MeshCounters *ctr, unsigned long long *status,
                          int *block_item, unsigned long long n_blocks) {

@@ -139,24 +139,48 @@ ABI = {
 ABI_VERSION = 7
 
 
+def _strip_c_comments(text):
+    """C / C++ source without its comments; string and character literals are left alone (a `//` inside a format string or
+    a URL is not a comment)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        ch = text[i]
+        if ch in '"\'':                                  # a literal: copy to its closing quote, honouring escapes
+            j = i + 1
+            while j < n and text[j] != ch:
+                j += 2 if text[j] == '\\' else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith('//', i):
+            j = text.find('\n', i)
+            i = n if j < 0 else j
+        elif text.startswith('/*', i):
+            j = text.find('*/', i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(ch); i += 1
+    return ''.join(out)
+
+
 def source_id():
-    """sha256 (16 hex digits) over the kernels' sources, sdf_amd/csrc/*.{h,hip,sh}, WITHOUT their comments and blank
-    lines: what a committed rocprofv3 summary was taken on (tools/summarize_prof.py writes it, bench.py only quotes a
-    summary whose id is this build's).  Editing a comment does not make a profile stale; editing code does."""
+    """sha256 (16 hex digits) over the library's sources -- sdf_amd/csrc/*.{h,hip,inc,sh} and the public header
+    include/sdf_hip.h -- WITHOUT their comments and blank lines: what a committed rocprofv3 summary was taken on
+    (tools/summarize_prof.py writes it, bench.py only quotes a summary whose id is this build's).  Editing a comment does
+    not make a profile stale; editing code, a string literal or the exchange's host code does."""
     import glob
     import hashlib
     import re
     h = hashlib.sha256()
-    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-    for f in sorted(glob.glob(os.path.join(d, '*'))):
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = os.path.join(here, 'csrc')
+    files = sorted(glob.glob(os.path.join(d, '*'))) + [os.path.join(os.path.dirname(here), 'include', 'sdf_hip.h')]
+    for f in files:
         ext = f.rsplit('.', 1)[-1]
-        if os.path.isfile(f) and ext in ('h', 'hip', 'sh'):      # (not sdf_comm.inc: the host side of the exchange, no kernel)
+        if os.path.isfile(f) and ext in ('h', 'hip', 'inc', 'sh'):
             text = open(f, encoding='utf-8', errors='replace').read()
             if ext == 'sh':
                 text = re.sub(r'(?m)^\s*#(?!!).*$', '', text)
             else:
-                text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-                text = re.sub(r'//[^\n]*', '', text)
+                text = _strip_c_comments(text)
             text = '\n'.join(ln.rstrip() for ln in text.split('\n') if ln.strip())
             h.update(os.path.basename(f).encode()); h.update(text.encode())
     return h.hexdigest()[:16]

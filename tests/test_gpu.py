@@ -156,6 +156,37 @@ def test_generate_matches_oracle_and_reference(path, ns, oracle_lib, eng):
         assert hashlib.sha256(pts.tobytes()).digest() == d['sha256'].tobytes()   # == reference
 
 
+@pytest.mark.parametrize('bs', [33, 40, 64, 100])
+def test_batch_size_above_32_goes_through_device_memory(bs, ns, oracle_lib, eng):
+    """batch_size > 32 (reference sdf/core.py:87, 114-119 takes any): the (batch_size + 1)^3 tile does not fit LDS; the batches
+    are sampled into device memory (k_eval_tiles) and marched there (k_field_*): same soup, classification and order as the
+    checker's restatement of `generate` -- regular, ragged and single-batch grids, sparse and not, sharded, into a caller
+    buffer (reported as not filled, like one that is too small), asynchronously.  The reference's own soups at batch sizes
+    40 / 48 / 64 / 128 are the gen_*_b*.npz goldens of test_generate_matches_oracle_and_reference."""
+    import torch
+    f = fixtures.build('ex_example', ns)
+    for samples, sparse in ((2 ** 18, True), (2 ** 20, False), (30000, True)):
+        X, Y, Z, _ = core.grid_axes(((-0.85, -0.85, -0.85), (0.85, 0.85, 0.85)), samples=samples)
+        o = oracle_lib.generate(f, X, Y, Z, bs, sparse)
+        m = eng.generate(f, X, Y, Z, bs, sparse)
+        st = m.stats()
+        assert np.array_equal(m.points(), o.points) and np.array_equal(m.kinds(), o.kinds)
+        assert (st['skipped'], st['empty'], st['nonempty']) == tuple(int((o.kinds == k).sum()) for k in (0, 1, 2))
+        assert st['n_eval_voxels'] == o.n_eval and st['triangles'] == len(o.points) // 3
+        m.close()
+    # shards concatenate to the whole; a caller buffer is not filled but the soup is there; the asynchronous entry point too
+    parts = []
+    for i in range(3):
+        m = eng.generate(f, X, Y, Z, bs, True, shard=(i, 3))
+        parts.append(m.points()); m.close()
+    assert np.array_equal(np.concatenate(parts), o.points)
+    buf = torch.full((9 * (len(o.points) // 3) + 9,), -7.0, dtype=torch.float64, device='cuda:0')
+    for wait in (True, False):
+        m = eng.generate(f, X, Y, Z, bs, True, out_ptr=buf.data_ptr(), out_cap=len(o.points) // 3, wait=wait)
+        assert np.array_equal(m.points(), o.points) and not m.emitted and float(buf[-1]) == -7.0
+        m.close()
+
+
 def test_generate_drop_in_api_and_stl(ns, tmp_path, capsys):
     """f.generate()/f.save() keep the reference signatures, prints and STL bytes"""
     f = fixtures.build('ex_example', ns)
@@ -250,7 +281,9 @@ def test_edge_cases(ns, eng, oracle_lib):
     # bad arguments fail loudly
     from sdf_amd import engine
     with pytest.raises(engine.SdfHipError):
-        eng.generate(f, np.arange(4.0), np.arange(4.0), np.arange(4.0), batch_size=64)
+        eng.generate(f, np.arange(4.0), np.arange(4.0), np.arange(4.0), batch_size=513)
+    with pytest.raises(engine.SdfHipError):
+        eng.generate(f, np.arange(4.0), np.arange(4.0), np.arange(4.0), batch_size=0)
 
 
 @pytest.mark.timeout(900)
@@ -1342,6 +1375,8 @@ def test_split_meshing_tile_arena_too_small_is_repeated(ns, eng):
 import sys, hashlib
 sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
 import numpy as np
+import torch
+torch.cuda.set_device(0)      # (torch's HIP runtime first, like every process of this suite)
 import sdf_amd
 from sdf_amd import core, engine
 import fixtures
@@ -1352,7 +1387,6 @@ X, Y, Z, _ = core.grid_axes(((-0.85, -0.85, -0.85), (0.85, 0.85, 0.85)), samples
 eng.set_split(1)
 m = eng.generate(f, X, Y, Z, 32, True); a = m.points(); sa = m.stats(); m.close()
 m = eng.generate(f, X, Y, Z, 32, True); a2 = m.points(); sa2 = m.stats(); m.close()
-import torch
 buf = torch.empty(9 * (sa['triangles'] + 8), dtype=torch.float64, device='cuda:0')
 g = fixtures.build('ex_blobby', ns)
 X2, Y2, Z2, _ = core.grid_axes(((-1.2, -1.2, -1.2), (1.2, 1.2, 1.2)), samples=2 ** 21)

@@ -244,8 +244,17 @@ def gen_generate():
         ('torus_s15', 'torus', True, dict(samples=2 ** 15)),
         ('slice_s15', 'slice', False, dict(samples=2 ** 15)),
         ('extrude_to_s15', 'extrude_to', False, dict(samples=2 ** 15)),
+        # batch_size > 32 (reference sdf/core.py:87, 114-119 takes any): round 5
+        ('example_s17_b64', 'ex_example', True, dict(samples=2 ** 17, batch_size=64)),
+        ('example_s22_b48', 'ex_example', False, dict(samples=2 ** 22, batch_size=48)),
+        ('example_s22_b128', 'ex_example', False, dict(samples=2 ** 22, batch_size=128)),
+        ('gearlike_s20_b64', 'ex_gearlike', False, dict(samples=2 ** 20, batch_size=64)),
+        ('blobby_s20_b40_dense', 'ex_blobby', False, dict(samples=2 ** 20, batch_size=40, sparse=False)),
     ]
+    only = os.environ.get('GOLDEN_ONLY')       # (comma-separated tags: make just those)
     for tag, name, full, kw in jobs:
+        if only and tag not in only.split(','):
+            continue
         rec = run_generate(name, full, **dict(kw))
         rec['fixture'] = np.array(name)
         rec['kwargs'] = np.array(repr(kw))
