@@ -52,13 +52,13 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 OTHER_CONFIGS = [('gearlike', 30, 10204096, 24), ('weave', 33, 53943912, 6), ('blobby', 30, 4048520, 24)]
 
 
-# DESIGN.md section 6, arithmetic for 8 GPUs (one GPU's measured stage times / 8 + fixed costs + 36 B per triangle over one xGMI
+# DESIGN.md section 6, arithmetic for 8 GPUs (one GPU's measured stage times / 8 + fixed costs + 16 B per triangle (sdf_slab.h records) over one xGMI
 # link at ~76 GB/s + the expansion every rank repeats); printed next to the measured stage times of an N > 1 run
 EXPECTED_SCALING = {
     'example': 'C2 512^3: break-even by construction (~1.0 - 1.3 x at 8 GPUs): the work that divides is ~0.03 ms of a ~0.3 ms step; fixed: skip test, '
-               'all-gather of 6 MB slabs (~0.08 ms on the wire), k_expand of the whole soup on every rank (~0.08 ms)',
-    'gearlike': 'C3 2^30: ~2.5 x at 8 GPUs (1.6 ms -> ~0.6 ms: 21 MB slabs ~0.3 ms on the wire overlap the next step\'s meshing with two lanes)',
-    'weave': 'C4 2^33: ~4 x at 8 GPUs (24 ms -> ~6 ms: meshing / 8 ~3 ms, 115 MB slab ~1.5 ms on the wire, k_expand ~1.6 ms)',
+               'all-gather of 6 MB slabs (16 B per triangle: 47 MB over seven links, ~0.08 ms on the wire), k_expand of the whole soup on every rank (~0.08 ms)',
+    'gearlike': 'C3 2^30: ~2.5 x at 8 GPUs (1.6 ms -> ~0.6 ms: 21 MB slabs (16 B per triangle) ~0.3 ms on the wire overlap the next step\'s meshing with two lanes)',
+    'weave': 'C4 2^33: ~4 x at 8 GPUs (24 ms -> ~6 ms: meshing / 8 ~3 ms, 115 MB slab (16 B per triangle) ~1.5 ms on the wire, k_expand ~1.6 ms)',
     'blobby': 'C5 2^30: ~2 x at 4 GPUs (1.2 ms -> ~0.6 ms)',
 }
 
@@ -191,6 +191,18 @@ def pipelined_overlap(spans, dev_ms):
             'start_to_start_ms': stats3([g * 1e-3 for g in gaps]) if gaps else None,
             'note': 'span = first workgroup start to last workgroup end of k_mesh on the device clock; a span overlapped by a neighbour '
                     'is a launch that shared the CUs, not a slower kernel: the start-to-start interval is the step time'}
+
+
+def valu_issue(pmc_kernel, k_ms, iso, world, sampled_vox, plain, special, st):
+    """share of the kernel's SIMD cycles spent issuing vector-ALU instructions, from the committed counters of this source"""
+    if not (pmc_kernel.get('SQ_INSTS_VALU') and world == 1 and iso and k_ms > 0 and iso['sclk_mhz_in_kernel']['median']):
+        return None
+    n = float(pmc_kernel['SQ_INSTS_VALU']['mean'])
+    cyc = 1024.0 * k_ms * 1e-3 * float(iso['sclk_mhz_in_kernel']['median']) * 1e6        # SIMD cycles of the launch
+    kept = 1.0 - (st.get('n_pruned_instrs', 0) / st['n_batch_instrs'] if st.get('n_batch_instrs') else 0.0)
+    f64 = min(n, sampled_vox / 64.0 * (plain + 20.0 * special) * kept)
+    return {'upper_all_4_cycles': round(4.0 * n / cyc, 3), 'lower_all_2_cycles': round(2.0 * n / cyc, 3),
+            'weighted_f64_4_rest_2': round((4.0 * f64 + 2.0 * (n - f64)) / cyc, 3), 'f64_wave_instructions_est': round(f64)}
 
 
 def stats3(v):
@@ -500,6 +512,41 @@ def main():
             mesh.close()
         incl = grid_voxels * n_incl / (time.perf_counter() - t1)
 
+    # ---- what a DROP-IN caller waits for: `f.generate(samples=2**27, verbose=False)` through sdf_amd.core on a FRESH model every
+    # time -- bounds estimate (k_estimate_bounds), lowering to a tape + upload, grid, meshing, D2H of the soup into the ndarray the
+    # reference's signature returns -- next to its parts; comparable like for like with the reference's generate() of
+    # cpu_baseline (which includes `_estimate_bounds` too).  Never `value`. ----
+    e2e = None
+    if world == 1 and args.model == 'example' and args.precision == 'f64':
+        trace('generate end to end')
+        tt, tb, tl = [], [], []
+        for i in range(12):
+            f2, _ = build_model(args.model)
+            t1 = time.perf_counter()
+            pts = f2.generate(samples=2 ** args.samples_log2, verbose=False)
+            tt.append(1e3 * (time.perf_counter() - t1))
+            n_e2e = len(pts) // 3
+            del pts
+            f3, _ = build_model(args.model)
+            t1 = time.perf_counter(); core._estimate_bounds(f3); tb.append(1e3 * (time.perf_counter() - t1))
+            f4, _ = build_model(args.model)
+            t1 = time.perf_counter(); eng.tape_for(f4); tl.append(1e3 * (time.perf_counter() - t1))
+        e2e = {'wall_ms': stats3(tt[2:]), 'triangles': n_e2e, 'voxels_per_sec_median': round(grid_voxels / (1e-3 * float(np.median(tt[2:]))), 1),
+               'of_which_ms': {'estimate_bounds': stats3(tb[2:]), 'lower_and_upload_tape': stats3(tl[2:])},
+               'what': 'f.generate(samples=2**%d, verbose=False) on a fresh model object, 10 calls after 2 warm-up calls: bounds + tape + grid + '
+                       'meshing + D2H of the float64 soup (pinned blocks) + the (n, 3) ndarray' % args.samples_log2}
+
+    # ---- a SUSTAINED run of the headline job: >= 2000 steps (>= 0.4 s of kernels back to back), same steps in flight, with the
+    # shader clock the kernels measured themselves -- the 20-step headline is a 5 ms burst that the clocks could flatter ----
+    sustained = None
+    if world == 1 and args.model == 'example' and not args.sync:
+        trace('sustained run')
+        rs = measure(args.model, args.samples_log2, 2000, 0, DEPTH)
+        sustained = {'steps': 2000, 'seconds': round(rs['dt'], 4), 'ms_per_step': round(1e3 * rs['dt'] / 2000, 4),
+                     'value': round(rs['grid_voxels'] * 2000 / rs['dt'], 1), 'sclk_mhz_in_kernel': stats3(rs['sclk']) if rs['sclk'] else None,
+                     'kernel_ms': stats3(rs['mesh_ms']), 'clocks_after': read_clocks()}
+        del rs
+
     # ---- SECONDARY: the same job with the tape evaluated in float32, and how far its soup is from the float64 one ----
     env32 = None
     if world == 1 and args.precision == 'f64' and not args.no_f32_envelope and not args.no_check:
@@ -663,8 +710,11 @@ def main():
                  # launch, and the share of the kernel's SIMD cycles they occupy at 4 cycles each (1024 SIMDs, the shader
                  # clock the kernel measured itself): how much of k_mesh is instruction issue
                  'valu_wave_instructions_per_launch': (pmc_kernel.get('SQ_INSTS_VALU') or {}).get('mean'),
-                 'valu_issue_fraction': (round(4.0 * pmc_kernel['SQ_INSTS_VALU']['mean'] / (1024.0 * k_ms * 1e-3 * float(iso['sclk_mhz_in_kernel']['median']) * 1e6), 3)
-                                         if pmc_kernel.get('SQ_INSTS_VALU') and world == 1 and iso and k_ms > 0 and iso['sclk_mhz_in_kernel']['median'] else None)},
+                 # upper bound: every VALU wave-instruction charged 4 cycles (true for float64 arithmetic only: a SIMD is 16 lanes
+                 # wide for it); lower bound: every one 2 cycles (MI355X_MICROARCH.md: a VALU instruction issues over 2 cycles);
+                 # weighted: 4 cycles for the interpreter's float64 instructions (interpreted voxels x the tape's operations per
+                 # voxel after pruning, sqrt / division sequences at ~ 20), 2 for everything else (marching, bookkeeping: int / f32)
+                 'valu_issue_fraction': valu_issue(pmc_kernel, k_ms, iso, world, sampled_vox, plain, special, st)},
     }
 
     # ---- CPU baseline 1: the reference's own path (reference sdf/core.py:84-150, NumPy thread pool + skimage) ----
@@ -705,6 +755,8 @@ def main():
         'triangles_per_sec': round(tris * args.steps / dt, 1),
         'eval_voxels_per_sec': round(int(st['n_eval_voxels']) * args.steps / dt, 1),
         'value_incl_d2h': round(incl, 1) if incl else None,
+        'generate_e2e': e2e,
+        'sustained': sustained,
         'steps_in_flight': DEPTH,
         'latency_ms_per_call': iso['wall_ms']['median'] if iso else None,
         'isolated_calls': iso,

@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -254,7 +255,7 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
                                                      const int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned char *cull_smem, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max, int levels) {
+                                                     int *__restrict__ order, int tail_max, int levels, int *__restrict__ owner, unsigned long long owner_cap) {
     int *wave_sums = reinterpret_cast<int *>(cull_smem);                       // 64 B
     double *axes = reinterpret_cast<double *>(cull_smem + 64);                 // 3 * 33 doubles
     unsigned char *scratch = cull_smem + 896;                                  // CULL_SCRATCH bytes
@@ -301,6 +302,13 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
             (unsigned)min(atomicAdd(&ctr->tile_cursor, (unsigned long long)tile_need256(ntl, lx * ly * lz)), 0xFFFFFFFFull);
     }
     __syncthreads();
+    if (owner) {   // (uniform) split meshing: whose samples each 256-byte unit of the tile's place holds (k_sample goes by units)
+        const unsigned long long off = reinterpret_cast<const unsigned *>(scratch)[1];
+        const int nvox = lx * ly * lz;
+        const unsigned need = tile_need256(ntl, nvox), data_units = (tile_data_bytes(ntl, nvox) + 255u) >> 8;
+        for (unsigned i = tid; i < need; i += CB)
+            if (off + i < owner_cap) owner[off + i] = i < data_units ? w : -1;
+    }
     {   // the record: header + the listed units (whole tasks), and the sub-group states
         unsigned *rec = reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD);
         const unsigned *src = reinterpret_cast<const unsigned *>(scratch);
@@ -333,9 +341,9 @@ __global__ __launch_bounds__(CB) void k_cull(const uint32_t *__restrict__ code, 
                                                      const int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max, int levels) {
+                                                     int *__restrict__ order, int tail_max, int levels, int *__restrict__ owner, unsigned long long owner_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<FULL, RARE, CB>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
+    cull_body<FULL, RARE, CB>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels, owner, owner_cap);
 }
 // the variant for tapes without trigonometry and without the rarer leaves: 70 VGPRs without spilling, seven waves per
 // SIMD (the others take 99 - 104; holding them to five or six waves was measured in r02p: no faster)
@@ -343,9 +351,9 @@ __global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
                                                      const int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max, int levels) {
+                                                     int *__restrict__ order, int tail_max, int levels, int *__restrict__ owner, unsigned long long owner_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
+    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels, owner, owner_cap);
 }
 // (experiment: the same with two waves per workgroup -- twelve workgroups fit a CU, every work item of the 512^3
 // example is resident at once instead of in two rounds)
@@ -353,9 +361,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                      const int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max, int levels) {
+                                                     int *__restrict__ order, int tail_max, int levels, int *__restrict__ owner, unsigned long long owner_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
+    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels, owner, owner_cap);
 }
 
 // (every kernel that is not a tape interpreter -- the compaction, marching cubes of caller-supplied volumes, the two-pass
@@ -537,6 +545,8 @@ struct sdf_ctx {
     int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
     int defer = 1;                    // SDF_DEFER=0: k_mesh keeps every tile dense and writes (or parks) a batch's triangles right after counting it
     unsigned long long tiles_first_cap256 = (1ull << 30) >> 8;   // SDF_TILES_FIRST_CAP256: the tile arena of a tape's FIRST call on a grid (tests force the too-small path)
+    int march_two = 1;                // SDF_MARCH_TWO=0: k_march counts, places and emits in ONE launch (its look-back then waits for tiles still being counted)
+    int march_block = 256;            // SDF_MARCH_BLOCK=256 / 512 / 1024: threads per workgroup of k_march (tuning)
     int split = -1;                   // SDF_MESH_SPLIT: the meshing pass as k_sample + k_march (sdf_split.h): -1 by the tape, 0 never (k_mesh), 1 wherever k_cull runs
     int cull_levels = 0;              // SDF_CULL_LEVELS=2 / 3: interval levels of k_cull (3: + sub-groups of 2^3 cells); 0: by the tape (see generate_impl)
 };
@@ -564,7 +574,7 @@ struct sdf_mesh {
     sdf_stats st = {};
     GridDesc g = {};
     DevBuf axes, kinds, worklist, status, out, prune, tapes, cull, order;
-    DevBuf tiles;                     // split meshing (sdf_split.h): the arena of sampled tiles, k_sample -> k_march
+    DevBuf tiles, owner;              // split meshing (sdf_split.h): the arena of sampled tiles (k_sample -> k_march), the work item of each of its 256-byte units
     DevBuf desc, cellrecs, trilist;   // two-pass meshing: per work item / per surface cell / per triangle (sdf_device.h ItemDesc)
     DevBuf blockidx;                  // ... and per 256 triangles of the soup: the work item of the first of them
     bool pruned = false;
@@ -711,6 +721,8 @@ static int ctx_init(sdf_ctx *c) {
     if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
     if (const char *e = getenv("SDF_DEFER")) c->defer = atoi(e) ? 1 : 0;
     if (const char *e = getenv("SDF_MESH_SPLIT")) c->split = atoi(e) < 0 ? -1 : (atoi(e) ? 1 : 0);
+    if (const char *e = getenv("SDF_MARCH_TWO")) c->march_two = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("SDF_MARCH_BLOCK")) { const int v = atoi(e); c->march_block = v == 512 || v == 1024 ? v : 256; }
     if (const char *e = getenv("SDF_TILES_FIRST_CAP256")) c->tiles_first_cap256 = std::max<long long>(atoll(e), 1);
     if (const char *e = getenv("SDF_CULL_LEVELS")) c->cull_levels = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
@@ -1120,8 +1132,9 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     return 0;
 }
 
-// split meshing (sdf_split.h): k_sample (four workgroups of 256 threads per compute unit: the interpreter's registers) and, behind
-// it on the stream, k_march (six per compute unit: its LDS); both persistent over the work list, surplus workgroups leave at once
+// split meshing (sdf_split.h): k_sample (four workgroups of 256 threads per compute unit -- the interpreter's registers -- whose
+// waves each work on their own) and, behind it on the stream, k_march (workgroups of 256 / 512 / 1024 threads: four / two / one per
+// compute unit); both persistent, surplus workgroups leave at once
 static int launch_split(sdf_tape *t, const void *code, MeshArgs &a, int nb, hipStream_t st) {
     sdf_ctx *c = t->ctx;
     a.bits_off = a.list_off = a.list_cap = 0; a.slot_bytes = 0; a.stage_off = 0; a.twopass = 0;
@@ -1130,11 +1143,10 @@ static int launch_split(sdf_tape *t, const void *code, MeshArgs &a, int nb, hipS
     int slots = 5;
     for (int k = 5; k >= 0; k--) if (np <= kFile[k][0] && nd <= kFile[k][1]) slots = k;
     if (c->mesh_slots >= 0 && c->mesh_slots <= 5 && np <= kFile[c->mesh_slots][0] && nd <= kFile[c->mesh_slots][1]) slots = c->mesh_slots;
-    const int grid_s = (int)std::min<long long>(nb, (long long)c->n_cu * 4), grid_m = (int)std::min<long long>(nb, (long long)c->n_cu * MARCH_WG_PER_CU);
-    int rc = t->full ? sdf_launch_sample_f64_full(slots, grid_s, st, (const uint32_t *)code, t->d_c64, a)
-                     : sdf_launch_sample_f64(slots, grid_s, st, (const uint32_t *)code, t->d_c64, a);
+    int rc = t->full ? sdf_launch_sample_f64_full(slots, c->n_cu * 4, st, (const uint32_t *)code, t->d_c64, a)
+                     : sdf_launch_sample_f64(slots, c->n_cu * 4, st, (const uint32_t *)code, t->d_c64, a);
     if (rc) return fail(std::string("k_sample launch: ") + hipGetErrorString((hipError_t)rc));
-    rc = sdf_launch_march(grid_m, st, a);
+    rc = sdf_launch_march(c->march_block, c->march_two, c->n_cu, nb, st, a);
     if (rc) return fail(std::string("k_march launch: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
@@ -1324,6 +1336,31 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     // workgroups -- counts RESIDENT workgroups, and a k_mesh that shares the device with another call's k_mesh may have
     // fewer of them for a while; the neighbours fill the tail of such a call anyway)
     const bool tail_order = culling && c->tail_order && tail_max >= 2 && !async_mode;
+    const unsigned long long key = ((unsigned long long)nx << 42) ^ ((unsigned long long)ny << 21) ^ (unsigned long long)nz ^
+                                   ((unsigned long long)shard_index << 56) ^ ((unsigned long long)shard_count << 48) ^
+                                   ((unsigned long long)bs << 36) ^ (sparse ? 1ull << 63 : 0ull);
+    // One kernel or two?  Wherever k_cull runs, the meshing pass can go as k_sample + k_march (sdf_split.h): small workgroups, many
+    // per compute unit, the sampled tiles through an arena in device memory -- instead of k_mesh's one workgroup per compute
+    // unit that does everything in turn.  Same soup, bit for bit.  Not with the phase counters (k_mesh's), not where the caller
+    // asked for the dense-tile scheme.
+    // (an explicit choice of the one-kernel or the two-pass scheme -- sdf_ctx_set_twopass 0 / 1 -- stands unless split meshing was
+    // asked for explicitly as well)
+    const bool twopass_sel = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
+    bool split = culling && !c->prof.p && c->defer && nb < (1 << 30) && (c->split == 1 || (c->split < 0 && c->twopass < 0 && !twopass_sel));
+    bool fresh_buffers = false;     // an allocation below made the stream idle (the kernels' event times then start behind it)
+    unsigned long long tiles_cap256 = 0;
+    if (split) {
+        // the arena: what k_cull handed out the last time this tape ran on this grid (+ a margin: the order of the atomic
+        // additions does not change the sum, the tape's pruning does not change k_cull's lists -- the need is a function of
+        // tape and grid), else every batch as a dense tile, capped at 1 GB; a call that needs more is flagged and repeated
+        // with what k_cull reported.  `owner`: a word per 256-byte unit of the arena (k_cull -> k_sample)
+        const unsigned long long worst = (unsigned long long)nb * tile_need256(-1, (int)mesh_nvox);
+        tiles_cap256 = (t->hint_key == key && t->hint_tiles256) ? t->hint_tiles256 + t->hint_tiles256 / 16 + 64 : std::min<unsigned long long>(worst, c->tiles_first_cap256);
+        tiles_cap256 = std::min(tiles_cap256, worst);
+        if (m->tiles.bytes < (size_t)tiles_cap256 * 256 || m->owner.bytes < (size_t)tiles_cap256 * 4) fresh_buffers = true;
+        if (m->tiles.ensure((size_t)tiles_cap256 * 256) || m->owner.ensure((size_t)tiles_cap256 * 4)) return 1;
+    }
+    std::function<hipError_t()> launch_cull;      // (k_cull again: a tile arena that was too small, below)
     if (culling) {
         if (c->prof.p) HIPCHK(hipMemsetAsync((unsigned char *)c->prof.p + 128, 0, 384, st));
         if (m->cull.ensure((size_t)nb * CULL_RECORD) || (tail_order && m->order.ensure(MESH_TAIL_MAX * sizeof(int)))) return 1;
@@ -1353,12 +1390,16 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 896 - CULL_SCRATCH);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
-                           pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
-                           (const int *)m->worklist.p, (MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
-                           ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p, (unsigned long long *)c->prof.p,
-                           tail_order ? (int *)m->order.p : (int *)nullptr, tail_max, cull_levels);
-        HIPCHK(hipGetLastError());
+        launch_cull = [=]() {
+            hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
+                               pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
+                               (const int *)m->worklist.p, (MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
+                               ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p, (unsigned long long *)c->prof.p,
+                               tail_order ? (int *)m->order.p : (int *)nullptr, tail_max, cull_levels,
+                               split ? (int *)m->owner.p : (int *)nullptr, (unsigned long long)(m->owner.bytes / 4));
+            return hipGetLastError();
+        };
+        HIPCHK(launch_cull());
     }
     HIPCHK(hipEventRecord(cs.e2, st));
 
@@ -1369,13 +1410,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     // call: from the work-list length, which costs one synchronisation).  A soup that does not fit
     // is detected on the device (nothing is written past the capacity) and the pass is re-run into
     // a library buffer of the exact size. ----
-    const unsigned long long key = ((unsigned long long)nx << 42) ^ ((unsigned long long)ny << 21) ^ (unsigned long long)nz ^
-                                   ((unsigned long long)shard_index << 56) ^ ((unsigned long long)shard_count << 48) ^
-                                   ((unsigned long long)bs << 36) ^ (sparse ? 1ull << 63 : 0ull);
     unsigned long long cap = 0;
     MeshCounters h;
     bool to_caller = compact || (d_out && cap_out > 0);
-    bool quiet = true;     // nothing but k_mesh follows ev[2] on the stream, and the host did not stall in between
+    bool quiet = !fresh_buffers;     // nothing but k_mesh follows ev[2] on the stream, and the host did not stall in between
     if (!to_caller) {
         if (t->hint_key == key && t->hint_total_tris) {
             cap = t->hint_total_tris + t->hint_total_tris / 4 + 4096;
@@ -1392,25 +1430,6 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         }
     }
     float ms = 0;
-    // One kernel or two?  Wherever k_cull ran, the meshing pass can go as k_sample + k_march (sdf_split.h): small workgroups, many
-    // per compute unit, the sampled tiles through an arena in device memory -- instead of k_mesh's one workgroup per compute
-    // unit that does everything in turn.  Same soup, bit for bit.  Not with the phase counters (k_mesh's), not where the caller
-    // asked for the dense-tile scheme or for two passes.
-    const bool twopass_sel = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
-    // (an explicit choice of the one-kernel or the two-pass scheme -- sdf_ctx_set_twopass 0 / 1 -- stands unless split meshing was
-    // asked for explicitly as well)
-    bool split = culling && !c->prof.p && c->defer && (c->split == 1 || (c->split < 0 && c->twopass < 0 && !twopass_sel));
-    unsigned long long tiles_cap256 = 0;
-    if (split) {
-        // the arena: what k_cull handed out the last time this tape ran on this grid (+ a margin: the order of the atomic
-        // additions does not change the sum, the tape's pruning does not change k_cull's lists -- the need is a function of
-        // tape and grid), else every batch as a dense tile, capped at 1 GB; a call that needs more is flagged and repeated
-        const unsigned long long worst = (unsigned long long)nb * tile_need256(-1, (int)mesh_nvox);
-        tiles_cap256 = (t->hint_key == key && t->hint_tiles256) ? t->hint_tiles256 + t->hint_tiles256 / 16 + 64 : std::min<unsigned long long>(worst, c->tiles_first_cap256);
-        tiles_cap256 = std::min(tiles_cap256, worst);
-        if (m->tiles.bytes < (size_t)tiles_cap256 * 256) quiet = false;
-        if (m->tiles.ensure((size_t)tiles_cap256 * 256)) return 1;
-    }
     for (int attempt = 0;; attempt++) {
         MeshArgs a;
         a.compact = 0; a.xf = nullptr; a.xf_cap = 0; a.raw = nullptr; a.raw_cap = 0;
@@ -1463,6 +1482,8 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         // override).
         const bool twopass = twopass_sel && !split;
         a.tiles = split ? (unsigned char *)m->tiles.p : nullptr; a.tiles_cap256 = split ? tiles_cap256 : 0;
+        a.owner = split ? (const int *)m->owner.p : nullptr;
+        a.code_for_stats = pruning ? m->tapes.p : (const void *)t->d_code;
         if (split) { a.park = nullptr; a.park_cap = 0; a.order = nullptr; a.tail = 0; }   // (k_march waits for its place: nothing is parked)
         if (twopass) {
             // the arenas of the two-pass scheme: a surface cell carries at least one triangle, so the soup's capacity
@@ -1546,8 +1567,14 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (h.overflow & MESH_OVERFLOW_TILES) {   // the tile arena was too small: k_cull's cursor says what the call needs
             if (attempt >= 3) return fail("sdf_generate: tile arena overflow persists");
             tiles_cap256 = h.tile_cursor;
-            if (m->tiles.ensure((size_t)tiles_cap256 * 256)) split = false;      // (no room for the arena: k_mesh needs none)
-            if (!(h.overflow & 1u)) { m->st.n_retries = attempt + 1; continue; }   // (same soup buffer)
+            if (m->tiles.ensure((size_t)tiles_cap256 * 256) || m->owner.ensure((size_t)tiles_cap256 * 4)) {
+                split = false;                                                    // (no room for the arena: k_mesh needs none)
+            } else {   // k_cull once more: it hands the places out again (any order) and names the owner of every unit this time
+                HIPCHK(hipMemsetAsync((unsigned char *)m->counters.p + offsetof(MeshCounters, tile_cursor), 0, 8, st));
+                HIPCHK(launch_cull());
+            }
+            m->st.n_retries = attempt + 1;
+            continue;                                                              // (same soup buffer)
         }
         if (h.overflow) {
             if (attempt >= 3) return fail("sdf_generate: soup buffer overflow persists");
@@ -2225,7 +2252,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
         m->out.p = nullptr; m->out.bytes = 0;
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
-    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->order, &m->tiles, &m->desc, &m->cellrecs, &m->trilist, &m->blockidx}) b->release();
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->order, &m->tiles, &m->owner, &m->desc, &m->cellrecs, &m->trilist, &m->blockidx}) b->release();
     (void)hipFree(m->weld_pts); (void)hipFree(m->weld_inv);
     delete m;
     return 0;

@@ -8,6 +8,8 @@
 // lanes diverge: r03's k_expand, written here first in the interpreters' unit, came out wrong for every workgroup that
 // straddled into the last slab (a divergent search loop next to a uniform one), and right without the option.
 // tests/test_gpu.py::test_expand_synthetic_slabs holds that case.
+#include <algorithm>
+
 #include "sdf_device.h"
 #include "sdf_plain.h"
 #include "sdf_slab.h"
@@ -550,9 +552,13 @@ static __device__ __attribute__((noinline)) void march_amb_triangle(const float 
     for (int q = 0; q < 9; q++) dst[q] = oa[q];
 }
 
-__global__ __launch_bounds__(MARCH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+// MODE 0: count, place and emit in one go (the look-back WAITS for predecessors that are still counting: a convoy behind the
+// slowest tile in flight); 1: count only -- sign bits into the arena, the count published; 2: emit only, behind a MODE 1 launch:
+// every count is known, nothing waits, the cells are classified again (cheaper than keeping them)
+template <int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k_march(MeshArgs a) {
-    constexpr int BLOCK = MARCH_BLOCK, RPT = 1024 / BLOCK, CPT = MARCH_CELLS / BLOCK;
+    constexpr int RPT = 1024 / BLOCK, CPT = MARCH_CELLS / BLOCK;
     __shared__ int wave_sums[16];
     __shared__ int bcast[8];
     __shared__ unsigned char ntri_lds[256];                                 // ntri | ambiguous << 7
@@ -571,21 +577,31 @@ void k_march(MeshArgs a) {
     double *const soup = a.out;
     const bool compact = a.compact != 0;
     const Tri16Sink sink{a.out, a.raw, a.raw_cap, &a.ctr->n_raw};
-    ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
+    if (tid < 256) ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
     for (int i = tid; i < 256 * 5; i += BLOCK) {
         const int cfg = i / 5, j = i - 5 * cfg;
         const signed char *t3 = &a.mc->tri[cfg][3 * j];
         tri_lds[i] = (unsigned short)(((unsigned)t3[0] & 15u) | (((unsigned)t3[1] & 15u) << 4) | (((unsigned)t3[2] & 15u) << 8));
     }
     const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
+    const bool have_arena = a.ctr->tile_cursor <= a.tiles_cap256;           // (else: flagged by k_sample, nothing was sampled, the call is repeated)
+    bool first_item = true;
     for (;;) {
-        if (tid == 0) bcast[0] = work_begin + (int)atomicAdd(&a.ctr->march_counter, 1u);
+        // (where nothing ever waits -- MODE 1 / 2 -- a workgroup's FIRST item is its own index: a thousand workgroups drawing from one
+        // counter in the same microsecond queue up at its address; MODE 0 must hand every item to a workgroup that is running)
+        if (tid == 0) {
+            int idx;
+            if (MODE != 0 && first_item) idx = (int)blockIdx.x;
+            else idx = (MODE != 0 ? (int)gridDim.x : 0) + (int)atomicAdd(MODE == 2 ? &a.ctr->emit_counter : &a.ctr->march_counter, 1u);
+            bcast[0] = work_begin + idx;
+        }
+        first_item = false;
         __syncthreads();
         const int w = __builtin_amdgcn_readfirstlane(bcast[0]);
         if (w >= work_end) break;
         // wave 0 asks for the predecessors' status words now: the answer arrives while the cells are counted
         unsigned long long pre = 0;
-        if (tid < 64) pre = lookback_prefetch(a.status, w, work_begin);
+        if (tid < 64 && MODE != 1) pre = lookback_prefetch(a.status, w, work_begin);
         const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
         const int b = __builtin_amdgcn_readfirstlane(a.worklist[w]);
         const unsigned n0 = (unsigned)__builtin_amdgcn_readfirstlane((int)rec[0]) & 0xFFFFu;
@@ -595,12 +611,62 @@ void k_march(MeshArgs a) {
         int ox, oy, oz, lx, ly, lz;
         batch_origin(g, b, ox, oy, oz, lx, ly, lz);
         const int lyz = ly * lz, nvox = lx * lyz, nwords = (nvox + 63) >> 6;
-        const bool have_tile = off256 + (unsigned long long)tile_need256(ntl, nvox) <= a.tiles_cap256;   // (else: flagged by k_sample, the call is repeated)
+        const bool have_tile = have_arena;
         const float *tile = reinterpret_cast<const float *>(a.tiles + off256 * 256ull);
-        const unsigned long long *tile_bits = reinterpret_cast<const unsigned long long *>(a.tiles + off256 * 256ull + tile_data_bytes(ntl, nvox));
-        if (have_tile) {
-            for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = tile_bits[i];
-            if (culled) for (int i = tid; i < 289; i += BLOCK) colinfo[i] = rec[CULL_COLINFO / 4 + i];
+        // ---- the tile's sign-bit volume (value > 0), one word per 64 consecutive samples: the marching phases classify cells from
+        // these bits.  Culled tile: the samples of DECIDED sub-groups get their bits straight from the sub-group states (a row of
+        // lz samples along z = `pos | pos << 1` of its 16 two-bit states, "positive" = 01: k_mesh's sign fill), the evaluated
+        // samples -- 64 per listed task, cull_sample's order -- OR theirs in.  Dense tile: a ballot per word. ----
+        unsigned long long *tile_bits = reinterpret_cast<unsigned long long *>(a.tiles + off256 * 256ull + tile_data_bytes(ntl, nvox));
+        if (MODE == 2) {   // (the counting launch left them in the arena)
+            if (have_tile) {
+                for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = tile_bits[i];
+                if (culled) for (int i = tid; i < 289; i += BLOCK) colinfo[i] = rec[CULL_COLINFO / 4 + i];
+            }
+        } else if (have_tile && culled) {
+            for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;
+            for (int i = tid; i < 289; i += BLOCK) colinfo[i] = rec[CULL_COLINFO / 4 + i];
+            __syncthreads();
+            const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
+            const int hlast = (c2 - 1) >> 1;
+            const unsigned *sstate = rec + CULL_SSTATE / 4;
+            for (int r = tid; r < lx * ly; r += BLOCK) {
+                const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
+                const unsigned st = sstate[(min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)];
+                const unsigned pos = st & ~(st >> 1) & 0x55555555u & (unsigned)((4ull << (2 * hlast)) - 1ull);
+                unsigned long long rowmask = (unsigned long long)(pos | (pos << 1));
+                if ((pos >> (2 * hlast)) & 1u) rowmask |= 1ull << c2;
+                if (rowmask) {
+                    const int o = r * lz, sh = o & 63;
+                    atomicOr(&bits[o >> 6], rowmask << sh);
+                    if (sh && (rowmask >> (64 - sh))) atomicOr(&bits[(o >> 6) + 1], rowmask >> (64 - sh));
+                }
+            }
+            const unsigned short *units = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(rec) + CULL_ULIST);
+            for (int s0 = tid; s0 < 64 * ntl; s0 += BLOCK) {
+                int ix, iy, iz;
+                if (cull_sample(units, s0 >> 6, s0 & 63, lx, ly, lz, ix, iy, iz) && tile[s0] > 0.0f) {
+                    const int i = ix * lyz + iy * lz + iz;
+                    atomicOr(&bits[i >> 6], 1ull << (i & 63));
+                }
+            }
+        } else if (have_tile) {
+            for (int i0 = tid; i0 < 64 * nwords; i0 += BLOCK) {               // (whole waves: a wave owns a word)
+                const unsigned long long mword = __ballot(i0 < nvox && tile[min(i0, nvox - 1)] > 0.0f);
+                if (lane == 0) bits[i0 >> 6] = mword;
+            }
+            if (tid < 2) bits[nwords + tid] = 0ull;                          // the row extraction reads one word ahead
+        }
+        if (MODE == 1 && have_tile) {
+            __syncthreads();
+            for (int i = tid; i < nwords + 2; i += BLOCK) tile_bits[i] = bits[i];
+        }
+        if (tid == 0 && have_tile && MODE != 2) {                             // (statistics k_mesh keeps while it samples)
+            if (a.tape_stride) {
+                const unsigned long long *wc = reinterpret_cast<const unsigned long long *>(a.code_for_stats) + (size_t)b * (size_t)a.tape_stride;
+                atomicAdd(&a.ctr->n_pruned, (unsigned long long)a.n_instr - wc[a.tape_stride - 1]);
+            }
+            atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
         }
         // points * scale + offset (reference sdf/core.py:58-60): offset = the batch's first sample, scale = its first step, per axis
         if (tid < 3) {
@@ -713,26 +779,29 @@ void k_march(MeshArgs a) {
             ncells = rows(row_mask, row_cell0);
             nchunks = (ncells + MARCH_CELLS - 1) / MARCH_CELLS;
             for (int ch = 0; ch < nchunks; ch++) {                          // (uniform)
-                const int sum = classify(ch, ncells, row_mask, row_cell0, cinfo, true);
+                const int sum = classify(ch, ncells, row_mask, row_cell0, cinfo, MODE != 2);
                 int tot;
                 const int excl = block_exclusive_scan<BLOCK>(sum, wave_sums, tot);
                 total += tot;
-                if (nchunks == 1 && tot <= MARCH_LCAP) { write_list(cinfo, excl, 0); listed = true; }   // (made visible by the allocation's barrier)
+                if (MODE != 1 && nchunks == 1 && tot <= MARCH_LCAP) { write_list(cinfo, excl, 0); listed = true; }   // (made visible by the allocation's barrier)
             }
         }
         total = __builtin_amdgcn_readfirstlane(total);
-        // ---- the tile's count is public from here on; bookkeeping that needs no position ----
-        if (tid < 64) publish_count(a.status, w, work_begin, (unsigned long long)total);
-        if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
-            double *xf = a.xf + (size_t)(w - work_begin) * 6;
-            for (int q = 0; q < 6; q++) xf[q] = xf_lds[q];
+        if (MODE != 2) {
+            // ---- the tile's count is public from here on; bookkeeping that needs no position ----
+            if (tid < 64) publish_count(a.status, w, work_begin, (unsigned long long)total);
+            if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
+                double *xf = a.xf + (size_t)(w - work_begin) * 6;
+                for (int q = 0; q < 6; q++) xf[q] = xf_lds[q];
+            }
+            if (tid == 0) {
+                atomicAdd(total ? &a.ctr->n_nonempty : &a.ctr->n_empty, 1u);
+                atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
+                a.kinds[b] = total ? 2 : 1;
+            }
+            if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
         }
-        if (tid == 0) {
-            atomicAdd(total ? &a.ctr->n_nonempty : &a.ctr->n_empty, 1u);
-            atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
-            a.kinds[b] = total ? 2 : 1;
-        }
-        if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
+        if (MODE == 1) continue;                                              // (the loop's top barrier orders this item's LDS reads before the next item's writes)
         // ---- place: the exclusive prefix of the triangle counts over the work list (wave 0; blocking) ----
         if (tid < 64) {
             const unsigned long long excl = ordered_base(a.status, w, work_begin, (unsigned long long)total, MESH_SPIN_FOREVER, pre);
@@ -831,8 +900,19 @@ void k_march(MeshArgs a) {
 }
 
 namespace sdfk {
-int sdf_launch_march(int grid, hipStream_t stream, const MeshArgs &a) {
-    hipLaunchKernelGGL(k_march, dim3(grid), dim3(MARCH_BLOCK), 0, stream, a);
+template <int BLOCK>
+static void launch_march_block(int two, int grid, hipStream_t stream, const MeshArgs &a) {
+    if (two) {
+        hipLaunchKernelGGL((k_march<BLOCK, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((k_march<BLOCK, 2>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    } else hipLaunchKernelGGL((k_march<BLOCK, 0>), dim3(grid), dim3(BLOCK), 0, stream, a);
+}
+int sdf_launch_march(int block, int two, int n_cu, int nb, hipStream_t stream, const MeshArgs &a) {
+    const int per_cu = block == 1024 ? 1 : (block == 512 ? 2 : 4);
+    const int grid = (int)std::min<long long>(nb, (long long)n_cu * per_cu);
+    if (block == 1024) launch_march_block<1024>(two, grid, stream, a);
+    else if (block == 512) launch_march_block<512>(two, grid, stream, a);
+    else launch_march_block<256>(two, grid, stream, a);
     return (int)hipGetLastError();
 }
 }  // namespace sdfk

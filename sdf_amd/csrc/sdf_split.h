@@ -45,117 +45,112 @@ __host__ __device__ __forceinline__ unsigned tile_need256(int ntl, int nvox) {
 }
 
 // ---- k_sample ------------------------------------------------------------------------------------------------
+// FLAT over the arena: a unit of 256 bytes of a tile's sample area is 64 float32 samples -- task t of a culled tile (eight listed
+// units of 2^3 samples, cull_sample's order = TileView's), or samples [64 j, 64 j + 64) of a dense one -- and `owner[u]` (written
+// by k_cull next to the place it hands out) says which work item unit u belongs to (-1: a unit of a tile's sign-bit area).  Every
+// WAVE works on its own: it draws a run of SAMPLE_RUN consecutive units from the counter, takes them NS at a time through the
+// interpreter (two units of the same tile share a pass; a lone one, at a tile boundary, goes alone) and stores unit u's 64 values
+// at arena float 64 u + lane.  No LDS, no barrier, no tile-sized work item: the 512^3 example is ~ 98 k units for 4096 waves,
+// where whole tiles were 1744 items of very different sizes for 1024 workgroups (measured, r05c: 134 us instead of the ~ 50 us
+// the arithmetic needs).  Per-tile bookkeeping (statistics, sign bits) is k_march's.
+enum { SAMPLE_RUN = 8 };
 template <typename T, bool FULL, int NP, int ND, int NS>
 __global__ __launch_bounds__(SPLIT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_sample(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
     typedef Vec<T, NS> V;
-    constexpr int BLOCK = SPLIT_BLOCK, NWAVE = BLOCK / 64;
-    __shared__ int bcast[4];
-    __shared__ double axes[99];                                            // X, Y, Z of the tile (33 each)
-    __shared__ unsigned long long bits[((33 * 33 * 33 + 63) >> 6) + 2];    // the tile's sign bits: value > 0
-    __shared__ unsigned short units[CULL_UNIT_CAP + 8];                    // k_cull's list (u16 each, whole tasks)
-    __shared__ unsigned sstate[256];                                       // its sub-group states, two bits each
-    int tid = threadIdx.x;
+    static_assert(NS == 1 || NS == 2, "units go through the interpreter one or two at a time");
+    const int lane = threadIdx.x & 63;
     const GridDesc g = a.g;
-    const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
-    if (tid == 0) {   // the pass's start on the device's own clock (sdf_stats.ms_mesh_device, sclk_mhz)
+    // (pointers that come out of the by-value argument block are generic to the compiler: said to be global here, so that the
+    // loop's loads and stores are global_* instructions, which do not count against the scalar loads' lgkmcnt)
+    typedef __attribute__((address_space(1))) const unsigned char gcuchar;
+    typedef __attribute__((address_space(1))) const int gcint;
+    typedef __attribute__((address_space(1))) const double gcdouble;
+    typedef __attribute__((address_space(1))) float gfloat;
+    gcuchar *const cull = (gcuchar *)a.cull;
+    gcint *const worklist = (gcint *)a.worklist, *const owner = (gcint *)a.owner;
+    gfloat *const arena = (gfloat *)a.tiles;
+    gcdouble *const gX = (gcdouble *)a.g.X, *const gY = (gcdouble *)a.g.Y, *const gZ = (gcdouble *)a.g.Z;
+    const int tape_stride = a.tape_stride;
+    MeshCounters *const ctr = a.ctr;
+    if (threadIdx.x == 0) {   // the pass's start on the device's own clock (sdf_stats.ms_mesh_device, sclk_mhz)
         const unsigned long long tw = wall_clock64();
-        atomicMax(&a.ctr->t_first_inv, ~tw);
-        if (blockIdx.x == 0) { a.ctr->clk_cycles = (unsigned long long)clock64(); a.ctr->clk_ticks = tw; }
+        atomicMax(&ctr->t_first_inv, ~tw);
+        if (blockIdx.x == 0) { ctr->clk_cycles = (unsigned long long)clock64(); ctr->clk_ticks = tw; }
     }
-    for (;;) {
-        if (tid == 0) bcast[0] = work_begin + (int)atomicAdd(&a.ctr->work_counter, 1u);
-        __syncthreads();
-        const int w = uni(bcast[0]);
-        if (w >= work_end) break;
-        const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
-        const int b = uni(a.worklist[w]);
-        const unsigned n0 = (unsigned)uni((int)rec[0]) & 0xFFFFu;
-        const unsigned long long off256 = (unsigned long long)(unsigned)uni((int)rec[1]);
-        const bool culled = n0 != 0xFFFFu;
-        const int ntl_cull = culled ? (int)((n0 + 7u) >> 3) : -1;
-        int ox, oy, oz, lx, ly, lz;
-        batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-        const TileTasks tt(lx, ly, lz);
-        const int nvox = tt.nvox, lyz = tt.lyz;
-        const int nwords = (nvox + 63) >> 6;
-        // (an arena that is too small: flagged, the host repeats the call through k_mesh; k_march skips the item alike)
-        if (off256 + (unsigned long long)tile_need256(ntl_cull, nvox) > a.tiles_cap256) {   // (uniform)
-            if (tid == 0) atomicOr(&a.ctr->overflow, (unsigned)MESH_OVERFLOW_TILES);
-            __syncthreads();   // (bcast is rewritten at the top)
-            continue;
-        }
-        float *tile = reinterpret_cast<float *>(a.tiles + off256 * 256ull);
-        unsigned long long *tile_bits = reinterpret_cast<unsigned long long *>(a.tiles + off256 * 256ull + tile_data_bytes(ntl_cull, nvox));
-        if (culled) {
-            const int nw_units = (16 * ntl_cull + 3) >> 2;                              // words of the unit list
-            for (int i = tid; i < nw_units; i += BLOCK) reinterpret_cast<unsigned *>(units)[i] = rec[CULL_ULIST / 4 + i];
-            sstate[tid] = rec[CULL_SSTATE / 4 + tid];
-        }
-        if (tid < lx) axes[tid] = g.X[ox + tid];
-        else if (tid >= 64 && tid < 64 + ly) axes[33 + tid - 64] = g.Y[oy + tid - 64];
-        else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
-        for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;
-        __syncthreads();
-        const uint32_t *wcode = code + (size_t)b * (size_t)a.tape_stride * 2;
-        if (tid == 0) {
-            if (a.tape_stride)
-                atomicAdd(&a.ctr->n_pruned, (unsigned long long)a.n_instr - reinterpret_cast<const unsigned long long *>(wcode)[a.tape_stride - 1]);
-            atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl_cull * 64ull : (unsigned long long)nvox);
-        }
-        const int wave = tid >> 6, lane = tid & 63;
-        int ntl = tt.ntask;
-        if (culled) {
-            ntl = ntl_cull;
-            // the sign bits of the samples of DECIDED sub-groups, straight from their states (k_mesh's sign fill: a row of lz
-            // samples along z = `pos | pos << 1` of its 16 two-bit states; "positive" = 01); evaluated samples OR theirs in below
-            const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
-            const int hlast = (c2 - 1) >> 1;
-            for (int r = tid; c0 > 0 && c1 > 0 && c2 > 0 && r < lx * ly; r += BLOCK) {
-                const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
-                const unsigned st = sstate[(min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)];
-                const unsigned pos = st & ~(st >> 1) & 0x55555555u & (unsigned)((4ull << (2 * hlast)) - 1ull);
-                unsigned long long rowmask = (unsigned long long)(pos | (pos << 1));
-                if ((pos >> (2 * hlast)) & 1u) rowmask |= 1ull << c2;
-                if (rowmask) {
-                    const int o = r * lz, sh = o & 63;
-                    atomicOr(&bits[o >> 6], rowmask << sh);
-                    if (sh && (rowmask >> (64 - sh))) atomicOr(&bits[(o >> 6) + 1], rowmask >> (64 - sh));
-                }
+    const unsigned long long n_units = ctr->tile_cursor;
+    if (n_units > a.tiles_cap256) {   // (uniform) the arena is too small: flagged, the host repeats the call with the size k_cull reported
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&ctr->overflow, (unsigned)MESH_OVERFLOW_TILES);
+        return;
+    }
+    // the tile in hand (uniform; reloaded when a unit of another work item comes up)
+    int cur_w = -1, ox = 0, oy = 0, oz = 0, lx = 1, ly = 1, lz = 1, lyz = 1, nvox = 0;
+    unsigned long long cur_off = 0;
+    bool culled = false;
+    float inv_lyz = 1.0f, inv_lz = 1.0f;
+    typedef __attribute__((address_space(1))) const unsigned short gcushort;
+    gcushort *units = nullptr;
+    int cur_b = 0;
+    // (runs are dealt out STATICALLY, wave by wave: a work counter in device memory was drawn from by 4096 waves at once and the
+    // atomics, serialised at one address behind eight L2s, were most of the kernel -- r05d: 253 us, 87 % of the wave cycles waiting)
+    const unsigned n_waves = gridDim.x * (SPLIT_BLOCK / 64), wave_id = blockIdx.x * (SPLIT_BLOCK / 64) + (threadIdx.x >> 6);
+    for (unsigned long long run = wave_id;; run += n_waves) {
+        const unsigned long long u0 = run * SAMPLE_RUN;
+        if (u0 >= n_units) break;
+        const int own = (lane < SAMPLE_RUN && u0 + (unsigned long long)lane < n_units) ? owner[u0 + lane] : -1;
+        for (int p_ = 0; p_ < SAMPLE_RUN;) {                                  // (uniform; said so explicitly: the values below feed scalar loads)
+            const int p = __builtin_amdgcn_readfirstlane(p_);
+            const int w = __builtin_amdgcn_readlane(own, p);
+            if (w < 0) { p_ = p + 1; continue; }
+            const bool pair = NS == 2 && p + 1 < SAMPLE_RUN && __builtin_amdgcn_readlane(own, min(p + 1, SAMPLE_RUN - 1)) == w;
+            if (w != cur_w) {
+                cur_w = w;
+                typedef __attribute__((address_space(1))) const unsigned gcunsigned;
+                gcunsigned *rec = (gcunsigned *)(cull + (size_t)w * CULL_RECORD);
+                const int b = __builtin_amdgcn_readfirstlane(worklist[w]);
+                const unsigned n0 = (unsigned)__builtin_amdgcn_readfirstlane((int)rec[0]) & 0xFFFFu;
+                cur_off = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)rec[1]);
+                culled = n0 != 0xFFFFu;
+                batch_origin(g, b, ox, oy, oz, lx, ly, lz);
+                lyz = ly * lz; nvox = lx * lyz;
+                inv_lyz = 1.0f / (float)lyz; inv_lz = 1.0f / (float)lz;
+                units = (gcushort *)((gcuchar *)rec + CULL_ULIST);
+                cur_b = b;
             }
-        }
-        // the listed tasks (every task of a tile that is not culled): NS per wave and pass through the interpreter, cast to
-        // float32 like skimage's volume cast; sample `lane` of task t of a culled tile goes to tile[64 t + lane]
-        for (int t0 = wave * NS; t0 < ntl; t0 += NWAVE * NS) {
+            // (the tile's state is uniform by construction; the compiler cannot see that through the loop)
+            ox = uni(ox); oy = uni(oy); oz = uni(oz); lx = uni(lx); ly = uni(ly); lz = uni(lz); lyz = uni(lyz); nvox = uni(nvox);
+            cur_off = uni64(cur_off);
+            units = (gcushort *)uni64((unsigned long long)units);
+            // (`code` stays the base of the tape's address: the interpreter's instruction fetches are scalar loads from a kernel argument)
+            const uint32_t *wc = code + (size_t)__builtin_amdgcn_readfirstlane(cur_b) * (size_t)tape_stride * 2;
             V px, py, pz;
+            bool valid[NS];
             SDF_UNROLL
             for (int k = 0; k < NS; k++) {
-                const int tk = min(t0 + k, ntl - 1);
+                const int t = (int)(u0 + (unsigned long long)(p + (pair ? k : 0)) - cur_off);   // the unit within its tile (a lone unit fills both slots)
                 int ix, iy, iz;
-                if (culled) cull_sample(units, tk, lane, lx, ly, lz, ix, iy, iz); else tt.sample(tk, lane, ix, iy, iz);
-                px.v[k] = (T)axes[ix]; py.v[k] = (T)axes[33 + iy]; pz.v[k] = (T)axes[66 + iz];
-            }
-            const V val = run_tape<T, FULL, NP, ND, NS>(wcode, consts, px, py, pz);
-            SDF_UNROLL
-            for (int k = 0; k < NS; k++) {   // (the sample index is worked out again rather than kept across the interpreter)
-                int ix, iy, iz;
-                const bool valid = t0 + k < ntl && (culled ? cull_sample(units, t0 + k, lane, lx, ly, lz, ix, iy, iz) : tt.sample(t0 + k, lane, ix, iy, iz));
-                if (valid) {
-                    const int i = ix * lyz + iy * tt.lz + iz;
-                    const float fv = (float)val.v[k];
-                    tile[culled ? 64 * (t0 + k) + lane : i] = fv;
-                    if (fv > 0.0f) atomicOr(&bits[i >> 6], 1ull << (i & 63));
+                if (culled) {   // (cull_sample, on the record in device memory)
+                    const unsigned u = units[8 * t + (lane >> 3)];
+                    const int x = (int)((u >> 9) & 62u) + ((lane >> 2) & 1), y = (int)((u >> 4) & 62u) + ((lane >> 1) & 1), z = (int)((u << 1) & 62u) + (lane & 1);
+                    valid[k] = x < lx && y < ly && z < lz;
+                    ix = valid[k] ? x : 0; iy = valid[k] ? y : 0; iz = valid[k] ? z : 0;
+                } else {
+                    const int i = min(64 * t + lane, nvox - 1);
+                    valid[k] = 64 * t + lane < nvox;
+                    ix = fast_div(i, inv_lyz); const int r = i - ix * lyz; iy = fast_div(r, inv_lz); iz = r - iy * lz;
                 }
+                px.v[k] = (T)gX[ox + ix]; py.v[k] = (T)gY[oy + iy]; pz.v[k] = (T)gZ[oz + iz];
             }
+            const V val = run_tape<T, FULL, NP, ND, NS>(wc, consts, px, py, pz);
+            SDF_UNROLL
+            for (int k = 0; k < NS; k++)
+                if (valid[k] && (k == 0 || pair)) arena[(u0 + (unsigned long long)(p + k)) * 64ull + (unsigned long long)lane] = (float)val.v[k];
+            p_ = p + (pair ? 2 : 1);
         }
-        __syncthreads();
-        for (int i = tid; i < nwords + 2; i += BLOCK) tile_bits[i] = bits[i];
-        // (no barrier here: the next round's writes to LDS come behind the barrier at its top, which every thread reaches
-        // only after its share of this copy)
     }
-    if (tid == 0 && blockIdx.x == 0) {
-        a.ctr->clk_cycles = (unsigned long long)clock64() - a.ctr->clk_cycles;
-        a.ctr->clk_ticks = wall_clock64() - a.ctr->clk_ticks;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctr->clk_cycles = (unsigned long long)clock64() - ctr->clk_cycles;
+        ctr->clk_ticks = wall_clock64() - ctr->clk_ticks;
     }
 }
 
@@ -166,7 +161,9 @@ SDF_DECLARE_SAMPLE_LAUNCH(sdf_launch_sample_f64);
 SDF_DECLARE_SAMPLE_LAUNCH(sdf_launch_sample_f64_full);
 
 // k_march (sdf_plain.hip): LDS per workgroup decides how many share a compute unit
-enum { MARCH_BLOCK = 256, MARCH_LCAP = 3072, MARCH_CELLS = 2048, MARCH_WG_PER_CU = 4 };
-int sdf_launch_march(int grid, hipStream_t stream, const MeshArgs &a);
+enum { MARCH_LCAP = 3072, MARCH_CELLS = 2048 };
+// block: 256 (four workgroups per compute unit), 512 (two) or 1024 (one) threads -- grid = that many per compute unit
+// two: the counting and the emitting as launches of their own (nothing waits) instead of one launch whose look-back waits
+int sdf_launch_march(int block, int two, int n_cu, int nb, hipStream_t stream, const MeshArgs &a);
 
 }  // namespace sdfk

@@ -322,11 +322,11 @@ def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=No
         cap_items = -(-nb // (world * C)) + 1
         # (triangles: a guess, 4096 per batch of the shard -- 2.4 x what the surviving batches of the BASELINE models
         # produce, and most batches do not survive -- within 8 GB for gathered slabs plus the expanded soup (72 B)
-        # together (budgeted at the 36 B a record took until r04n; it takes 16); a slab that is too small is flagged in its header, the headers carry the exact need, and the step is
+        # together (a triangle of a slab is a 16-byte record plus 1/128 of a 36-byte raw entry: 89 B with the soup's 72); a slab that is too small is flagged in its header, the headers carry the exact need, and the step is
         # repeated once with that.  The capacities size the collective: nothing rank-local -- free memory, say -- may
         # enter the formula, every rank must arrive at the same numbers)
         budget = 8 << 30
-        cap_tris = max(min(4096 * cap_items, budget // (108 * world * C)), 1 << 16)
+        cap_tris = max(min(4096 * cap_items, budget // (89 * world * C)), 1 << 16)
         total_hint = 0
 
     st = ShardedStep()
