@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 7
+#define SDF_ABI_VERSION 6
 
 #define SDF_PRECISION_F64 0 /* parity mode: float64 sampling like the reference's NumPy path */
 #define SDF_PRECISION_F32 1 /* fast mode: float32 sampling */
@@ -88,13 +88,6 @@ int sdf_ctx_set_cull(sdf_ctx *ctx, int enabled);
  * (sample + classify / number the triangles / emit), -1 = the library's choice by the tape's length (default; the
  * environment variable SDF_MESH_TWOPASS sets the initial state).  Results are identical either way. */
 int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
-/* Split meshing (round 5): the meshing pass as TWO kernels of small workgroups, several per compute unit -- k_sample
- * (`volume = sdf(P)`, reference sdf/core.py:50-52: the tape interpreter, the sampled tiles go to an arena in device memory)
- * and k_march (`_marching_cubes` + `points * scale + offset`, core.py:54-60: ordered by the same look-back) -- instead of
- * the one kernel that holds a compute unit with one workgroup and does a batch's phases in turn.  1 = wherever the
- * interval pass k_cull ran (float64, monotone axes), 0 = never, -1 = the library's choice by the tape (default; the
- * environment variable SDF_MESH_SPLIT sets the initial state).  Results are identical either way. */
-int sdf_ctx_set_split(sdf_ctx *ctx, int mode);
 /* Inside the one-kernel scheme: 1 (default; SDF_DEFER sets the initial state) = a culled batch keeps only the samples the
  * interval pass listed (a sparse tile) and STAYS in the CU's LDS while the workgroup samples its next batch, so that its
  * triangles are written once, in their final place, when the earlier batches' counts are known; 0 = dense tiles, a
@@ -173,9 +166,15 @@ int sdf_marching_cubes_host(sdf_ctx *ctx, const float *h_volume, int n0, int n1,
 
 /* The batch loop of `generate` (reference sdf/core.py:114-141) with `_worker` (:45-60) and
  * `_skip` (:28-43) inside: X, Y, Z are the float64 `np.arange` axes (host), batch_size the
- * reference's BATCH_SIZE (<= 32), sparse its `sparse=` flag.  shard_index/shard_count split the
- * surviving-batch work list into contiguous chunks (1 GPU: 0, 1).  The triangles stay on the
- * device in the returned mesh until emitted. */
+ * reference's BATCH_SIZE (1 .. 512; the reference takes any, core.py:87, 114-119), sparse its
+ * `sparse=` flag.  shard_index/shard_count split the surviving-batch work list into contiguous
+ * chunks (1 GPU: 0, 1).  The triangles stay on the device in the returned mesh until emitted.
+ * batch_size <= 32 (the default: 32) runs the fused LDS-resident kernels; a larger batch's
+ * (batch_size + 1)^3 float32 tile does not fit a compute unit's LDS and goes through device
+ * memory, a chunk of batches per submission, synchronously, into library memory: the variants
+ * below that take a caller buffer then report it as not filled (*emitted = 0), exactly as for a
+ * buffer that is too small; sdf_generate_compact_async / sdf_generate_from_kinds (the multi-GPU
+ * exchange) refuse batch_size > 32. */
 int sdf_generate(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
                  int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,
                  sdf_mesh **out);

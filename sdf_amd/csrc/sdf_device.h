@@ -56,16 +56,11 @@ struct MeshCounters {   // zeroed before every k_mesh run
     // the kernel actually ran at)
     unsigned long long t_first_inv, t_last, clk_cycles, clk_ticks;
     unsigned long long n_raw;         // compact output: triangles that went to the slab's raw area (sdf_slab.h)
-    unsigned int march_counter;       // split meshing (sdf_split.h): the work counter of k_march (work_counter is k_sample's)
-    unsigned int emit_counter;        // ... and of its emitting launch when counting and emitting are launches of their own
     // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
     // and this shard's slice of it, so k_mesh can start without a host round trip
     int nwork, work_begin, work_end, pad_;
-    // written by k_cull (NOT cleared between meshing retries): bytes / 256 of the tile arena handed out so far (split meshing,
-    // sdf_split.h: every work item's sampled tile gets a place there; the place is word 1 of the item's record)
-    unsigned long long tile_cursor;
 };
-enum { MESH_COUNTERS_RESET_BYTES = 120 };   // the part of MeshCounters cleared before every k_mesh run
+enum { MESH_COUNTERS_RESET_BYTES = 112 };   // the part of MeshCounters cleared before every k_mesh run
 
 struct GridDesc {
     const double *X, *Y, *Z;   // device copies of the np.arange axes
@@ -123,12 +118,6 @@ struct MeshArgs {
     // items do (see k_mesh).
     const int *order;
     int tail;
-    // split meshing (sdf_split.h: k_sample + k_march instead of k_mesh): the arena of sampled tiles, its size in units of
-    // 256 bytes; a work item's place is word 1 of its k_cull record
-    unsigned char *tiles;
-    unsigned long long tiles_cap256;
-    const void *code_for_stats;    // the tapes k_sample runs (k_march reads a pruned tape's length for the statistics)
-    const int *owner;              // per 256-byte unit of the arena: the work item whose samples it holds, -1 = a unit of sign bits (k_cull)
 };
 enum { MESH_TAIL_MAX = 255 };
 

@@ -36,7 +36,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -47,7 +46,6 @@
 #include "sdf_prune.h"
 #include "sdf_slab.h"
 #include "sdf_plain.h"
-#include "sdf_split.h"
 
 using namespace sdfk;
 
@@ -252,10 +250,10 @@ __global__ __launch_bounds__(PRUNE_BLOCK) void k_prune_list(const uint32_t *__re
 #define CULL_BLOCK 256
 template <bool FULL, bool RARE, int CB = CULL_BLOCK>
 __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
-                                                     const int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
+                                                     const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned char *cull_smem, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max, int levels, int *__restrict__ owner, unsigned long long owner_cap) {
+                                                     int *__restrict__ order, int tail_max, int levels) {
     int *wave_sums = reinterpret_cast<int *>(cull_smem);                       // 64 B
     double *axes = reinterpret_cast<double *>(cull_smem + 64);                 // 3 * 33 doubles
     unsigned char *scratch = cull_smem + 896;                                  // CULL_SCRATCH bytes
@@ -293,26 +291,12 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     if (prof) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart1) : "s"(n_instr_w) : "memory");
     const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd, prof, levels);
     const long long tw = prof ? clock64() : 0;
-    if (tid == 0) {
-        if (ntl < 0) reinterpret_cast<unsigned short *>(scratch)[0] = (unsigned short)0xFFFF;   // (else: the number of listed units, cull_tasks)
-        // the work item's place in the arena of sampled tiles (split meshing, sdf_split.h: k_sample writes the tile there,
-        // k_march reads it), in units of 256 bytes: word 1 of the record.  Handed out in the order the workgroups get here --
-        // any order will do; the cursor's final value is what the call needed (the host sizes the next call's arena by it)
-        reinterpret_cast<unsigned *>(scratch)[1] =
-            (unsigned)min(atomicAdd(&ctr->tile_cursor, (unsigned long long)tile_need256(ntl, lx * ly * lz)), 0xFFFFFFFFull);
-    }
+    if (tid == 0 && ntl < 0) reinterpret_cast<unsigned short *>(scratch)[0] = (unsigned short)0xFFFF;   // (else: the number of listed units, cull_tasks)
     __syncthreads();
-    if (owner) {   // (uniform) split meshing: whose samples each 256-byte unit of the tile's place holds (k_sample goes by units)
-        const unsigned long long off = reinterpret_cast<const unsigned *>(scratch)[1];
-        const int nvox = lx * ly * lz;
-        const unsigned need = tile_need256(ntl, nvox), data_units = (tile_data_bytes(ntl, nvox) + 255u) >> 8;
-        for (unsigned i = tid; i < need; i += CB)
-            if (off + i < owner_cap) owner[off + i] = i < data_units ? w : -1;
-    }
     {   // the record: header + the listed units (whole tasks), and the sub-group states
         unsigned *rec = reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD);
         const unsigned *src = reinterpret_cast<const unsigned *>(scratch);
-        const int nwords = ntl < 0 ? 2 : (CULL_ULIST + 16 * ntl + 3) >> 2;
+        const int nwords = ntl < 0 ? 1 : (CULL_ULIST + 16 * ntl + 3) >> 2;
         for (int i = tid; i < nwords; i += CB) rec[i] = src[i];
         if (ntl >= 0) for (int i = tid; i < (CULL_RECORD - CULL_SSTATE) / 4; i += CB) rec[CULL_SSTATE / 4 + i] = src[CULL_SSTATE / 4 + i];   // sub-group states + column words
     }
@@ -338,32 +322,32 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
 
 template <bool FULL, bool RARE, int CB = CULL_BLOCK>
 __global__ __launch_bounds__(CB) void k_cull(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
-                                                     const int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
+                                                     const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max, int levels, int *__restrict__ owner, unsigned long long owner_cap) {
+                                                     int *__restrict__ order, int tail_max, int levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<FULL, RARE, CB>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels, owner, owner_cap);
+    cull_body<FULL, RARE, CB>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
 }
 // the variant for tapes without trigonometry and without the rarer leaves: 70 VGPRs without spilling, seven waves per
 // SIMD (the others take 99 - 104; holding them to five or six waves was measured in r02p: no faster)
 __global__ __launch_bounds__(CULL_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
-                                                     const int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
+                                                     const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max, int levels, int *__restrict__ owner, unsigned long long owner_cap) {
+                                                     int *__restrict__ order, int tail_max, int levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels, owner, owner_cap);
+    cull_body<false, false>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
 }
 // (experiment: the same with two waves per workgroup -- twelve workgroups fit a CU, every work item of the 512^3
 // example is resident at once instead of in two rounds)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_cull_lean128(const uint32_t *__restrict__ code, const double *__restrict__ consts, GridDesc g,
-                                                     const int *__restrict__ worklist, MeshCounters *__restrict__ ctr,
+                                                     const int *__restrict__ worklist, const MeshCounters *__restrict__ ctr,
                                                      int tape_stride, int n_instr, int ia_np, int ia_nd, int ia_bytes,
                                                      unsigned char *__restrict__ out, unsigned long long *prof,
-                                                     int *__restrict__ order, int tail_max, int levels, int *__restrict__ owner, unsigned long long owner_cap) {
+                                                     int *__restrict__ order, int tail_max, int levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cull_smem[];
-    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels, owner, owner_cap);
+    cull_body<false, false, 128>(code, consts, g, worklist, ctr, tape_stride, n_instr, ia_np, ia_nd, ia_bytes, out, cull_smem, prof, order, tail_max, levels);
 }
 
 // (every kernel that is not a tape interpreter -- the compaction, marching cubes of caller-supplied volumes, the two-pass
@@ -544,10 +528,6 @@ struct sdf_ctx {
     int tail_order = 1;               // SDF_TAIL_ORDER=0: k_mesh takes the whole work list in order
     int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
     int defer = 1;                    // SDF_DEFER=0: k_mesh keeps every tile dense and writes (or parks) a batch's triangles right after counting it
-    unsigned long long tiles_first_cap256 = (1ull << 30) >> 8;   // SDF_TILES_FIRST_CAP256: the tile arena of a tape's FIRST call on a grid (tests force the too-small path)
-    int march_two = 1;                // SDF_MARCH_TWO=0: k_march counts, places and emits in ONE launch (its look-back then waits for tiles still being counted)
-    int march_block = 256;            // SDF_MARCH_BLOCK=256 / 512 / 1024: threads per workgroup of k_march (tuning)
-    int split = -1;                   // SDF_MESH_SPLIT: the meshing pass as k_sample + k_march (sdf_split.h): -1 by the tape, 0 never (k_mesh), 1 wherever k_cull runs
     int cull_levels = 0;              // SDF_CULL_LEVELS=2 / 3: interval levels of k_cull (3: + sub-groups of 2^3 cells); 0: by the tape (see generate_impl)
 };
 
@@ -564,7 +544,6 @@ struct sdf_tape {
     bool ia_rare = false;                                // ... one of them a leaf of ia_leaf_rare (the k_cull variant that knows them)
     uint32_t n_extern = 0;                               // user closures the tape reads through L_EXTERN leaves (sdf_eval_points_extern_*)
     unsigned long long hint_key = 0, hint_total_tris = 0;   // arena sizing: last call of this tape
-    unsigned long long hint_tiles256 = 0;                   // ... and what k_cull handed out of the tile arena then (units of 256 bytes; split meshing)
     unsigned long long content_hash = 0;                    // FNV-1a of the code words and the constants' bits: what identifies the MODEL,
                                                             // on every rank alike and whatever address the tape object lands on (sdf_comm.inc)
 };
@@ -574,7 +553,6 @@ struct sdf_mesh {
     sdf_stats st = {};
     GridDesc g = {};
     DevBuf axes, kinds, worklist, status, out, prune, tapes, cull, order;
-    DevBuf tiles, owner;              // split meshing (sdf_split.h): the arena of sampled tiles (k_sample -> k_march), the work item of each of its 256-byte units
     DevBuf desc, cellrecs, trilist;   // two-pass meshing: per work item / per surface cell / per triangle (sdf_device.h ItemDesc)
     DevBuf blockidx;                  // ... and per 256 triangles of the soup: the work item of the first of them
     bool pruned = false;
@@ -720,10 +698,6 @@ static int ctx_init(sdf_ctx *c) {
     if (const char *e = getenv("SDF_PRUNE_LIST_MIN")) c->prune_list_min = std::max(atoi(e), 0);
     if (const char *e = getenv("SDF_CULL")) c->cull = atoi(e);
     if (const char *e = getenv("SDF_DEFER")) c->defer = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("SDF_MESH_SPLIT")) c->split = atoi(e) < 0 ? -1 : (atoi(e) ? 1 : 0);
-    if (const char *e = getenv("SDF_MARCH_TWO")) c->march_two = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("SDF_MARCH_BLOCK")) { const int v = atoi(e); c->march_block = v == 512 || v == 1024 ? v : 256; }
-    if (const char *e = getenv("SDF_TILES_FIRST_CAP256")) c->tiles_first_cap256 = std::max<long long>(atoll(e), 1);
     if (const char *e = getenv("SDF_CULL_LEVELS")) c->cull_levels = atoi(e);
     if (const char *e = getenv("SDF_PARK_SPINS")) c->park_spins = std::max(atoi(e), 1);
     if (const char *e = getenv("SDF_MESH_PROF")) { if (atoi(e) && c->prof.ensure(512 + 4096 * 32)) return 1; }
@@ -765,12 +739,6 @@ int sdf_ctx_set_prune(sdf_ctx *c, int enabled) {
 int sdf_ctx_set_cull(sdf_ctx *c, int enabled) {
     if (!c) return fail("sdf_ctx_set_cull: ctx is NULL");
     c->cull = enabled ? 1 : 0;
-    return 0;
-}
-
-int sdf_ctx_set_split(sdf_ctx *c, int mode) {
-    if (!c) return fail("sdf_ctx_set_split: ctx is NULL");
-    c->split = mode < 0 ? -1 : (mode ? 1 : 0);
     return 0;
 }
 
@@ -1132,25 +1100,6 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     return 0;
 }
 
-// split meshing (sdf_split.h): k_sample (four workgroups of 256 threads per compute unit -- the interpreter's registers -- whose
-// waves each work on their own) and, behind it on the stream, k_march (workgroups of 256 / 512 / 1024 threads: four / two / one per
-// compute unit); both persistent, surplus workgroups leave at once
-static int launch_split(sdf_tape *t, const void *code, MeshArgs &a, int nb, hipStream_t st) {
-    sdf_ctx *c = t->ctx;
-    a.bits_off = a.list_off = a.list_cap = 0; a.slot_bytes = 0; a.stage_off = 0; a.twopass = 0;
-    static const uint32_t kFile[6][2] = {{1, 1}, {2, 2}, {4, 2}, {2, 4}, {4, 4}, {8, 8}};
-    const uint32_t np = std::max(t->n_p, 1u), nd = std::max(t->n_d, 1u);
-    int slots = 5;
-    for (int k = 5; k >= 0; k--) if (np <= kFile[k][0] && nd <= kFile[k][1]) slots = k;
-    if (c->mesh_slots >= 0 && c->mesh_slots <= 5 && np <= kFile[c->mesh_slots][0] && nd <= kFile[c->mesh_slots][1]) slots = c->mesh_slots;
-    int rc = t->full ? sdf_launch_sample_f64_full(slots, c->n_cu * 4, st, (const uint32_t *)code, t->d_c64, a)
-                     : sdf_launch_sample_f64(slots, c->n_cu * 4, st, (const uint32_t *)code, t->d_c64, a);
-    if (rc) return fail(std::string("k_sample launch: ") + hipGetErrorString((hipError_t)rc));
-    rc = sdf_launch_march(c->march_block, c->march_two, c->n_cu, nb, st, a);
-    if (rc) return fail(std::string("k_march launch: ") + hipGetErrorString((hipError_t)rc));
-    return 0;
-}
-
 // the skip test (`_skip`, reference sdf/core.py:28-43) of batches [b0, b1) alone, enqueued on `st`: d_kinds[b] = 0 (skipped) or
 // 255 (pending) for those batches; the axes are on the device already (X, then Y, then Z)
 static int enqueue_skip(sdf_tape *t, const double *d_axes, int nx, int ny, int nz, int bs, int b0, int b1, int precision,
@@ -1190,7 +1139,6 @@ static void finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb
     m->pruned = pruning;
     m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
-    t->hint_tiles256 = h.tile_cursor;
     m->st.ms_prepass = ms_prepass;
     m->st.ms_total = ms_total;
 }
@@ -1339,28 +1287,6 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     const unsigned long long key = ((unsigned long long)nx << 42) ^ ((unsigned long long)ny << 21) ^ (unsigned long long)nz ^
                                    ((unsigned long long)shard_index << 56) ^ ((unsigned long long)shard_count << 48) ^
                                    ((unsigned long long)bs << 36) ^ (sparse ? 1ull << 63 : 0ull);
-    // One kernel or two?  Wherever k_cull runs, the meshing pass can go as k_sample + k_march (sdf_split.h): small workgroups, many
-    // per compute unit, the sampled tiles through an arena in device memory -- instead of k_mesh's one workgroup per compute
-    // unit that does everything in turn.  Same soup, bit for bit.  Not with the phase counters (k_mesh's), not where the caller
-    // asked for the dense-tile scheme.
-    // (an explicit choice of the one-kernel or the two-pass scheme -- sdf_ctx_set_twopass 0 / 1 -- stands unless split meshing was
-    // asked for explicitly as well)
-    const bool twopass_sel = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
-    bool split = culling && !c->prof.p && c->defer && nb < (1 << 30) && (c->split == 1 || (c->split < 0 && c->twopass < 0 && !twopass_sel));
-    bool fresh_buffers = false;     // an allocation below made the stream idle (the kernels' event times then start behind it)
-    unsigned long long tiles_cap256 = 0;
-    if (split) {
-        // the arena: what k_cull handed out the last time this tape ran on this grid (+ a margin: the order of the atomic
-        // additions does not change the sum, the tape's pruning does not change k_cull's lists -- the need is a function of
-        // tape and grid), else every batch as a dense tile, capped at 1 GB; a call that needs more is flagged and repeated
-        // with what k_cull reported.  `owner`: a word per 256-byte unit of the arena (k_cull -> k_sample)
-        const unsigned long long worst = (unsigned long long)nb * tile_need256(-1, (int)mesh_nvox);
-        tiles_cap256 = (t->hint_key == key && t->hint_tiles256) ? t->hint_tiles256 + t->hint_tiles256 / 16 + 64 : std::min<unsigned long long>(worst, c->tiles_first_cap256);
-        tiles_cap256 = std::min(tiles_cap256, worst);
-        if (m->tiles.bytes < (size_t)tiles_cap256 * 256 || m->owner.bytes < (size_t)tiles_cap256 * 4) fresh_buffers = true;
-        if (m->tiles.ensure((size_t)tiles_cap256 * 256) || m->owner.ensure((size_t)tiles_cap256 * 4)) return 1;
-    }
-    std::function<hipError_t()> launch_cull;      // (k_cull again: a tile arena that was too small, below)
     if (culling) {
         if (c->prof.p) HIPCHK(hipMemsetAsync((unsigned char *)c->prof.p + 128, 0, 384, st));
         if (m->cull.ensure((size_t)nb * CULL_RECORD) || (tail_order && m->order.ensure(MESH_TAIL_MAX * sizeof(int)))) return 1;
@@ -1390,16 +1316,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const size_t ia_bytes = std::min<size_t>((size_t)cull_block * (6 * ia_np + 2 * ia_nd) * 8, c->lds_max - 896 - CULL_SCRATCH);
         const size_t lds = 896 + CULL_SCRATCH + ia_bytes;
         if (lds > 32768) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        launch_cull = [=]() {
-            hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
-                               pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
-                               (const int *)m->worklist.p, (MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
-                               ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p, (unsigned long long *)c->prof.p,
-                               tail_order ? (int *)m->order.p : (int *)nullptr, tail_max, cull_levels,
-                               split ? (int *)m->owner.p : (int *)nullptr, (unsigned long long)(m->owner.bytes / 4));
-            return hipGetLastError();
-        };
-        HIPCHK(launch_cull());
+        hipLaunchKernelGGL(kc, dim3(nb), dim3(cull_block), lds, st,
+                           pruning ? (const uint32_t *)m->tapes.p : (const uint32_t *)t->d_code, (const double *)t->d_c64, g,
+                           (const int *)m->worklist.p, (const MeshCounters *)m->counters.p, pruning ? tape_stride : 0, (int)n_instr,
+                           ia_np, ia_nd, (int)ia_bytes, (unsigned char *)m->cull.p, (unsigned long long *)c->prof.p,
+                           tail_order ? (int *)m->order.p : (int *)nullptr, tail_max, cull_levels);
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(cs.e2, st));
 
@@ -1413,7 +1335,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     unsigned long long cap = 0;
     MeshCounters h;
     bool to_caller = compact || (d_out && cap_out > 0);
-    bool quiet = !fresh_buffers;     // nothing but k_mesh follows ev[2] on the stream, and the host did not stall in between
+    bool quiet = true;     // nothing but k_mesh follows ev[2] on the stream, and the host did not stall in between
     if (!to_caller) {
         if (t->hint_key == key && t->hint_total_tris) {
             cap = t->hint_total_tris + t->hint_total_tris / 4 + 4096;
@@ -1468,7 +1390,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.prof = (unsigned long long *)c->prof.p;
         DevBuf &park = async_mode ? cs.park : c->park;   // (k_mesh kernels of calls in flight may overlap in time, whichever
                                                          // streams they run on: each call slot has its own staging slots)
-        if (c->parking && !park.p && !split) { quiet = false; if (park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
+        if (c->parking && !park.p) { quiet = false; if (park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
         a.park = c->parking ? (float *)park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
         a.park_spins = (unsigned)c->park_spins;
         a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
@@ -1480,11 +1402,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         // two-pass one moves a third of the bytes (9 GB against 25 GB per call: no parking, and the 4-slot sampling
         // kernel spills less without the emit phases): the tape's length decides (sdf_ctx_set_twopass / SDF_MESH_TWOPASS
         // override).
-        const bool twopass = twopass_sel && !split;
-        a.tiles = split ? (unsigned char *)m->tiles.p : nullptr; a.tiles_cap256 = split ? tiles_cap256 : 0;
-        a.owner = split ? (const int *)m->owner.p : nullptr;
-        a.code_for_stats = pruning ? m->tapes.p : (const void *)t->d_code;
-        if (split) { a.park = nullptr; a.park_cap = 0; a.order = nullptr; a.tail = 0; }   // (k_march waits for its place: nothing is parked)
+        const bool twopass = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
         if (twopass) {
             // the arenas of the two-pass scheme: a surface cell carries at least one triangle, so the soup's capacity
             // bounds both (a call whose arenas turn out too small is flagged and repeated like one whose soup is)
@@ -1501,9 +1419,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         const bool own_start = attempt > 0 || a.prof || !quiet;   // (something was enqueued, or the host waited, since ev[2])
         if (own_start) HIPCHK(hipEventRecord(cs.e3, st));
-        if (split) {
-            if (launch_split(t, pruning ? m->tapes.p : (const void *)t->d_code, a, nb, st)) return 1;
-        } else if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs, st)) return 1;
+        if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs, st)) return 1;
         if (a.twopass) {
             const unsigned long long emit_blocks = (a.out_cap + 255ull) / 256ull;
             if (emit_blocks > 0x7fffffffull) return fail("sdf_generate: soup capacity too large for one k_emit2 launch");
@@ -1564,18 +1480,6 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         }
         m->st.n_retries = attempt;
         if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
-        if (h.overflow & MESH_OVERFLOW_TILES) {   // the tile arena was too small: k_cull's cursor says what the call needs
-            if (attempt >= 3) return fail("sdf_generate: tile arena overflow persists");
-            tiles_cap256 = h.tile_cursor;
-            if (m->tiles.ensure((size_t)tiles_cap256 * 256) || m->owner.ensure((size_t)tiles_cap256 * 4)) {
-                split = false;                                                    // (no room for the arena: k_mesh needs none)
-            } else {   // k_cull once more: it hands the places out again (any order) and names the owner of every unit this time
-                HIPCHK(hipMemsetAsync((unsigned char *)m->counters.p + offsetof(MeshCounters, tile_cursor), 0, 8, st));
-                HIPCHK(launch_cull());
-            }
-            m->st.n_retries = attempt + 1;
-            continue;                                                              // (same soup buffer)
-        }
         if (h.overflow) {
             if (attempt >= 3) return fail("sdf_generate: soup buffer overflow persists");
             to_caller = false;                       // the exact need is known now: h.total
@@ -1985,7 +1889,6 @@ int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
             // the soup did not fit the caller's buffer: the call is repeated synchronously into library memory
             // (sized from the count just learned)
             pd.tape->hint_key = pd.key; pd.tape->hint_total_tris = std::max<unsigned long long>(h.total, 1);
-            pd.tape->hint_tiles256 = h.tile_cursor;      // (a tile arena that was too small is sized by what k_cull handed out)
             const double *X = pd.axes.data(), *Y = X + pd.nx, *Z = Y + pd.ny;
             if (generate_impl(pd.tape, m, X, pd.nx, Y, pd.ny, Z, pd.nz, pd.bs, pd.sparse, pd.shard_index, pd.shard_count, pd.precision,
                               nullptr, 0, false))
@@ -2252,7 +2155,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
         m->out.p = nullptr; m->out.bytes = 0;
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
-    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->order, &m->tiles, &m->owner, &m->desc, &m->cellrecs, &m->trilist, &m->blockidx}) b->release();
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->order, &m->desc, &m->cellrecs, &m->trilist, &m->blockidx}) b->release();
     (void)hipFree(m->weld_pts); (void)hipFree(m->weld_inv);
     delete m;
     return 0;

@@ -2,7 +2,6 @@
 // Built four times (see build.sh): -DMESH_T=double|float -DMESH_FULL=0|1 -DMESH_NAME=...
 // so the families compile in parallel.
 #include "sdf_device.h"
-#include "sdf_split.h"
 
 namespace sdfk {
 
@@ -57,25 +56,5 @@ SDF_DECLARE_MESH_LAUNCH(MESH_NAME, MESH_T) {
                                : launch_one<8, 8, 1, 1024>(grid, lds, stream, code, consts, a);
     }
 }
-
-#ifdef MESH_SAMPLE_NAME
-// k_sample (split meshing, sdf_split.h) of this family: float64 only -- the tile arena exists where k_cull ran, and the interval
-// passes bound the float64 interpreter.  The register files as for k_mesh; two samples per lane wherever the file allows.
-template <int NP, int ND, int NS>
-static int launch_sample_one(int grid, hipStream_t stream, const uint32_t *code, const MESH_T *consts, const MeshArgs &a) {
-    hipLaunchKernelGGL((k_sample<MESH_T, (MESH_FULL != 0), NP, ND, NS>), dim3(grid), dim3(SPLIT_BLOCK), 0, stream, code, consts, a);
-    return (int)hipGetLastError();
-}
-SDF_DECLARE_SAMPLE_LAUNCH(MESH_SAMPLE_NAME) {
-    switch (slots) {
-    case 0: return launch_sample_one<1, 1, 2>(grid, stream, code, consts, a);
-    case 1: return launch_sample_one<2, 2, 2>(grid, stream, code, consts, a);
-    case 2: return launch_sample_one<4, 2, 2>(grid, stream, code, consts, a);
-    case 3: return launch_sample_one<2, 4, 2>(grid, stream, code, consts, a);
-    case 4: return launch_sample_one<4, 4, 2>(grid, stream, code, consts, a);
-    default: return launch_sample_one<8, 8, 1>(grid, stream, code, consts, a);
-    }
-}
-#endif
 
 }  // namespace sdfk

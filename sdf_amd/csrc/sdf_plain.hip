@@ -8,12 +8,9 @@
 // lanes diverge: r03's k_expand, written here first in the interpreters' unit, came out wrong for every workgroup that
 // straddled into the last slab (a divergent search loop next to a uniform one), and right without the option.
 // tests/test_gpu.py::test_expand_synthetic_slabs holds that case.
-#include <algorithm>
-
 #include "sdf_device.h"
 #include "sdf_plain.h"
 #include "sdf_slab.h"
-#include "sdf_split.h"
 
 using namespace sdfk;
 
@@ -510,409 +507,3 @@ void launch_k_emit2(dim3 grid, dim3 block, hipStream_t stream, const MeshArgs &a
 void launch_k_stl(dim3 grid, dim3 block, hipStream_t stream, const double *pts, long long ntri, unsigned short *out) {
     hipLaunchKernelGGL(k_stl, grid, block, 0, stream, pts, ntri, out);
 }
-
-// ---- split meshing, second kernel (sdf_split.h): marching cubes + ordered emission of the tiles k_sample left in the arena ----
-// Workgroups of 256 threads, several per compute unit; each takes work items IN ORDER from `march_counter` (what makes the
-// look-back safe: every predecessor of an item is held by a running workgroup) and does for one tile what k_mesh's phases 2 - 4
-// do (sdf_device.h), on the sign bits and column words in LDS and the samples in the arena:
-//   rows    a thread owns FOUR CONSECUTIVE (i0, i1) rows of cells: their surface-cell masks from the sign strings, one block
-//           scan -> every surface cell's running index in soup order (i0, i1, i2 ascending: skimage's emission order)
-//   cells   chunks of up to 2048 surface cells: the rows' threads scatter (row, column) into a table; a thread then owns a RUN
-//           of consecutive cells of the chunk (ceil(cells / 256) each), looks up their triangle counts (ambiguous
-//           configurations: Lewiner's tests on the 8 corner samples) -- one block scan -> every cell's first triangle -- and
-//           writes the per-triangle list (cell | configuration | triangle of the cell) over the table
-//   place   the tile's count is published, wave 0 walks back over its predecessors' words (ordered_base, blocking: the other
-//           workgroups of the compute unit fill the wait)
-//   emit    a lane per triangle: three edge interpolations on samples fetched from the arena (TileView), transposed through LDS
-//           so that consecutive lanes store consecutive coordinates, `points * scale + offset` in float64 (reference
-//           sdf/core.py:58-60)
-// The common tile -- at most 2048 surface cells and MARCH_LCAP triangles -- is classified ONCE; any other one classifies every
-// chunk for the count and again per window of MARCH_LCAP triangles for the emission (rows and cells are recomputed rather
-// than kept in registers across the phases: nothing but the loop state lives through the emission).
-
-// triangles of an ambiguous cell: Lewiner's tests on its 8 corner samples pick the tiling (rare; out of line: its registers are
-// the call's, not the kernel's)
-static __device__ __attribute__((noinline)) int march_amb_count(const float *smp, const unsigned *colinfo, int lyz, int lz, bool sparse,
-                                                                int i0, int i1, int i2, const signed char *tab) {
-    const TileView vw{smp, colinfo, lyz, lz, sparse};
-    float c8[8];
-    double lv[8];
-    int off;
-    vw.cell(i0, i1, i2, c8);
-    mc33_load_cell(c8, 4, 2, lv);
-    return mc33_cell(lv, tab, &off);
-}
-// triangle j of an ambiguous cell, its nine local coordinates straight into the wave's transposition area
-static __device__ __attribute__((noinline)) void march_amb_triangle(const float *smp, const unsigned *colinfo, int lyz, int lz, bool sparse,
-                                                                    int i0, int i1, int i2, const signed char *tab, int j, float *dst) {
-    const TileView vw{smp, colinfo, lyz, lz, sparse};
-    float c8[8], oa[9];
-    vw.cell(i0, i1, i2, c8);
-    mc33_triangle(c8, 4, 2, i0, i1, i2, tab, j, oa);
-    for (int q = 0; q < 9; q++) dst[q] = oa[q];
-}
-
-// MODE 0: count, place and emit in one go (the look-back WAITS for predecessors that are still counting: a convoy behind the
-// slowest tile in flight); 1: count only -- sign bits into the arena, the count published; 2: emit only, behind a MODE 1 launch:
-// every count is known, nothing waits, the cells are classified again (cheaper than keeping them)
-template <int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void k_march(MeshArgs a) {
-    constexpr int RPT = 1024 / BLOCK, CPT = MARCH_CELLS / BLOCK;
-    __shared__ int wave_sums[16];
-    __shared__ int bcast[8];
-    __shared__ unsigned char ntri_lds[256];                                 // ntri | ambiguous << 7
-    __shared__ unsigned short tri_lds[256 * 5];                             // e0 | e1 << 4 | e2 << 8 of triangle j of configuration cfg at [5 cfg + j]
-    __shared__ unsigned colinfo[292];                                       // k_cull's column words (TileView, sparse form)
-    __shared__ unsigned long long bits[((33 * 33 * 33 + 63) >> 6) + 2];
-    __shared__ double xf_lds[6];                                            // offset[3], scale[3] of the tile in hand
-    __shared__ float stage[BLOCK / 64][64 * 9];                             // per wave: 64 triangles, transposed on their way out
-    __shared__ __attribute__((aligned(16))) unsigned lst[MARCH_LCAP];       // the chunk's cell table, then the triangle list
-    static_assert(MARCH_LCAP >= MARCH_CELLS, "the cell table lives in the list");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const GridDesc g = a.g;
-    // (what the phases below need of the argument block, as values of their own: a by-value kernel argument whose address a
-    // lambda captures is copied to private memory as a whole)
-    const signed char *const mc33 = a.mc->mc33;
-    double *const soup = a.out;
-    const bool compact = a.compact != 0;
-    const Tri16Sink sink{a.out, a.raw, a.raw_cap, &a.ctr->n_raw};
-    if (tid < 256) ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
-    for (int i = tid; i < 256 * 5; i += BLOCK) {
-        const int cfg = i / 5, j = i - 5 * cfg;
-        const signed char *t3 = &a.mc->tri[cfg][3 * j];
-        tri_lds[i] = (unsigned short)(((unsigned)t3[0] & 15u) | (((unsigned)t3[1] & 15u) << 4) | (((unsigned)t3[2] & 15u) << 8));
-    }
-    const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
-    const bool have_arena = a.ctr->tile_cursor <= a.tiles_cap256;           // (else: flagged by k_sample, nothing was sampled, the call is repeated)
-    bool first_item = true;
-    for (;;) {
-        // (where nothing ever waits -- MODE 1 / 2 -- a workgroup's FIRST item is its own index: a thousand workgroups drawing from one
-        // counter in the same microsecond queue up at its address; MODE 0 must hand every item to a workgroup that is running)
-        if (tid == 0) {
-            int idx;
-            if (MODE != 0 && first_item) idx = (int)blockIdx.x;
-            else idx = (MODE != 0 ? (int)gridDim.x : 0) + (int)atomicAdd(MODE == 2 ? &a.ctr->emit_counter : &a.ctr->march_counter, 1u);
-            bcast[0] = work_begin + idx;
-        }
-        first_item = false;
-        __syncthreads();
-        const int w = __builtin_amdgcn_readfirstlane(bcast[0]);
-        if (w >= work_end) break;
-        // wave 0 asks for the predecessors' status words now: the answer arrives while the cells are counted
-        unsigned long long pre = 0;
-        if (tid < 64 && MODE != 1) pre = lookback_prefetch(a.status, w, work_begin);
-        const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
-        const int b = __builtin_amdgcn_readfirstlane(a.worklist[w]);
-        const unsigned n0 = (unsigned)__builtin_amdgcn_readfirstlane((int)rec[0]) & 0xFFFFu;
-        const unsigned long long off256 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)rec[1]);
-        const bool culled = n0 != 0xFFFFu;
-        const int ntl = culled ? (int)((n0 + 7u) >> 3) : -1;
-        int ox, oy, oz, lx, ly, lz;
-        batch_origin(g, b, ox, oy, oz, lx, ly, lz);
-        const int lyz = ly * lz, nvox = lx * lyz, nwords = (nvox + 63) >> 6;
-        const bool have_tile = have_arena;
-        const float *tile = reinterpret_cast<const float *>(a.tiles + off256 * 256ull);
-        // ---- the tile's sign-bit volume (value > 0), one word per 64 consecutive samples: the marching phases classify cells from
-        // these bits.  Culled tile: the samples of DECIDED sub-groups get their bits straight from the sub-group states (a row of
-        // lz samples along z = `pos | pos << 1` of its 16 two-bit states, "positive" = 01: k_mesh's sign fill), the evaluated
-        // samples -- 64 per listed task, cull_sample's order -- OR theirs in.  Dense tile: a ballot per word. ----
-        unsigned long long *tile_bits = reinterpret_cast<unsigned long long *>(a.tiles + off256 * 256ull + tile_data_bytes(ntl, nvox));
-        if (MODE == 2) {   // (the counting launch left them in the arena)
-            if (have_tile) {
-                for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = tile_bits[i];
-                if (culled) for (int i = tid; i < 289; i += BLOCK) colinfo[i] = rec[CULL_COLINFO / 4 + i];
-            }
-        } else if (have_tile && culled) {
-            for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;
-            for (int i = tid; i < 289; i += BLOCK) colinfo[i] = rec[CULL_COLINFO / 4 + i];
-            __syncthreads();
-            const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
-            const int hlast = (c2 - 1) >> 1;
-            const unsigned *sstate = rec + CULL_SSTATE / 4;
-            for (int r = tid; r < lx * ly; r += BLOCK) {
-                const int ix = fast_div(r, 1.0f / (float)ly), iy = r - ly * ix;
-                const unsigned st = sstate[(min(ix, c0 - 1) >> 1) * 16 + (min(iy, c1 - 1) >> 1)];
-                const unsigned pos = st & ~(st >> 1) & 0x55555555u & (unsigned)((4ull << (2 * hlast)) - 1ull);
-                unsigned long long rowmask = (unsigned long long)(pos | (pos << 1));
-                if ((pos >> (2 * hlast)) & 1u) rowmask |= 1ull << c2;
-                if (rowmask) {
-                    const int o = r * lz, sh = o & 63;
-                    atomicOr(&bits[o >> 6], rowmask << sh);
-                    if (sh && (rowmask >> (64 - sh))) atomicOr(&bits[(o >> 6) + 1], rowmask >> (64 - sh));
-                }
-            }
-            const unsigned short *units = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(rec) + CULL_ULIST);
-            for (int s0 = tid; s0 < 64 * ntl; s0 += BLOCK) {
-                int ix, iy, iz;
-                if (cull_sample(units, s0 >> 6, s0 & 63, lx, ly, lz, ix, iy, iz) && tile[s0] > 0.0f) {
-                    const int i = ix * lyz + iy * lz + iz;
-                    atomicOr(&bits[i >> 6], 1ull << (i & 63));
-                }
-            }
-        } else if (have_tile) {
-            for (int i0 = tid; i0 < 64 * nwords; i0 += BLOCK) {               // (whole waves: a wave owns a word)
-                const unsigned long long mword = __ballot(i0 < nvox && tile[min(i0, nvox - 1)] > 0.0f);
-                if (lane == 0) bits[i0 >> 6] = mword;
-            }
-            if (tid < 2) bits[nwords + tid] = 0ull;                          // the row extraction reads one word ahead
-        }
-        if (MODE == 1 && have_tile) {
-            __syncthreads();
-            for (int i = tid; i < nwords + 2; i += BLOCK) tile_bits[i] = bits[i];
-        }
-        if (tid == 0 && have_tile && MODE != 2) {                             // (statistics k_mesh keeps while it samples)
-            if (a.tape_stride) {
-                const unsigned long long *wc = reinterpret_cast<const unsigned long long *>(a.code_for_stats) + (size_t)b * (size_t)a.tape_stride;
-                atomicAdd(&a.ctr->n_pruned, (unsigned long long)a.n_instr - wc[a.tape_stride - 1]);
-            }
-            atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
-        }
-        // points * scale + offset (reference sdf/core.py:58-60): offset = the batch's first sample, scale = its first step, per axis
-        if (tid < 3) {
-            const double *ax = tid == 0 ? g.X + ox : (tid == 1 ? g.Y + oy : g.Z + oz);
-            const double o_ = ax[0];
-            xf_lds[tid] = o_;
-            xf_lds[3 + tid] = ax[(tid == 0 ? lx : (tid == 1 ? ly : lz)) > 1 ? 1 : 0] - o_;
-        }
-        __syncthreads();
-        const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
-        const int nrows = (have_tile && c0 > 0 && c1 > 0 && c2 > 0) ? c0 * c1 : 0;
-        const float inv_c1 = 1.0f / (float)max(c1, 1);
-        auto row_signs = [&](int i0, int i1, unsigned long long *rb) __attribute__((always_inline)) -> unsigned {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {   // q = 2 * o0 + o1
-                const int o = (i0 + (q >> 1)) * lyz + (i1 + (q & 1)) * lz;
-                const unsigned long long w0 = bits[o >> 6], w1 = bits[(o >> 6) + 1];
-                const int sh = o & 63;
-                rb[q] = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-            }
-            const unsigned long long any = rb[0] | rb[1] | rb[2] | rb[3];
-            const unsigned long long all = rb[0] & rb[1] & rb[2] & rb[3];
-            const unsigned long long ones = all & (all >> 1), zeros = ~any & ~(any >> 1);
-            return (unsigned)(~(ones | zeros)) & (c2 >= 32 ? 0xFFFFFFFFu : ((1u << c2) - 1u));
-        };
-        // ---- rows: the surface-cell masks of this thread's four consecutive rows, the cells' running index; returns the
-        // tile's surface cells ----
-        auto rows = [&](unsigned *row_mask, int *row_cell0) __attribute__((always_inline)) -> int {
-            int mine = 0;
-#pragma unroll
-            for (int k = 0; k < RPT; k++) {
-                const int r = RPT * tid + k;
-                unsigned mask = 0;
-                if (r < nrows) {
-                    unsigned long long rb[4];
-                    const int i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
-                    mask = row_signs(i0, i1, rb);
-                }
-                row_mask[k] = mask;
-                row_cell0[k] = mine;
-                mine += __popc(mask);
-            }
-            int n;
-            const int excl = block_exclusive_scan<BLOCK>(mine, wave_sums, n);
-#pragma unroll
-            for (int k = 0; k < RPT; k++) row_cell0[k] += excl;
-            return __builtin_amdgcn_readfirstlane(n);
-        };
-        // ---- cells: chunk `ch` of the surface cells -> this thread's run of them: entry | triangles << 28 each (a cell has at
-        // most 12 triangles, the entry ends at bit 27); returns the thread's triangle sum ----
-        int my_amb = 0;
-        auto classify = [&](int ch, int ncells, const unsigned *row_mask, const int *row_cell0, unsigned *cinfo, bool count_amb) __attribute__((always_inline)) -> int {
-            const int cbase = ch * MARCH_CELLS, ccount = min(MARCH_CELLS, ncells - cbase);
-            const int cpt = (ccount + BLOCK - 1) / BLOCK;                    // cells per thread (uniform, <= CPT)
-#pragma unroll
-            for (int k = 0; k < RPT; k++) {
-                const int r = RPT * tid + k;
-                unsigned m = row_mask[k];
-                int pos = row_cell0[k] - cbase;
-                while (m) {
-                    const int i2 = __ffs((int)m) - 1;
-                    m &= m - 1u;
-                    if (pos >= 0 && pos < MARCH_CELLS) lst[pos] = (unsigned)r | ((unsigned)i2 << 10);
-                    pos++;
-                }
-            }
-            __syncthreads();
-            int sum = 0;
-#pragma unroll
-            for (int q = 0; q < CPT; q++) {
-                const int s = cpt * tid + q;
-                int n = 0;
-                unsigned info = 0;
-                if (q < cpt && s < ccount) {
-                    const unsigned ce = lst[s];
-                    const int r = (int)(ce & 1023u), i2 = (int)((ce >> 10) & 31u), i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
-                    unsigned long long rb[4];
-                    row_signs(i0, i1, rb);
-                    const unsigned cfg = cell_config(rb, i2);
-                    const unsigned e = ntri_lds[cfg];
-                    if (e & 128u) {
-                        n = march_amb_count(tile, colinfo, lyz, lz, culled, i0, i1, i2, mc33);
-                        if (count_amb) my_amb++;
-                    } else n = (int)(e & 7u);
-                    // entry: cell (15 bits) | ambiguous (1) | configuration (8) | triangle in cell (4)
-                    info = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((e & 128u) << 5) | (cfg << 4);
-                }
-                cinfo[q] = info | ((unsigned)n << 28);
-                sum += n;
-            }
-            return sum;
-        };
-        // the triangles [lo, lo + MARCH_LCAP) of a chunk into the list (over the table: every thread has read its entries
-        // before the scan's barriers); `excl` = this thread's first triangle in the chunk
-        auto write_list = [&](const unsigned *cinfo, int excl, int lo) __attribute__((always_inline)) {
-            int pos = excl - lo;
-#pragma unroll
-            for (int q = 0; q < CPT; q++) {
-                const int n = (int)(cinfo[q] >> 28);
-                const unsigned ent = cinfo[q] & 0x0FFFFFFFu;
-                for (int j = 0; j < n; j++, pos++)
-                    if (pos >= 0 && pos < MARCH_LCAP) lst[pos] = ent | (unsigned)j;
-            }
-        };
-        int total = 0, ncells, nchunks;
-        bool listed = false;            // the common tile: its whole list is in LDS after the count
-        {
-            unsigned row_mask[RPT], cinfo[CPT];
-            int row_cell0[RPT];
-            ncells = rows(row_mask, row_cell0);
-            nchunks = (ncells + MARCH_CELLS - 1) / MARCH_CELLS;
-            for (int ch = 0; ch < nchunks; ch++) {                          // (uniform)
-                const int sum = classify(ch, ncells, row_mask, row_cell0, cinfo, MODE != 2);
-                int tot;
-                const int excl = block_exclusive_scan<BLOCK>(sum, wave_sums, tot);
-                total += tot;
-                if (MODE != 1 && nchunks == 1 && tot <= MARCH_LCAP) { write_list(cinfo, excl, 0); listed = true; }   // (made visible by the allocation's barrier)
-            }
-        }
-        total = __builtin_amdgcn_readfirstlane(total);
-        if (MODE != 2) {
-            // ---- the tile's count is public from here on; bookkeeping that needs no position ----
-            if (tid < 64) publish_count(a.status, w, work_begin, (unsigned long long)total);
-            if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
-                double *xf = a.xf + (size_t)(w - work_begin) * 6;
-                for (int q = 0; q < 6; q++) xf[q] = xf_lds[q];
-            }
-            if (tid == 0) {
-                atomicAdd(total ? &a.ctr->n_nonempty : &a.ctr->n_empty, 1u);
-                atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
-                a.kinds[b] = total ? 2 : 1;
-            }
-            if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
-        }
-        if (MODE == 1) continue;                                              // (the loop's top barrier orders this item's LDS reads before the next item's writes)
-        // ---- place: the exclusive prefix of the triangle counts over the work list (wave 0; blocking) ----
-        if (tid < 64) {
-            const unsigned long long excl = ordered_base(a.status, w, work_begin, (unsigned long long)total, MESH_SPIN_FOREVER, pre);
-            if (tid == 0) {
-                if (excl == ~0ull) atomicOr(&a.ctr->overflow, 2u);           // look-back timed out (never expected)
-                else if (excl + (unsigned long long)total > a.out_cap) atomicOr(&a.ctr->overflow, 1u);
-                if (w == work_end - 1 && excl != ~0ull) a.ctr->total = excl + (unsigned long long)total;
-                reinterpret_cast<unsigned long long *>(bcast + 2)[0] = excl;
-            }
-        }
-        __syncthreads();
-        const unsigned long long base = uni64(reinterpret_cast<unsigned long long *>(bcast + 2)[0]);
-        const bool fits = base != ~0ull && base + (unsigned long long)total <= a.out_cap;
-        // ---- emit: the triangles [0, ecn) of the list in LDS go to soup positions pos0 .. ----
-        auto emit = [&](int ecn, unsigned long long pos0) __attribute__((always_inline)) {
-            double *dst0 = soup + pos0 * 9ull;
-            float *stg = stage[wave];
-            const TileView vw{tile, colinfo, lyz, lz, culled};
-            for (int t0 = wave * 64; t0 < ecn; t0 += BLOCK) {               // (whole waves: the transposition below is wave-wide)
-                const int t = t0 + lane;
-                const bool live = t < ecn;
-                const unsigned e = lst[live ? t : ecn - 1];
-                const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
-                const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
-                if (compact) {   // (uniform) the exchange's 16-byte record, straight from the registers
-                    float o[9];
-                    if (e & 4096u) {
-                        march_amb_triangle(tile, colinfo, lyz, lz, culled, i0, i1, i2, mc33, j, stg + lane * 9);
-#pragma unroll
-                        for (int q = 0; q < 9; q++) o[q] = stg[lane * 9 + q];
-                    } else {
-                        const unsigned tt3 = tri_lds[5 * cfg + min(j, 4)];
-                        mc_vertex_view(vw, i0, i1, i2, (int)(tt3 & 15u), o);
-                        mc_vertex_view(vw, i0, i1, i2, (int)((tt3 >> 4) & 15u), o + 3);
-                        mc_vertex_view(vw, i0, i1, i2, (int)(tt3 >> 8), o + 6);
-                    }
-                    if (live) store_tri16(sink, pos0 + (unsigned long long)t, o);
-                    continue;
-                }
-                // through LDS: lane l leaves triangle t0 + l (9 floats) at stg[9 l ..]; afterwards lane l stores coordinates
-                // 64 k + l, k = 0 .. 8, of the wave's 576: consecutive lanes, consecutive addresses.  Coordinate c belongs to axis
-                // c % 3 and 64 % 3 == 1: the axis of a lane's k-th coordinate is (l + k) % 3.
-                if (e & 4096u) march_amb_triangle(tile, colinfo, lyz, lz, culled, i0, i1, i2, mc33, j, stg + lane * 9);
-                else {
-                    const unsigned tt3 = tri_lds[5 * cfg + min(j, 4)];
-#pragma unroll
-                    for (int v = 0; v < 3; v++) {
-                        float o[3];
-                        mc_vertex_view(vw, i0, i1, i2, (int)((tt3 >> (4 * v)) & 15u), o);
-                        stg[lane * 9 + 3 * v] = o[0]; stg[lane * 9 + 3 * v + 1] = o[1]; stg[lane * 9 + 3 * v + 2] = o[2];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int nval = min(64, ecn - t0) * 9;
-                double *dstw = dst0 + (size_t)t0 * 9;
-                int ax = lane % 3;
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int c = 64 * k + lane;
-                    if (c < nval) dstw[c] = (double)stg[c] * xf_lds[3 + ax] + xf_lds[ax];
-                    ax = ax == 2 ? 0 : ax + 1;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();   // (the area is rewritten by the wave's next 64 triangles)
-            }
-        };
-        if (fits && total > 0) {                                             // (uniform)
-            if (listed) {
-                emit(total, base);
-                __syncthreads();   // (the list is rewritten by the next item's table)
-            } else {
-                int tri_base = 0;
-                for (int ch = 0; ch < nchunks; ch++) {
-                    int tot_c = 0;
-                    for (int lo = 0; lo == 0 || lo < tot_c; lo += MARCH_LCAP) {
-                        unsigned row_mask[RPT], cinfo[CPT];
-                        int row_cell0[RPT];
-                        rows(row_mask, row_cell0);
-                        const int sum = classify(ch, ncells, row_mask, row_cell0, cinfo, false);
-                        const int excl = block_exclusive_scan<BLOCK>(sum, wave_sums, tot_c);
-                        tot_c = __builtin_amdgcn_readfirstlane(tot_c);
-                        write_list(cinfo, excl, lo);
-                        __syncthreads();
-                        emit(min(MARCH_LCAP, tot_c - lo), base + (unsigned long long)(tri_base + lo));
-                        __syncthreads();   // (the list is rewritten by the next window's table)
-                    }
-                    tri_base += tot_c;
-                }
-            }
-        }
-        // (the loop's top barrier separates this item's last reads of bits / colinfo / bcast from the next item's writes)
-    }
-    if (tid == 0) atomicMax(&a.ctr->t_last, (unsigned long long)wall_clock64());
-}
-
-namespace sdfk {
-template <int BLOCK>
-static void launch_march_block(int two, int grid, hipStream_t stream, const MeshArgs &a) {
-    if (two) {
-        hipLaunchKernelGGL((k_march<BLOCK, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
-        hipLaunchKernelGGL((k_march<BLOCK, 2>), dim3(grid), dim3(BLOCK), 0, stream, a);
-    } else hipLaunchKernelGGL((k_march<BLOCK, 0>), dim3(grid), dim3(BLOCK), 0, stream, a);
-}
-int sdf_launch_march(int block, int two, int n_cu, int nb, hipStream_t stream, const MeshArgs &a) {
-    const int per_cu = block == 1024 ? 1 : (block == 512 ? 2 : 4);
-    const int grid = (int)std::min<long long>(nb, (long long)n_cu * per_cu);
-    if (block == 1024) launch_march_block<1024>(two, grid, stream, a);
-    else if (block == 512) launch_march_block<512>(two, grid, stream, a);
-    else launch_march_block<256>(two, grid, stream, a);
-    return (int)hipGetLastError();
-}
-}  // namespace sdfk

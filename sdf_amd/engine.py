@@ -65,7 +65,6 @@ ABI = {
     'sdf_ctx_set_prune': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_cull': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_twopass': (ctypes.c_int, [_vp, ctypes.c_int]),
-    'sdf_ctx_set_split': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_tail_order': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_defer': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_cull_levels': (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -136,7 +135,7 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 7
+ABI_VERSION = 6
 
 
 def _strip_c_comments(text):
@@ -525,11 +524,6 @@ class Engine:
         """meshing scheme: 0 one kernel (look-back + parking), 1 three kernels (sample / number / emit), -1 the
         library's choice by the tape's length (default); results are identical"""
         _check(self.lib, self.lib.sdf_ctx_set_twopass(self.ctx, int(mode)))
-
-    def set_split(self, mode):
-        """meshing pass as two kernels of small workgroups (k_sample + k_march, csrc/sdf_split.h): 1 wherever the interval
-        pass ran, 0 never (the one-kernel k_mesh), -1 the library's choice by the tape (default); results are identical"""
-        _check(self.lib, self.lib.sdf_ctx_set_split(self.ctx, int(mode)))
 
     def synchronize(self):
         _check(self.lib, self.lib.sdf_ctx_synchronize(self.ctx))

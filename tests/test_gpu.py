@@ -1323,87 +1323,6 @@ def test_one_pass_and_two_pass_meshing_agree(name, samples, ns, eng):
             assert a[4][k] == b[4][k], k
 
 
-# ---- split meshing (k_sample + k_march, csrc/sdf_split.h) against the one-kernel scheme ----
-
-@pytest.mark.parametrize('name,samples,bs', [('ex_example', 2 ** 22, 32), ('ex_example', 1500000, 32), ('ex_example', 2 ** 18, 7), ('ex_example', 2 ** 20, 16),
-                                             ('ex_gearlike', 2 ** 22, 32), ('ex_blobby', 2 ** 23, 32), ('ex_weave', 2 ** 22, 32), ('ex_knurling', 2 ** 21, 32),
-                                             ('ex_pawn', 2 ** 21, 32), ('wireframe_box', 2 ** 18, 32), ('ex_blobby', 2 ** 20, 31)])
-def test_split_meshing_agrees_with_one_kernel(name, samples, bs, ns, eng):
-    """The meshing pass as two kernels of small workgroups (k_sample: the interpreter, tiles into an arena in device memory;
-    k_march: marching cubes + ordered emission from the arena) gives the soup, the per-batch verdicts and offsets and the
-    statistics of the one-kernel k_mesh bit for bit -- regular, ragged and small tiles, sparse and dense grids, trig tapes,
-    tapes the library would mesh in two passes (forced here), a caller buffer that is too small."""
-    import torch
-    f = fixtures.build(name, ns)
-    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, BOUNDS[name])), samples=samples)
-    res = {}
-    try:
-        for split in (0, 1):
-            eng.set_split(split)
-            for sparse in (True, False):
-                m = eng.generate(f, X, Y, Z, bs, sparse)
-                res[(split, sparse)] = (m.points(), m.kinds(), m.batch_offsets(), m.stats())
-                m.close()
-        t = res[(1, True)][3]['triangles']
-        assert t > 100
-        small = torch.full((9 * (t // 2) + 9,), -7.0, dtype=torch.float64, device='cuda:0')
-        m = eng.generate(f, X, Y, Z, bs, True, out_ptr=small.data_ptr(), out_cap=t // 2)
-        assert not m.emitted and m.n_triangles == t and np.array_equal(m.points(), res[(0, True)][0])
-        assert float(small[-1]) == -7.0
-        m.close()
-        big = torch.full((9 * t + 9,), -7.0, dtype=torch.float64, device='cuda:0')
-        m = eng.generate(f, X, Y, Z, bs, True, out_ptr=big.data_ptr(), out_cap=t)
-        assert m.emitted and m.n_triangles == t
-        assert np.array_equal(big[:9 * t].cpu().numpy().reshape(-1, 3), res[(0, True)][0]) and float(big[-1]) == -7.0
-        m.close()
-    finally:
-        eng.set_split(-1)
-    for sparse in (True, False):
-        a, b = res[(0, sparse)], res[(1, sparse)]
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), sparse
-        for k in ('triangles', 'skipped', 'empty', 'nonempty', 'n_eval_voxels', 'n_ambiguous_cells', 'n_sampled_voxels', 'n_pruned_instrs'):
-            assert a[3][k] == b[3][k], (sparse, k)
-
-
-def test_split_meshing_tile_arena_too_small_is_repeated(ns, eng):
-    """the arena of sampled tiles is sized by what k_cull handed out the last time the tape ran on the grid; a FIRST call on a
-    grid whose tiles do not fit the first guess (forced here: SDF_TILES_FIRST_CAP256) is flagged on the device and repeated
-    with the size the interval pass reported -- in a process of its own, the context reads the variable when it is created"""
-    import subprocess
-    import sys
-    script = '''
-import sys, hashlib
-sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
-import numpy as np
-import torch
-torch.cuda.set_device(0)      # (torch's HIP runtime first, like every process of this suite)
-import sdf_amd
-from sdf_amd import core, engine
-import fixtures
-ns = {k: getattr(sdf_amd, k) for k in dir(sdf_amd) if not k.startswith('_')}
-eng = engine.get_engine(0)
-f = fixtures.build('ex_example', ns)
-X, Y, Z, _ = core.grid_axes(((-0.85, -0.85, -0.85), (0.85, 0.85, 0.85)), samples=2 ** 22)
-eng.set_split(1)
-m = eng.generate(f, X, Y, Z, 32, True); a = m.points(); sa = m.stats(); m.close()
-m = eng.generate(f, X, Y, Z, 32, True); a2 = m.points(); sa2 = m.stats(); m.close()
-buf = torch.empty(9 * (sa['triangles'] + 8), dtype=torch.float64, device='cuda:0')
-g = fixtures.build('ex_blobby', ns)
-X2, Y2, Z2, _ = core.grid_axes(((-1.2, -1.2, -1.2), (1.2, 1.2, 1.2)), samples=2 ** 21)
-m = eng.generate(g, X2, Y2, Z2, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9, wait=False)
-c = m.points(); sc = m.stats(); m.close()
-eng.set_split(0)
-m = eng.generate(f, X, Y, Z, 32, True); b = m.points(); m.close()
-m = eng.generate(g, X2, Y2, Z2, 32, True); d = m.points(); m.close()
-assert np.array_equal(a, b) and np.array_equal(a2, b) and np.array_equal(c, d)
-assert sa['n_retries'] >= 1 and sa2['n_retries'] == 0, (sa['n_retries'], sa2['n_retries'])
-print('ok', sa['n_retries'], sa2['n_retries'], sc['n_retries'])
-''' % (ROOT, ROOT)
-    env = dict(os.environ, SDF_TILES_FIRST_CAP256='64')
-    r = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-2000:] + r.stderr[-3000:]
-
-
 def test_two_pass_meshing_full_size_and_slabs(ns, oracle_lib, eng):
     """the two-pass scheme at BASELINE config 2: the reference's soup hash; and as the source of exchange slabs"""
     import torch

@@ -10,8 +10,8 @@ pids=""
 for u in "$@"; do
   case $u in
     hip) $HIPCC $FLAGS -c -o build/sdf_hip.o sdf_hip.hip & pids="$pids $!" ;;
-    f64) $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f64 -DMESH_SAMPLE_NAME=sdf_launch_sample_f64 -c -o build/mesh_f64.o sdf_mesh_inst.hip & pids="$pids $!" ;;
-    f64full) $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f64_full -DMESH_SAMPLE_NAME=sdf_launch_sample_f64_full -c -o build/mesh_f64_full.o sdf_mesh_inst.hip & pids="$pids $!" ;;
+    f64) $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f64 -c -o build/mesh_f64.o sdf_mesh_inst.hip & pids="$pids $!" ;;
+    f64full) $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f64_full -c -o build/mesh_f64_full.o sdf_mesh_inst.hip & pids="$pids $!" ;;
     f32) $HIPCC $FLAGS -DMESH_T=float -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f32 -c -o build/mesh_f32.o sdf_mesh_inst.hip & pids="$pids $!" ;;
     f32full) $HIPCC $FLAGS -DMESH_T=float -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f32_full -c -o build/mesh_f32_full.o sdf_mesh_inst.hip & pids="$pids $!" ;;
     plain) $HIPCC $PLAIN -c -o build/sdf_plain.o sdf_plain.hip & pids="$pids $!" ;;
