@@ -210,66 +210,6 @@ def stats3(v):
     return {'min': round(float(v.min()), 4), 'median': round(float(np.median(v)), 4), 'max': round(float(v.max()), 4), 'n': int(len(v))}
 
 
-def f32_envelope(eng, tape, X, Y, Z, calls=20):
-    """SECONDARY figure, never the headline (the reference computes in float64, and so does `value`): the same job with
-    the tape evaluated in float32 (`Engine.precision = PRECISION_F32`: k_mesh<float>; the grid, the skip test's verdict
-    rule, marching cubes and the float64 `points * scale + offset` are the same code).  Returns how far that soup is from
-    the float64 one -- triangle counts per work item, and the distance from every vertex of either soup to the nearest
-    vertex of the other (a sample whose sign differs between the two modes moves the surface across a grid vertex: the
-    triangles around it change, their vertices stay where they were to within the rounding that flipped the sign; a
-    position-by-position comparison of the soups would call that a deviation of cells), relative to the grid's largest
-    side -- and what a synchronous call costs in either mode."""
-    import torch
-    from scipy.spatial import cKDTree
-    from sdf_amd import engine
-    dev = torch.device('cuda', torch.cuda.current_device())
-
-    def one(prec):
-        eng.precision = prec
-        m = eng.generate(tape, X, Y, Z, 32, True)
-        offs, st, ntri = m.batch_offsets(), m.stats(), m.n_triangles
-        verts = np.array(m.weld()[0])                       # the soup's distinct vertices (sorted on the device)
-        m.close()
-        buf = torch.empty(9 * (ntri + ntri // 8 + 1024), dtype=torch.float64, device=dev)
-        wall, k = [], []
-        for i in range(3 + calls):
-            t1 = time.perf_counter()
-            mesh = eng.generate(tape, X, Y, Z, 32, True, out_ptr=buf.data_ptr(), out_cap=buf.numel() // 9)
-            w = time.perf_counter() - t1
-            s1 = mesh.stats()
-            mesh.close()
-            if i >= 3:
-                wall.append(1e3 * w); k.append(s1['ms_mesh'])
-        return verts, offs, st, ntri, wall, k
-
-    try:
-        v64, o64, s64, t64, w64, k64 = one(engine.PRECISION_F64)
-        v32, o32, s32, t32, w32, k32 = one(engine.PRECISION_F32)
-    finally:
-        eng.precision = engine.PRECISION_F64
-    n64, n32 = np.diff(o64), np.diff(o32)
-    touched = (n64 > 0) | (n32 > 0)
-    extent = float(max(X[-1] - X[0], Y[-1] - Y[0], Z[-1] - Z[0]))
-
-    def toward(a, b):          # every vertex of a: distance to the nearest vertex of b
-        if not len(a) or not len(b):
-            return {'max': 0.0 if len(a) == len(b) else float('inf'), 'p9999': 0.0, 'share_within_1e-5': float(len(a) == len(b))}
-        d = cKDTree(b).query(a, k=1, workers=-1)[0] / extent
-        return {'max': float(d.max()), 'p9999': float(np.quantile(d, 0.9999)), 'share_within_1e-5': float((d <= 1e-5).mean())}
-
-    return {
-        'what': 'float32 tape evaluation against the float64 soup of the same job (= the reference soup where parity_check is true); '
-                'rel_distance: from every distinct vertex of one soup to the nearest vertex of the other, over the largest side of the grid',
-        'triangles_f64': int(t64), 'triangles_f32': int(t32),
-        'batches_with_triangles': int(touched.sum()), 'batches_with_equal_count': int(((n64 == n32) & touched).sum()),
-        'skipped_f64': int(s64['skipped']), 'skipped_f32': int(s32['skipped']),
-        'distinct_vertices_f64': int(len(v64)), 'distinct_vertices_f32': int(len(v32)),
-        'rel_distance_f32_to_f64': toward(v32, v64), 'rel_distance_f64_to_f32': toward(v64, v32),
-        'wall_ms_per_call': {'f64': stats3(w64), 'f32': stats3(w32)},
-        'k_mesh_ms': {'f64': stats3(k64), 'f32': stats3(k32)},
-    }
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -277,11 +217,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--model', default='example', help='example | gearlike | blobby | weave | knurling')
     ap.add_argument('--samples-log2', type=int, default=27, help='grid = samples=2**k through the reference step rule')
-    ap.add_argument('--precision', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--precision', default='f64', choices=['f64'], help='the meshing path is float64 (the reference\'s arithmetic); float32 sampling was removed in round 5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-check', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE configs 3 - 5 section')
-    ap.add_argument('--no-f32-envelope', action='store_true', help='skip the secondary float32 section')
+    ap.add_argument('--no-f32-envelope', action='store_true', help='(accepted and ignored: the float32 section was removed with the mode, round 5)')
     ap.add_argument('--sync', action='store_true', help='one step in flight: every call synchronises before the next is submitted')
     ap.add_argument('--inflight', type=int, default=6, help='steps in flight on a single GPU (each on a lane of its own; at most 8)')
     ap.add_argument('--chunks', type=int, default=None, help='N > 1: shards per rank and step (default 1: one all-gather per step)')
@@ -315,7 +255,7 @@ def main():
 
     from sdf_amd import core, engine, dist
     eng = engine.get_engine(local_rank)
-    eng.precision = engine.PRECISION_F64 if args.precision == 'f64' else engine.PRECISION_F32
+    eng.precision = engine.PRECISION_F64
     dev = torch.device('cuda', local_rank)
     comm_dev = dev if (backend == 'nccl' or os.environ.get('SDF_BENCH_COMM_DEVICE') == 'cuda') else torch.device('cpu')
     stat_dev = dev if backend == 'nccl' else torch.device('cpu')      # (the few scalars the ranks exchange about the run itself)
@@ -547,12 +487,6 @@ def main():
                      'kernel_ms': stats3(rs['mesh_ms']), 'clocks_after': read_clocks()}
         del rs
 
-    # ---- SECONDARY: the same job with the tape evaluated in float32, and how far its soup is from the float64 one ----
-    env32 = None
-    if world == 1 and args.precision == 'f64' and not args.no_f32_envelope and not args.no_check:
-        trace('float32 envelope')
-        env32 = f32_envelope(eng, tape, X, Y, Z)
-
     # ---- BASELINE configs 3 - 5 at their real sizes (every rank takes part; a few steps each).  This section comes LAST
     # and, for N > 1, under a watchdog: it is the one place where a rank-local failure (an allocation that fails on one
     # rank only) would leave the other ranks inside a collective for ever, and the headline line must not depend on it ----
@@ -779,7 +713,6 @@ def main():
         'roofline': roofline,
         'cpu_baseline': cpu_ref if cpu_ref is not None else cpu,
         'cpu_port': cpu,
-        'f32_envelope': env32,
         'other_configs': None,
     }
     if want_others:

@@ -24,10 +24,10 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 6
+#define SDF_ABI_VERSION 7
 
-#define SDF_PRECISION_F64 0 /* parity mode: float64 sampling like the reference's NumPy path */
-#define SDF_PRECISION_F32 1 /* fast mode: float32 sampling */
+#define SDF_PRECISION_F64 0 /* float64 evaluation like the reference's NumPy path: what every sdf_generate* entry point samples in */
+#define SDF_PRECISION_F32 1 /* float32 evaluation: sdf_eval_* and sdf_estimate_bounds only (the meshing path refuses it since round 5) */
 
 typedef struct sdf_ctx sdf_ctx;   /* one HIP device + stream + scratch arenas            */
 typedef struct sdf_tape sdf_tape; /* a lowered model (op tape + constants) on the device */
@@ -62,6 +62,8 @@ typedef struct sdf_stats {
 } sdf_stats;
 
 int sdf_abi_version(void);
+/* what built this library: the compiler's version lines and the interpreters' flags, as csrc/build.sh recorded them (ABI 7) */
+const char *sdf_build_info(void);
 const char *sdf_last_error(void);
 int sdf_device_count(void); /* <= 0 when no HIP device is usable */
 

@@ -2,8 +2,8 @@
 # Builds libsdf_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
 # -ffp-contract=off: the interpreter must round like NumPy (separate multiply and add);
 # fused multiply-adds are written explicitly where the reference goes through BLAS.
-# The fused sample+march kernel is instantiated per (precision, trig) family in its own
-# translation unit so the families compile in parallel.
+# The fused sample+march kernel is instantiated per family (float64, with / without the trigonometric ops) in its own
+# translation unit so the families compile in parallel.  (float32 sampling of the meshing path: removed in round 5.)
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
@@ -15,16 +15,18 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -mllvm -structurizecfg-skip-uniform-regions=1"
 mkdir -p build
 rm -f libsdf_hip.so build/*.o
+# what built the library goes INTO the library (sdf_build_info(): compiler version + the interpreters' flags): a box without the
+# test suite can still say which toolchain its .so came from; tools/isa_check.py (run by build()) checks what that toolchain made
+INFO="$($HIPCC --version | grep -m1 -i 'HIP version' | tr -d '"' | sed 's/^ *//'); $($HIPCC --version | grep -m1 -i 'clang version' | tr -d '"' | cut -c1-60); flags: $FLAGS"
 pids=""
-$HIPCC $FLAGS -c -o build/sdf_hip.o sdf_hip.hip "$@" & pids="$pids $!"
+$HIPCC $FLAGS "-DSDF_BUILD_INFO=\"$INFO\"" -c -o build/sdf_hip.o sdf_hip.hip "$@" & pids="$pids $!"
+$HIPCC $FLAGS -c -o build/sdf_bounds.o sdf_bounds.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f64 -c -o build/mesh_f64.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f64_full -c -o build/mesh_f64_full.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
-$HIPCC $FLAGS -DMESH_T=float -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f32 -c -o build/mesh_f32.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
-$HIPCC $FLAGS -DMESH_T=float -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f32_full -c -o build/mesh_f32_full.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
 # (every kernel that is not a tape interpreter: built WITHOUT the structurizer option, see sdf_plain.hip)
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -c -o build/sdf_plain.o sdf_plain.hip "$@" & pids="$pids $!"
 # (the weld uses hipCUB's radix sort and scan; it has no floating-point arithmetic of its own)
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c -o build/sdf_weld.o sdf_weld.hip "$@" & pids="$pids $!"
 for p in $pids; do wait $p; done
 exec $HIPCC --offload-arch=gfx950 -fPIC -shared -o libsdf_hip.so build/sdf_hip.o build/mesh_f64.o build/mesh_f64_full.o \
-    build/mesh_f32.o build/mesh_f32_full.o build/sdf_weld.o build/sdf_plain.o
+    build/sdf_bounds.o build/sdf_weld.o build/sdf_plain.o

@@ -1494,7 +1494,5 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     int NAME(int slots, int shape, int twopass, int grid, size_t lds, hipStream_t stream, const uint32_t *code, const T *consts, const MeshArgs &a)
 SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f64, double);
 SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f64_full, double);
-SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f32, float);
-SDF_DECLARE_MESH_LAUNCH(sdf_launch_mesh_f32_full, float);
 
 }  // namespace sdfk

@@ -46,6 +46,7 @@
 #include "sdf_prune.h"
 #include "sdf_slab.h"
 #include "sdf_plain.h"
+#include "sdf_bounds.h"
 
 using namespace sdfk;
 
@@ -104,70 +105,8 @@ __global__ __launch_bounds__(256) void k_eval_points_ext(const uint32_t *__restr
     if (!dump) out[i] = (double)v;
 }
 
-// `_estimate_bounds` (reference sdf/core.py:62-82) as ONE launch of ONE workgroup: up to 32 rounds of a 16^3 probe grid
-// (np.linspace per axis: lo + i * step, the last sample forced to hi), threshold = |d| / 2, the box of the samples with
-// |f| <= threshold, grown by half a probe cell -- float64 throughout, operation by operation like the reference (and
-// the oracle's restatement).  The host loop it replaces paid a kernel launch, two copies and a synchronisation per
-// round: 3 ms per model.  out[0..6) = lo, hi; out[6] = 1 when a round found no sample within its threshold (the
-// reference raises there: `where.max` of an empty array).
-// The rounds are a dependent chain (a round's grid is the previous round's hit box), so what counts is the latency of ONE
-// round.  Until r04 four workgroups shared a round's 4096 probes and met at a barrier in device memory after each: 25 us per
-// round, nearly all of it the barrier (atomics at agent scope, a polling loop, two fences) -- 0.8 ms per model, three times
-// the meshing of 512^3.  One workgroup of 1024 threads takes FOUR probes per lane and needs `__syncthreads` only: ~ 7 us per
-// round (r05).
-template <typename T, bool FULL>
-__global__ __launch_bounds__(1024) void k_estimate_bounds(const uint32_t *__restrict__ code, const T *__restrict__ consts, double *__restrict__ out) {
-    __shared__ double ax[3][16];
-    __shared__ double lo[3], hi[3], d[3], thr, prev;
-    __shared__ int box[6], stop;
-    const int tid = threadIdx.x;
-    if (tid < 3) { lo[tid] = -1e9; hi[tid] = 1e9; }
-    if (tid == 0) { prev = -1.0; stop = 0; }
-    __syncthreads();
-    for (int it = 0; it < 32; it++) {
-        if (tid < 48) {
-            const int a = tid >> 4, i = tid & 15;
-            const double step = (hi[a] - lo[a]) / 15.0;
-            ax[a][i] = i == 15 ? hi[a] : lo[a] + (double)i * step;
-        }
-        if (tid < 6) box[tid] = 0;      // maxima of 16 - index (lower corner) and index + 1 (upper corner): 0 = no hit
-        __syncthreads();
-        if (tid == 0) {
-            for (int a = 0; a < 3; a++) d[a] = ax[a][1] - ax[a][0];
-            const double t = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) / 2;
-            if (it > 0 && t == prev) stop = 1;
-            prev = t; thr = t;
-        }
-        __syncthreads();
-        if (stop) break;
-        int b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
-#pragma unroll 1
-        for (int p = 0; p < 4; p++) {
-            const int q = p * 1024 + tid;
-            const int i = q >> 8, j = (q >> 4) & 15, k = q & 15;
-            const double v = (double)run_tape1<T, FULL>(code, consts, (T)ax[0][i], (T)ax[1][j], (T)ax[2][k]);
-            if (fabs(v) <= thr) {
-                b0 = max(b0, 16 - i); b1 = max(b1, 16 - j); b2 = max(b2, 16 - k);
-                b3 = max(b3, i + 1); b4 = max(b4, j + 1); b5 = max(b5, k + 1);
-            }
-        }
-        if (b3) {
-            atomicMax(&box[0], b0); atomicMax(&box[1], b1); atomicMax(&box[2], b2);
-            atomicMax(&box[3], b3); atomicMax(&box[4], b4); atomicMax(&box[5], b5);
-        }
-        __syncthreads();
-        if (box[3] == 0) { if (tid == 0) out[6] = 1.0; return; }       // no probe within the threshold
-        if (tid < 3) {
-            const double l0 = lo[tid];
-            const int mn = 16 - box[tid], mx = box[3 + tid] - 1;
-            hi[tid] = l0 + (double)mx * d[tid] + d[tid] / 2;
-            lo[tid] = l0 + (double)mn * d[tid] - d[tid] / 2;
-        }
-        __syncthreads();
-    }
-    if (tid < 3) { out[tid] = lo[tid]; out[3 + tid] = hi[tid]; }
-    if (tid == 0) out[6] = 0.0;
-}
+// (k_estimate_bounds -- `_estimate_bounds`, reference sdf/core.py:62-82, as one launch -- lives in sdf_bounds.hip: one interpreter per
+// register file, built next to this unit)
 
 // reference sdf/core.py:28-43.  9 lanes per batch, 7 batches per wave (lane 63 idles): lane 0 of a batch = centre,
 // lanes 1..8 = corners in itertools.product((x0,x1),(y0,y1),(z0,z1)) order.  kinds[b] = 0 (skipped) or 255 (pending).
@@ -628,6 +567,11 @@ static int ctx_init(sdf_ctx *c);
 extern "C" {
 
 int sdf_abi_version(void) { return SDF_ABI_VERSION; }
+
+#ifndef SDF_BUILD_INFO
+#define SDF_BUILD_INFO "unknown toolchain (not built by csrc/build.sh)"
+#endif
+const char *sdf_build_info(void) { return SDF_BUILD_INFO; }
 const char *sdf_last_error(void) { return g_err.c_str(); }
 
 int sdf_device_count(void) {
@@ -949,11 +893,20 @@ int sdf_estimate_bounds(sdf_tape *t, double *h_out6, int precision) {
     sdf_ctx *c = t->ctx;
     HIPCHK(set_device(c->device));
     if (c->scratch_out.ensure(2048)) return 1;
-    LAUNCH_TAPE(k_estimate_bounds, dim3(1), dim3(1024), 0, t, precision, (double *)c->scratch_out.p);
-    HIPCHK(hipGetLastError());
+    {
+        static const uint32_t kFile[4][2] = {{1, 1}, {2, 2}, {4, 4}, {8, 8}};     // (the register files sdf_bounds.hip instantiates)
+        const uint32_t np = std::max(t->n_p, 1u), nd = std::max(t->n_d, 1u);
+        int slots = 3;
+        for (int k = 3; k >= 0; k--) if (np <= kFile[k][0] && nd <= kFile[k][1]) slots = k;
+        const int rc = sdf_launch_bounds(precision == SDF_PRECISION_F64 ? 1 : 0, t->full ? 1 : 0, slots, c->stream, (const uint32_t *)t->d_code,
+                                         precision == SDF_PRECISION_F64 ? (const void *)t->d_c64 : (const void *)t->d_c32, (double *)c->scratch_out.p,
+                                         reinterpret_cast<int *>((char *)c->scratch_out.p + 64));
+        if (rc) return fail(std::string("k_estimate_bounds launch: ") + hipGetErrorString((hipError_t)rc));
+    }
     double h[7];
     HIPCHK(hipMemcpyAsync(h, c->scratch_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(stream_wait(c->stream));
+    if (h[6] == 2.0) return fail("sdf_estimate_bounds: the probe workgroups did not meet at their barrier (device busy): use the host loop");
     if (h[6] != 0.0) return fail("zero-size array to reduction operation maximum which has no identity");   // (NumPy's words, reference sdf/core.py:80)
     memcpy(h_out6, h, 48);
     return 0;
@@ -1089,13 +1042,9 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     // wherever that shape exists; the 8-slot file runs 1024 x 1
     int shape = slots <= 4 ? 3 : 0;
     if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
-    int rc;
-    if (precision == SDF_PRECISION_F64)
-        rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a)
-                     : sdf_launch_mesh_f64(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a);
-    else
-        rc = t->full ? sdf_launch_mesh_f32_full(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c32, a)
-                     : sdf_launch_mesh_f32(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c32, a);
+    if (precision != SDF_PRECISION_F64) return fail("k_mesh: float64 only");
+    const int rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a)
+                           : sdf_launch_mesh_f64(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a);
     if (rc) return fail(std::string("k_mesh launch: ") + hipGetErrorString((hipError_t)rc));
     return 0;
 }
@@ -1636,7 +1585,11 @@ static int generate_entry(sdf_tape *t, const double *X, int nx, const double *Y,
     if (bs > 32 && slab_items >= 0) return fail("sdf_generate_compact: batch_size must be in 1..32 (batches of more than 33^3 samples are not part of the multi-GPU exchange)");
     if (bs > 32 && d_kinds_in) return fail("sdf_generate_from_kinds: batch_size must be in 1..32");
     if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("sdf_generate: bad shard");
-    if (precision != SDF_PRECISION_F64 && precision != SDF_PRECISION_F32) return fail("sdf_generate: bad precision");
+    if (precision == SDF_PRECISION_F32)
+        return fail("sdf_generate: the meshing path samples in float64 (the reference's arithmetic); SDF_PRECISION_F32 was a diagnostic until round 4 -- "
+                    "outside the 1e-5 tolerance at its maximum, slower than float64 behind the interval passes -- and was removed; sdf_eval_* and "
+                    "sdf_estimate_bounds keep both precisions");
+    if (precision != SDF_PRECISION_F64) return fail("sdf_generate: bad precision");
     if (nx < 0 || ny < 0 || nz < 0) return fail("sdf_generate: negative axis length");
     sdf_ctx *c = t->ctx;
     HIPCHK(set_device(c->device));

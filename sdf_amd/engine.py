@@ -55,6 +55,7 @@ class SdfStats(ctypes.Structure):
 # name -> (restype, argtypes); this table is also what tests/test_host.py checks against the header
 ABI = {
     'sdf_abi_version': (ctypes.c_int, []),
+    'sdf_build_info': (ctypes.c_char_p, []),
     'sdf_last_error': (ctypes.c_char_p, []),
     'sdf_device_count': (ctypes.c_int, []),
     'sdf_device_mem_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
@@ -135,7 +136,12 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 6
+ABI_VERSION = 7
+
+
+def build_info():
+    """the toolchain that built the loaded library (csrc/build.sh records it: sdf_build_info)"""
+    return load_library().sdf_build_info().decode()
 
 
 def _strip_c_comments(text):

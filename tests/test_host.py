@@ -274,3 +274,28 @@ def test_bench_refuses_more_ranks_than_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=dict(env, RANK='0', WORLD_SIZE='3', LOCAL_RANK='0'),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=3' in (r.stderr + r.stdout)
+
+
+def test_build_self_check_and_build_info():
+    """tools/isa_check.py (run by __graft_entry__.build()): the tape interpreters of the built library carry their scalar
+    jump-table dispatch, the kernels of the plain translation units do not, every kernel the host launches is there; and the
+    library says which toolchain built it (sdf_build_info)"""
+    import subprocess
+    import sys
+    from sdf_amd import engine
+    engine.load_library()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_check.py'), engine.LIB_PATH], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert 'k_mesh<double, false, 1, 1, 2, 1024, false>' in r.stdout and 'ISA CHECK FAILED' not in r.stdout
+    info = engine.build_info()
+    assert 'HIP version' in info and 'structurizecfg-skip-uniform-regions' in info, info
+
+
+def test_source_id_ignores_comments_not_string_literals():
+    """engine.source_id() hashes the sources without their comments; a `//` inside a string or character literal is not one"""
+    from sdf_amd import engine
+    strip = engine._strip_c_comments
+    assert strip('a = "http://x"; // c1\n/* c2 */ b = \'"\'; c = "\\"//"; // end\nd') == 'a = "http://x"; \n b = \'"\'; c = "\\"//"; \nd'
+    assert strip('x /* a // b */ y // z') == 'x  y '
+    assert len(engine.source_id()) == 16
+
