@@ -410,14 +410,30 @@ def main():
 
     # parity check inside the bench run: the sha256 of the soup the LAST TIMED STEP left on the device
     # (copied out after the timed region) against the hash of the reference's own soup on this grid
-    check = soup_hash = None
+    # N > 1: EVERY rank hashes the soup IT holds after the exchange (rank-local: a transport bug that corrupts one rank's copy shows
+    # up as a parity failure of that rank, not as a hang); the verdicts -- one number per rank -- travel in one small all-gather
+    # behind the timed region
+    check = soup_hash = parity_per_rank = None
     if not args.no_check:
         last = state.get('soup')
-        if last is not None and tris * 9 <= last.numel() and rank == 0:
+        if last is not None and tris * 9 <= last.numel() and (rank == 0 or world > 1):
             soup_hash = soup_sha(last, tris)
-        if args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64' and rank == 0:
+        headline_job = args.model == 'example' and args.samples_log2 == 27 and args.precision == 'f64'
+        if headline_job:
             check = bool(soup_hash == EXAMPLE_S27_SHA256 and
                          (st['batches'], st['skipped'], st['empty'], st['nonempty'], tris) == (4096, 2352, 120, 1624, 2945152))
+        if td is not None:
+            mine_ok = torch.tensor([1.0 if (check if headline_job else soup_hash is not None) else 0.0,
+                                    float(int(soup_hash[:12], 16)) if soup_hash else -1.0], dtype=torch.float64, device=stat_dev)
+            allv = torch.empty(2 * world, dtype=torch.float64, device=stat_dev)
+            td.all_gather_into_tensor(allv, mine_ok)
+            allv = allv.cpu().numpy().reshape(world, 2)
+            # (every rank's verdict against the reference's hash, and whether all ranks hold the SAME soup: the first 48 bits of their hashes)
+            parity_per_rank = {'ok': [bool(v) for v in allv[:, 0]], 'all_ranks_hold_the_same_soup': bool(len(set(allv[:, 1].tolist())) == 1)}
+            if headline_job and rank == 0:
+                check = bool(check and all(parity_per_rank['ok']) and parity_per_rank['all_ranks_hold_the_same_soup'])
+        if rank != 0:
+            check = None
 
     # ---- ONE call at a time (single GPU): what a drop-in caller of generate() sees.  A warm-up burst, then >= 20
     # synchronous calls back to back, nothing else in flight; per call: wall time submit -> counters on the host,
@@ -707,6 +723,7 @@ def main():
                                              'collectives_per_step': st.get('chunks'), 'host_syncs_per_step': 1,
                                              'driver': st.get('exchange', 'torch.distributed (%s)' % backend)},
         'parity_check': check,
+        'parity_per_rank': parity_per_rank,
         'parity': {'soup_sha256': soup_hash, 'reference_sha256': EXAMPLE_S27_SHA256 if check is not None else None,
                    'what': 'sha256 of the float64 soup of the last timed step (copied from its device buffer after the '
                            'timed region) vs the unmodified reference on the same grid (tests/golden/full_c2_example_s27.npz)'},
