@@ -105,8 +105,7 @@ __global__ __launch_bounds__(256) void k_eval_points_ext(const uint32_t *__restr
     if (!dump) out[i] = (double)v;
 }
 
-// (k_estimate_bounds -- `_estimate_bounds`, reference sdf/core.py:62-82, as one launch -- lives in sdf_bounds.hip: one interpreter per
-// register file, built next to this unit)
+// (k_estimate_bounds -- `_estimate_bounds`, reference sdf/core.py:62-82, as one launch -- lives in sdf_bounds.hip, built next to this unit)
 
 // reference sdf/core.py:28-43.  9 lanes per batch, 7 batches per wave (lane 63 idles): lane 0 of a batch = centre,
 // lanes 1..8 = corners in itertools.product((x0,x1),(y0,y1),(z0,z1)) order.  kinds[b] = 0 (skipped) or 255 (pending).
@@ -892,15 +891,11 @@ int sdf_estimate_bounds(sdf_tape *t, double *h_out6, int precision) {
     if (t->n_extern) return fail("sdf_estimate_bounds: the tape reads user closures (L_EXTERN): probe it through the *_extern_* entry points");
     sdf_ctx *c = t->ctx;
     HIPCHK(set_device(c->device));
-    if (c->scratch_out.ensure(2048)) return 1;
+    if (c->scratch_out.ensure(4096)) return 1;
     {
-        static const uint32_t kFile[4][2] = {{1, 1}, {2, 2}, {4, 4}, {8, 8}};     // (the register files sdf_bounds.hip instantiates)
-        const uint32_t np = std::max(t->n_p, 1u), nd = std::max(t->n_d, 1u);
-        int slots = 3;
-        for (int k = 3; k >= 0; k--) if (np <= kFile[k][0] && nd <= kFile[k][1]) slots = k;
-        const int rc = sdf_launch_bounds(precision == SDF_PRECISION_F64 ? 1 : 0, t->full ? 1 : 0, slots, c->stream, (const uint32_t *)t->d_code,
+        const int rc = sdf_launch_bounds(precision == SDF_PRECISION_F64 ? 1 : 0, t->full ? 1 : 0, c->stream, (const uint32_t *)t->d_code,
                                          precision == SDF_PRECISION_F64 ? (const void *)t->d_c64 : (const void *)t->d_c32, (double *)c->scratch_out.p,
-                                         reinterpret_cast<int *>((char *)c->scratch_out.p + 64));
+                                         (char *)c->scratch_out.p + 64);
         if (rc) return fail(std::string("k_estimate_bounds launch: ") + hipGetErrorString((hipError_t)rc));
     }
     double h[7];

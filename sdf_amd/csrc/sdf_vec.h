@@ -104,15 +104,6 @@ template <typename T> SDF_DEV void late_bind(Vec<T, 2> &a, Vec<T, 2> &b, Vec<T, 
     asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(c.v[0]), "+v"(c.v[1]));
 }
 
-// (four samples per lane: k_estimate_bounds, sdf_bounds.hip)
-template <typename T> SDF_DEV void late_bind(Vec<T, 4> &a, Vec<T, 4> &b) {
-    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]));
-}
-template <typename T> SDF_DEV void late_bind(Vec<T, 4> &a, Vec<T, 4> &b, Vec<T, 4> &c) {
-    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]),
-                      "+v"(c.v[0]), "+v"(c.v[1]), "+v"(c.v[2]), "+v"(c.v[3]));
-}
-
 // A copy the register coalescer cannot see through (an explicit v_mov): used where a value moves
 // from one piece of machine state to another and the two must keep their own home registers.
 SDF_DEV double real_move(double x) { double r; asm volatile("v_mov_b64 %0, %1" : "=v"(r) : "v"(x)); return r; }

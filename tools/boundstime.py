@@ -1,7 +1,5 @@
 """Time of `_estimate_bounds` on the device per model (GPU box only, diagnostics): python tools/boundstime.py
-(r03: one workgroup with four probes per lane instead of four workgroups and a spin barrier was measured and reverted:
-example 0.8 -> 1.17 ms, weave 4.0 -> 15.1 ms -- the rounds are latency-bound, four times the sequential tape work per lane
-costs more than the barrier.)"""
+(the variants that were measured: csrc/sdf_bounds.hip)"""
 import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
 import sdf_amd, fixtures
