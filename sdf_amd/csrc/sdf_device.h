@@ -673,7 +673,14 @@ __device__ __forceinline__ int cull_tasks(const uint32_t *wcode, const double *c
 enum { MESH_SLOT_HDR = 1232, MESH_SLOT_COLINFO = 64, MESH_STAGE_BYTES = 32 * 9 * 4 };   // (a wave transposes its 64 triangles in two halves)
 
 template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK, bool TWOPASS = false>
-__global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a) {
+__global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ code, const T *__restrict__ consts, MeshArgs a_byval) {
+    // (the argument block is read from the kernel-argument segment where it is used -- a scalar load from constant memory, two
+    // words of pointer to keep -- instead of living in ~ 80 scalar registers that the round structure then spills)
+    typedef __attribute__((address_space(4))) const MeshArgs KArgs;
+    KArgs *ap = (KArgs *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + 16);
+    (void)a_byval;
+#define a (*ap)
+#define SDF_SINK (Tri16Sink{a.out, a.raw, a.raw_cap, &a.ctr->n_raw})
     typedef Vec<T, NS> V;
     constexpr int RPT = 1024 / BLOCK;   // (i0, i1) rows of cells per thread (a tile has <= 32 x 32 rows)
     constexpr int MESH_CELL_CHUNKS = 2;
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     // from it is worked out again there instead of being kept -- i.e. spilled -- across the interpreter
     int tid = threadIdx.x;
 #define SDF_FRESH() asm volatile("" : "+v"(tid))
-    const GridDesc g = a.g;
+    const GridDesc g = a_byval.g;
     // the triangle table in LDS: edge ids e0 | e1 << 4 | e2 << 8 of triangle j of configuration cfg at [5 cfg + j] (a
     // non-ambiguous configuration has at most 5).  The emission used to fetch them as three byte loads from the 4 KB table in
     // device memory per triangle: 4.6 % of the kernel by knock-out (r04aj)
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     for (int t = tid; t < pend_total; t += BLOCK) {
                         float f[9];
                         SDF_UNROLL for (int q = 0; q < 9; q++) f[q] = src[(size_t)t * 9 + q];
-                        store_tri16(a, pbase + (unsigned long long)t, f);
+                        store_tri16(SDF_SINK, pbase + (unsigned long long)t, f);
                     }
                 } else
                 for (int e0 = tid; e0 < n9; e0 += BLOCK * U) {
@@ -816,6 +823,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     bool have = false;         // ... and its batch index / header are in bcast[9..10], record and axes in LDS
     for (;;) {
         SDF_FRESH();
+        asm volatile("" : "+s"(ap));
         dq_slot = uni(dq_slot); pq_head = uni(pq_head); pq_count = uni(pq_count);   // (uniform by construction)
         if (!carry) {
             if (nx_valid) {   // (uniform) drawn during the last round's emission; visible since that round's last barrier
@@ -1424,7 +1432,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         mc_vertex_view(vw, i0, i1, i2, (int)(tt3 >> 8), o + 6);
                     }
                     if (a.compact && !parking) {   // (uniform) the exchange's 16-byte record, straight from the registers
-                        if (live) store_tri16(a, base + (unsigned long long)(lo + t), o);
+                        if (live) store_tri16(SDF_SINK, base + (unsigned long long)(lo + t), o);
                     } else if (staged) {
                         // through LDS: lane l holds triangle t0 + l (9 floats); afterwards lane l stores coordinates 64 k + l,
                         // k = 0 .. 8, of the wave's 576: consecutive lanes, consecutive addresses.  Coordinate c belongs to axis
@@ -1486,6 +1494,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
 #undef SDF_FRESH
 #undef SDF_PROF
 }
+#undef a
+#undef SDF_SINK
 
 // host-side launcher of one (T, FULL) family, defined in sdf_mesh_inst.hip (one translation
 // unit per family so the variants compile in parallel).  slots: 0 = (1,1), 1 = (2,2), 2 = (4,2), 3 = (2,4), 4 = (4,4), 5 = (8,8)
