@@ -210,6 +210,52 @@ def stats3(v):
     return {'min': round(float(v.min()), 4), 'median': round(float(np.median(v)), 4), 'max': round(float(v.max()), 4), 'n': int(len(v))}
 
 
+def _oracle_chunk(job):
+    """worker of whole_soup_vs_oracle (its own process, no GPU): the checker's soup of batches [b0, b1) of a model's grid"""
+    model, bounds, log2, b0, b1 = job
+    import oracle
+    from sdf_amd import core
+    f, _ = build_model(model)
+    X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** log2)
+    return b0, oracle.generate(f, X, Y, Z, 32, True, batch_range=(b0, b1)).points
+
+
+def whole_soup_vs_oracle(model, bounds, log2, soup_host, n_batches, budget_cores=128):
+    """EVERY coordinate of a soup against the CPU checker's (oracle/sdf_oracle.c, the reference's algorithm restated): the checker
+    meshes the grid's batches in pieces on the host's cores (processes of their own), the pieces come back in order and are
+    compared with the soup where it stands.  Returns counts -- how many coordinates differ at all, the largest difference over
+    the grid's extent -- not a verdict: models that go through libm (sin / cos / atan2: gearlike, weave) are pinned by tolerance."""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, budget_cores))
+    pieces = max(cores * 4, 8)
+    cuts = [n_batches * i // pieces for i in range(pieces + 1)]
+    jobs = [(model, bounds, log2, cuts[i], cuts[i + 1]) for i in range(pieces) if cuts[i + 1] > cuts[i]]
+    extent = float(np.ptp(np.asarray(bounds), axis=0).max())
+    pos = differ = 0
+    worst = 0.0
+    t0 = time.perf_counter()
+    with mp.get_context('spawn').Pool(cores) as pool:
+        it = pool.imap(_oracle_chunk, jobs)
+        for _ in jobs:
+            try:
+                _, pts = it.next(timeout=max(5.0, 240.0 - (time.perf_counter() - t0)))     # (the whole comparison within four minutes, or not at all)
+            except mp.TimeoutError:
+                return {'error': 'the checker did not finish within 240 s on %d host processes' % cores, 'vertices_compared': pos}
+            n = len(pts)
+            if pos + n > len(soup_host):
+                return {'error': 'the checker has more triangles than the soup', 'at_vertex': pos}
+            mine = soup_host[pos:pos + n]
+            ne = mine != pts
+            differ += int(ne.sum())
+            if ne.any():
+                worst = max(worst, float(np.abs(mine - pts)[ne].max()))
+            pos += n
+    return {'vertices': pos, 'vertices_expected': int(len(soup_host)), 'coordinates': 3 * pos, 'coordinates_that_differ': differ,
+            'share_bit_equal': round(1.0 - differ / max(3 * pos, 1), 9), 'max_abs_diff_over_extent': worst / extent,
+            'within_1e-5': bool(pos == len(soup_host) and worst / extent <= 1e-5), 'checker_seconds': round(time.perf_counter() - t0, 1),
+            'host_processes': cores, 'what': 'every coordinate of the soup against oracle/sdf_oracle.c meshing the whole grid on the host'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -570,6 +616,14 @@ def main():
                         o['reference_sampled_triangles'] = {'n': int(len(ref_tris)), 'stride': stride, 'max_abs_dev_over_extent': dev,
                                                             'bit_equal_share': round(float((mine == ref_tris).mean()), 6) if dev is not None else None,
                                                             'within_1e-5': bool(dev is not None and dev <= 1e-5)}
+                # ... and the WHOLE soup, coordinate by coordinate, against the CPU checker meshing the same grid on the host's cores
+                # (single GPU, rank 0; weave at 2**33 is ~ 4400 core-seconds of checker: only where the host has the cores)
+                if world == 1 and rank == 0 and not args.no_check and not args.no_cpu_baseline and r['state'].get('soup') is not None \
+                        and (model != 'weave' or (os.cpu_count() or 1) >= 64):
+                    trace('whole soup of %s against the checker' % model)
+                    host = r['state']['soup'][:9 * t2].cpu().numpy().reshape(-1, 3)
+                    o['whole_soup_vs_oracle'] = whole_soup_vs_oracle(model, core._estimate_bounds(r['f']), log2, host, int(s2['batches']))
+                    del host
                 others.append(o)
                 del r
             except Exception as e:          # (reported, never fatal for the headline line)
