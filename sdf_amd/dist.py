@@ -165,7 +165,8 @@ def _job(eng, tape, X, Y, Z, batch_size, sparse, device, group, chunks):
         chunks = int(os.environ.get('SDF_DIST_CHUNKS', '1'))
     C = max(1, min(int(chunks), MAX_SLABS // max(world, 1)))
     # sdf_expand_slabs takes at most MAX_SLABS slabs per call: a larger world ships the float64 soup through host memory
-    on_device = device.type == 'cuda' and hasattr(eng, 'generate_compact') and not externs and world * C <= MAX_SLABS
+    # (batch_size > 32 goes through device memory in chunks, csrc generate_big: its soup comes back like a closure model's)
+    on_device = device.type == 'cuda' and hasattr(eng, 'generate_compact') and not externs and world * C <= MAX_SLABS and int(batch_size) <= 32
     codec = DeviceCodec(eng) if on_device else HostCodec(eng)
     s = int(batch_size)
     nb = (-(-len(X) // s)) * (-(-len(Y) // s)) * (-(-len(Z) // s))
@@ -287,7 +288,9 @@ def submit_sharded(eng, tape, X, Y, Z, batch_size, sparse, device=None, group=No
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if td.get_backend(group) == 'nccl' else torch.device('cpu')
     comm = None
-    if _native_ok(eng, td, tape, device, group) and not _NATIVE_BROKEN:
+    # (batch_size > 32 is not part of the native exchange -- sdf_generate_compact refuses it: the torch.distributed path below
+    # ships those soups as float64 through the host codec; a property of the call, the same on every rank)
+    if int(batch_size) <= 32 and _native_ok(eng, td, tape, device, group) and not _NATIVE_BROKEN:
         try:
             comm = _native_comm(eng, td, group)
         except Exception as e:       # (librccl not loadable, communicator refused: every rank fails alike and takes the torch path)

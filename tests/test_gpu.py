@@ -424,6 +424,11 @@ def test_sharded_generate_over_rccl_single_rank(driver, ns, eng, monkeypatch):
             assert np.array_equal(soup.cpu().numpy().reshape(-1, 3), w) and st['triangles'] == len(w) // 3
         pts = f.generate(bounds=tuple(map(tuple, d['bounds'])), step=d['step'].tolist(), verbose=False)
         assert np.array_equal(pts, want)          # core.generate takes the sharded route when dist is up
+        # batch_size > 32 is not part of the 16-byte exchange: its soup travels as float64 through torch.distributed, whatever the driver
+        big = eng.generate(f, X, Y, Z, 48)
+        want48 = big.points(); big.close()
+        pts = f.generate(bounds=tuple(map(tuple, d['bounds'])), step=d['step'].tolist(), batch_size=48, verbose=False)
+        assert np.array_equal(pts, want48)
     finally:
         dist.shutdown_native()
         td.destroy_process_group()
@@ -1406,6 +1411,38 @@ def test_tail_of_the_work_list_by_cost_or_in_order_same_soup(name, samples, ns, 
         for k in ('triangles', 'skipped', 'empty', 'nonempty', 'n_eval_voxels', 'n_ambiguous_cells', 'n_sampled_voxels', 'n_pruned_instrs'):
             assert r[3][k] == ref[3][k], (smp, mode, on, k)
     assert res[(samples, 0, 0)][3]['triangles'] > 1000
+
+
+def test_rare_paths_of_the_one_kernel_scheme_on_a_lattice_of_small_spheres(ns, oracle_lib, eng):
+    """k_mesh's rarely taken branches in one job (the round-4 advisor asked for it): a lattice of small spheres puts > 2048 surface
+    cells and more triangles than the LDS list holds into most tiles -- the per-row counting, the list rebuilt in passes, dense
+    tiles (too many units for a slot) next to sparse ones at the lattice's edge (a dense tile takes the slots' region: the waiting
+    batch is written first, the work item carried over), batches written right behind their counting next to deferred ones,
+    the park slots in use -- with the tail of the list in cost order and in list order, deferred and not, two and three interval
+    levels: every soup equal to the checker's, bit for bit."""
+    f = ns['sphere'](0.055).repeat(0.17) & ns['box'](1.7)
+    X, Y, Z, _ = core.grid_axes(((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)), samples=2 ** 23)      # 203^3: 343 batches, ragged far tiles
+    o = oracle_lib.generate(f, X, Y, Z, 32, True)
+    assert len(o.points) // 3 > 400000
+    res = []
+    try:
+        eng.set_twopass(0)
+        for defer, levels, tail in ((1, 0, 1), (1, 0, 0), (0, 0, 1), (1, 3, 1), (1, 2, 0)):
+            eng.set_defer(defer); eng.set_cull_levels(levels); eng.set_tail_order(tail)
+            m = eng.generate(f, X, Y, Z, 32, True)
+            res.append(((defer, levels, tail), m.points(), m.kinds(), m.stats()))
+            m.close()
+        eng.set_twopass(1)
+        m = eng.generate(f, X, Y, Z, 32, True)
+        res.append(('two-pass', m.points(), m.kinds(), m.stats()))
+        m.close()
+    finally:
+        eng.set_twopass(-1); eng.set_defer(1); eng.set_cull_levels(0); eng.set_tail_order(1)
+    per_tile = max(r[3]['triangles'] for r in res) / max(1, res[0][3]['nonempty'])
+    assert per_tile > 3000, per_tile            # (the list of a dense tile holds ~ 2400 entries: passes are needed)
+    for key, pts, kinds, st in res:
+        assert np.array_equal(kinds, o.kinds), key
+        assert np.array_equal(pts, o.points), key
 
 
 @pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 24), ('ex_example', 1500000), ('ex_blobby', 2 ** 23), ('ex_gearlike', 2 ** 22),
