@@ -20,7 +20,11 @@ Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kerne
 reference's own CPU path (NumPy thread pool + skimage; live where the reference is installed, else the committed
 build-container run, see `kind`), `cpu_port` = the C oracle timed live on one host core, `isolated_calls` = what ONE
 synchronous call costs (min / median / max over back-to-back calls with nothing else in flight: what a drop-in
-caller of f.generate() sees), `clocks`, `other_configs` = BASELINE configs 3 - 5 at their real sizes (a few steps each).
+caller of f.generate() sees), `generate_e2e` = `f.generate(samples=2**27)` on a fresh model end to end (bounds estimate, tape,
+meshing, the copy of the soup to the host: like for like with `cpu_baseline`), `sustained` = the headline job over 2000 steps
+with the shader clock the kernels measured, `clocks`, `other_configs` = BASELINE configs 3 - 5 at their real sizes (a few steps
+each; `whole_soup_vs_oracle`: every coordinate of their soups against the CPU checker meshing the same grid on the host's
+cores), `parity_per_rank` (N > 1: every rank hashes the soup it holds).
 """
 import argparse
 import gc
