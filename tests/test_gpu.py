@@ -1067,6 +1067,12 @@ def test_user_closure_save_and_errors(ns, eng, tmp_path):
         broken('raise').generate(samples=2 ** 12, bounds=((-1, -1, -1), (1, 1, 1)), verbose=False)
     # the engine is still usable afterwards
     assert len(g.generate(samples=2 ** 12, verbose=False)) > 0
+    # batch_size > 32 with a closure in the model (sdf_generate_field with a row-slot count per tile): the README's sphere IS the
+    # library's sphere, whose soup at that batch size is the checker's (test_batch_size_above_32_goes_through_device_memory)
+    for bs in (40, 64):
+        a = f.generate(samples=2 ** 17, batch_size=bs, verbose=False)
+        b = g.generate(samples=2 ** 17, batch_size=bs, verbose=False)
+        assert len(a) > 1000 and np.array_equal(a, b)
 
 
 # ---- the voxel-grid leaf of Mesh.sdf (reference sdf/mesh.py:96-105) ----
