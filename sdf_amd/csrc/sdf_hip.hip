@@ -1,11 +1,12 @@
-// sdf_hip.hip -- the tape-interpreter kernels (k_eval_*, k_estimate_bounds, k_skip, k_prune_list, k_cull) + the C ABI of
-// libsdf_hip.so (gfx950 only).  k_mesh is instantiated in sdf_mesh_inst.hip; every kernel that is not an interpreter
-// (k_compact, k_scan_items, k_emit2, k_pack_slab, k_expand, k_mc_*, k_field_*, k_cast_f32, k_stl) in sdf_plain.hip.
+// sdf_hip.hip -- the tape-interpreter kernels (k_eval_*, k_skip, k_prune_list, k_cull) + the C ABI of libsdf_hip.so (gfx950
+// only).  k_mesh is instantiated in sdf_mesh_inst.hip, k_estimate_bounds in sdf_bounds.hip; every kernel that is not an
+// interpreter (k_compact, k_scan_items, k_emit2, k_pack_slab, k_expand, k_mc_*, k_field_*, k_cast_f32, k_stl) in sdf_plain.hip.
 //
 // Kernels (one call of sdf_generate enqueues k_skip -> k_compact [-> k_prune_list] -> k_cull -> k_mesh
 // [-> k_scan_items -> k_emit2] on one stream, without a host round trip in between)
 //   k_eval_points / k_eval_grid   f(P): the tape interpreter alone; k_eval_points_ext: with user closures (L_EXTERN)
-//   k_estimate_bounds             the reference's `_estimate_bounds` loop (sdf/core.py:62-82) as one launch
+//   k_eval_tiles                  the float32 volumes of a chunk of batches of more than 33^3 samples (batch_size > 32: generate_big)
+//   k_estimate_bounds             the reference's `_estimate_bounds` loop (sdf/core.py:62-82) as one launch (sdf_bounds.hip)
 //   k_skip                        the reference's `_skip` predicate for every batch at once
 //                                 (reference sdf/core.py:28-43), 9 lanes per batch, 7 batches per wave; its surplus
 //                                 workgroups run the interval pruning pass of the same batches (sdf_prune.h)
