@@ -1333,10 +1333,14 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         a.ctr = (MeshCounters *)m->counters.p;
         a.mc = (const McTables *)c->mc.p;
         a.prof = (unsigned long long *)c->prof.p;
+        // One pass or two?  (decided here: the two-pass scheme parks nothing -- its triangles are numbered by k_scan_items -- so a
+        // call that takes it does not make its lane allocate park slots: 1.2 GB that the long jobs' lanes never touched, r04 advisor)
+        const bool twopass = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
         DevBuf &park = async_mode ? cs.park : c->park;   // (k_mesh kernels of calls in flight may overlap in time, whichever
                                                          // streams they run on: each call slot has its own staging slots)
-        if (c->parking && !park.p) { quiet = false; if (park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
-        a.park = c->parking ? (float *)park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
+        const bool parks = c->parking && !twopass;
+        if (parks && !park.p) { quiet = false; if (park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
+        a.park = parks ? (float *)park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
         a.park_spins = (unsigned)c->park_spins;
         a.cull = culling ? (const unsigned char *)m->cull.p : nullptr;
         a.tape_stride = pruning ? tape_stride : 0;
@@ -1347,7 +1351,6 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         // two-pass one moves a third of the bytes (9 GB against 25 GB per call: no parking, and the 4-slot sampling
         // kernel spills less without the emit phases): the tape's length decides (sdf_ctx_set_twopass / SDF_MESH_TWOPASS
         // override).
-        const bool twopass = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
         if (twopass) {
             // the arenas of the two-pass scheme: a surface cell carries at least one triangle, so the soup's capacity
             // bounds both (a call whose arenas turn out too small is flagged and repeated like one whose soup is)
