@@ -299,3 +299,35 @@ def test_source_id_ignores_comments_not_string_literals():
     assert strip('x /* a // b */ y // z') == 'x  y '
     assert len(engine.source_id()) == 16
 
+
+def test_bench_whole_soup_comparison_counts_differences(ns):
+    """bench.py's `whole_soup_vs_oracle` (every coordinate of a config's soup against the checker meshing the grid in processes of
+    their own): a soup that IS the checker's differs nowhere; one perturbed coordinate is counted, with its size"""
+    import subprocess
+    import sys
+    script = '''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, bench, oracle
+from sdf_amd import core
+if __name__ == '__main__':
+    f, _ = bench.build_model('gearlike')
+    bounds = ((-2.1, -2.1, -0.6), (2.1, 2.1, 0.6))
+    X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** 19)
+    nb = (-(-len(X) // 32)) * (-(-len(Y) // 32)) * (-(-len(Z) // 32))
+    ref = oracle.generate(f, X, Y, Z, 32, True).points
+    a = bench.whole_soup_vs_oracle('gearlike', bounds, 19, ref, nb, budget_cores=3)
+    host = ref.copy(); host[len(host) // 2, 1] += 1e-7
+    b = bench.whole_soup_vs_oracle('gearlike', bounds, 19, host, nb, budget_cores=3)
+    assert a['coordinates_that_differ'] == 0 and a['whole_soup'] and a['within_1e-5'] and a['vertices'] == len(ref), a
+    assert b['coordinates_that_differ'] == 1 and abs(b['max_abs_diff_over_extent'] * 4.2 - 1e-7) < 1e-12 and b['whole_soup'], b
+    print('ok', a['vertices'])
+''' % ROOT
+    path = os.path.join(ROOT, 'tests', '_whole_soup_check.py')
+    try:
+        open(path, 'w').write(script)         # (a real file: the spawned workers import the main module)
+        r = subprocess.run([sys.executable, path], capture_output=True, text=True, timeout=600)
+    finally:
+        os.remove(path)
+    assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-1500:] + r.stderr[-3000:]
+
