@@ -468,6 +468,9 @@ struct sdf_ctx {
     int twopass = -1;                 // SDF_MESH_TWOPASS=0 / 1: force the one-pass k_mesh (look-back + parking) resp. k_mesh / k_scan_items / k_emit2
     int defer = 1;                    // SDF_DEFER=0: k_mesh keeps every tile dense and writes (or parks) a batch's triangles right after counting it
     int cull_levels = 0;              // SDF_CULL_LEVELS=2 / 3: interval levels of k_cull (3: + sub-groups of 2^3 cells); 0: by the tape (see generate_impl)
+    DevBuf bounds_work;               // k_estimate_bounds_w: the waves' exchange words (tagged per call, sdf_bounds.hip)
+    unsigned bounds_tag = 0, bounds_tag0 = 0;
+    int bounds_waves = 1;             // SDF_BOUNDS_WAVES=0: the four-workgroup form of r05h (A/B)
 };
 
 struct sdf_tape {
@@ -618,7 +621,7 @@ static int ctx_init(sdf_ctx *c) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(host_malloc(&c->h_stage, (size_t)SDF_CALL_SLOTS * SDF_STAGE_BYTES));
+    HIPCHK(host_malloc(&c->h_stage, (size_t)SDF_CALL_SLOTS * SDF_STAGE_BYTES + 4096));   // (+ the bounds estimate's result, sdf_estimate_bounds)
     for (auto &cs : c->slots) {
         HIPCHK(hipEventCreate(&cs.e0)); HIPCHK(hipEventCreate(&cs.e2)); HIPCHK(hipEventCreate(&cs.e3)); HIPCHK(hipEventCreate(&cs.e4));
         HIPCHK(hipEventCreateWithFlags(&cs.done, hipEventDisableTiming));
@@ -635,6 +638,8 @@ static int ctx_init(sdf_ctx *c) {
     memcpy(t.mc33, MC33_FLAT, sizeof(t.mc33));
     if (c->mc.ensure(sizeof(t))) return 1;
     HIPCHK(hipMemcpy(c->mc.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    if (const char *e = getenv("SDF_BOUNDS_WAVES")) c->bounds_waves = atoi(e);
+    if (const char *e = getenv("SDF_BOUNDS_TAG0")) c->bounds_tag0 = (unsigned)atoi(e) & 0xFFFFu;   // (tests: the first tag of the exchange words)
     if (const char *e = getenv("SDF_MESH_SHAPE")) c->mesh_shape = atoi(e);
     if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
     if (const char *e = getenv("SDF_PRUNE")) c->prune = atoi(e);
@@ -654,7 +659,7 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     (void)stream_wait(c->stream);
     for (auto &cs : c->slots) { if (cs.stream) (void)stream_wait(cs.stream); cs.park.release(); }
     for (DevBuf *b : {&c->scratch_in, &c->scratch_out, &c->rows, &c->rows_off, &c->mc, &c->prof, &c->park, &c->ext, &c->field_vals,
-                      &c->field_vol, &c->field_tiles})
+                      &c->field_vol, &c->field_tiles, &c->bounds_work})
         b->release();
     for (auto &b : c->arena_pool) b.release();
     for (auto &b : c->counter_pool) b.release();
@@ -893,14 +898,29 @@ int sdf_estimate_bounds(sdf_tape *t, double *h_out6, int precision) {
     sdf_ctx *c = t->ctx;
     HIPCHK(set_device(c->device));
     if (c->scratch_out.ensure(4096)) return 1;
+    // the waves' exchange words are tagged per call instead of zeroed per call (sdf_bounds.hip): cleared when the buffer is new and when
+    // the 16-bit tag wraps
+    unsigned tag = 0;
+    void *work = (char *)c->scratch_out.p + 64;
+    if (c->bounds_waves) {
+        if (!c->bounds_work.p || c->bounds_tag >= 65535u) {
+            if (c->bounds_work.ensure(SDF_BOUNDS_WORK_BYTES)) return 1;
+            HIPCHK(hipMemsetAsync(c->bounds_work.p, 0, SDF_BOUNDS_WORK_BYTES, c->stream));
+            c->bounds_tag = c->bounds_tag0; c->bounds_tag0 = 0;
+        }
+        tag = ++c->bounds_tag;
+        work = c->bounds_work.p;
+    }
     {
         const int rc = sdf_launch_bounds(precision == SDF_PRECISION_F64 ? 1 : 0, t->full ? 1 : 0, c->stream, (const uint32_t *)t->d_code,
                                          precision == SDF_PRECISION_F64 ? (const void *)t->d_c64 : (const void *)t->d_c32, (double *)c->scratch_out.p,
-                                         (char *)c->scratch_out.p + 64);
+                                         work, tag);
         if (rc) return fail(std::string("k_estimate_bounds launch: ") + hipGetErrorString((hipError_t)rc));
     }
-    double h[7];
-    HIPCHK(hipMemcpyAsync(h, c->scratch_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    // (the seven doubles land in pinned memory behind the call slots' staging: a copy into pageable memory goes through the runtime's
+    // own staging and a second host copy)
+    double *h = (double *)((char *)c->h_stage + (size_t)SDF_CALL_SLOTS * SDF_STAGE_BYTES);
+    HIPCHK(hipMemcpyAsync(h, c->scratch_out.p, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(stream_wait(c->stream));
     if (h[6] == 2.0) return fail("sdf_estimate_bounds: the probe workgroups did not meet at their barrier (device busy): use the host loop");
     if (h[6] != 0.0) return fail("zero-size array to reduction operation maximum which has no identity");   // (NumPy's words, reference sdf/core.py:80)

@@ -1277,6 +1277,32 @@ def test_estimate_bounds_failure_is_numpys(ns):
     assert np.array_equal(np.array(core._estimate_bounds(f)), CUSTOM['bounds_custom_leaf_in_example'])
 
 
+def test_bounds_exchange_words_survive_the_tag_wrapping():
+    """k_estimate_bounds_w's waves exchange a word per round that carries the CALL's 16-bit tag instead of being zeroed per call
+    (csrc/sdf_bounds.hip); the host clears the words when the tag wraps.  A context whose first tag is 65530 (SDF_BOUNDS_TAG0) runs
+    through the wrap: the same bounds before, at and after it, for two models in turn (stale words of the other model under every tag)"""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import sdf_amd, fixtures
+from sdf_amd import core
+ns = {k: getattr(sdf_amd, k) for k in dir(sdf_amd) if not k.startswith('_')}
+B = np.load(os.path.join(%r, 'bounds.npz'))
+fs = [(n, fixtures.build(n, ns)) for n in ('ex_example', 'ex_blobby', 'torus')]
+for rep in range(12):
+    for n, f in fs:
+        assert np.array_equal(np.array(core._estimate_bounds(f)), B[n]), (rep, n)
+print('ok')
+''' % (ROOT, ROOT, GOLDEN)
+    for waves in ('1', '0'):
+        r = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, SDF_BOUNDS_TAG0='65530', SDF_BOUNDS_WAVES=waves),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
 # ---- the two meshing schemes (one kernel with look-back + parking / sample + number + emit) give the same soup ----
 
 @pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 22), ('ex_gearlike', 2 ** 22), ('ex_blobby', 2 ** 23), ('ex_weave', 2 ** 22),
