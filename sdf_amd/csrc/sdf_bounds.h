@@ -1,7 +1,6 @@
-// sdf_bounds.h -- launcher of k_estimate_bounds (sdf_bounds.hip).  f64: SDF_PRECISION_F64; full: the tape uses the trigonometric ops;
+// sdf_bounds.h -- launcher of k_estimate_bounds_w (sdf_bounds.hip).  f64: SDF_PRECISION_F64; full: the tape uses the trigonometric ops;
 // work: SDF_BOUNDS_WORK_BYTES of device memory (the waves' per-round exchange words, 32 rounds x 64 waves); tag: 1 .. 65535, different
-// from the tag of every call since `work` was last zeroed (the words are NOT cleared per call); tag 0: the four-workgroup form of
-// r05h (zeroes its 32 x 4 words itself)
+// from the tag of every call since `work` was last zeroed (the words are NOT cleared per call)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

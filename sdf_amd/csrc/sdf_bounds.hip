@@ -5,122 +5,27 @@
 // a round found no sample within its threshold (the reference raises there: `where.max` of an empty array).
 //
 // The rounds are a dependent chain (a round's grid is the previous round's hit box), so what counts is the latency of ONE round: 4096
-// probes through the tape, then everybody needs the hit box.  A tape instruction of the one-sample interpreter takes ~ 500 cycles
-// whatever it computes (the scalar fetch of its words, the dispatch; sixteen waves per compute unit hide none of it from a single
-// lane), so a probe per lane on FOUR compute units is the shortest round there is: ~ 5 us for the example's tape.  Measured, r05h
-// (ms per model: example / gearlike / blobby / weave / knurling / pawn):
+// probes through the tape, then everybody needs the hit box.  Measured (ms per call incl. the host's share, per model: example /
+// gearlike / blobby / weave / knurling / pawn; r05h, the last two rows r05u on one box, alternating):
 //   four workgroups, six atomic maxima + arrival counter + polling + fences per round (r02 - r04)   0.80 /  -   /  -   / 4.0  /  -   /  -
 //   one workgroup, four probes per lane one after the other (`__syncthreads` only)                  0.78: the barrier was not the cost alone
 //   one workgroup of 512, eight probes per lane, four at a time through the interpreter (NS = 4)    0.58 / 0.80 / 1.10 / 3.5* / 1.63 / 0.86*
 //   two workgroups, two probes per lane at a time (NS = 2)                                          0.50 / 0.61 / 0.68 / 3.5* / 1.03 / 0.87*
-//   four workgroups, a probe per lane, the box as ONE word per workgroup and round (this file)      0.43 / 0.55 / 0.56 / 3.49 / 0.84 / 0.87
+//   four workgroups of 1024, a probe per lane, the box as ONE word per workgroup and round (r05h)   0.43 / 0.55 / 0.56 / 3.48 / 0.84 / 0.87
+//   SIXTY-FOUR workgroups of ONE wave, no barrier, the box as a bit mask per axis (this file)       0.17 / 0.21 / 0.29 / 2.13 / 0.36 / 0.45
 //   (* = the tape's register file has no room for NS > 1: the four-workgroup kernel ran)
+// What the table says: a tape instruction of the one-sample interpreter is a latency chain (the scalar fetch of its words, the
+// dispatch, a few dependent float64 operations), and a wave that shares its SIMD with three others -- 1024 lanes on one compute unit
+// -- waits for them at every link of it: ~ 500 cycles per instruction whatever it computes.  Alone on its SIMD the same wave takes a
+// third of that, and a workgroup of one wave has nothing to synchronise with but the other sixty-three once per round.
 // A translation unit of its own: built in parallel with the others (build.sh), with the interpreters' structurizer option.
 #include "sdf_interp.h"
 #include "sdf_bounds.h"
 
 using namespace sdfk;
 
-// NWG workgroups of BLOCK lanes share a round's 4096 probes, 4096 / (NWG * BLOCK) per lane, NS at a time through the interpreter.
-// NWG > 1: the workgroups keep in lockstep through device memory (they are co-resident on any gfx950: a handful of workgroups, 256
-// compute units); every workgroup carries the whole state -- the same arithmetic on the same reduced indices -- so nothing but the
-// round's hit box is exchanged, and that as ONE 64-bit word per workgroup and round: valid bit | six 5-bit fields (maxima of 16 -
-// index for the lower corner and of index + 1 for the upper one: 0 = no hit), stored once (release) into a slot of its own and read
-// by everybody (four lanes poll the round's four slots).  Until r04 the box went through six atomic maxima, an arrival counter, a
-// polling loop and two fences per round: ~ 19 us of a 25 us round.  out[6] = 2: the workgroups did not meet (the device was held by
-// other kernels for seconds).  `work`: 32 x NWG words, zeroed by the host.
-template <typename T, bool FULL, int NP, int ND, int NS, int BLOCK, int NWG>
-__global__ __launch_bounds__(BLOCK) void k_estimate_bounds(const uint32_t *__restrict__ code, const T *__restrict__ consts, double *__restrict__ out,
-                                                         unsigned long long *__restrict__ work) {
-    constexpr int PER_WG = 4096 / NWG, PER_LANE = PER_WG / BLOCK;
-    static_assert((NS == 1 || NS == 2 || NS == 4) && PER_LANE >= 1 && PER_LANE % NS == 0 && NWG <= 8, "probes per lane, NS at a time");
-    __shared__ double ax[3][16];
-    __shared__ double lo[3], hi[3], d[3], thr, prev;
-    __shared__ int box[6], stop;
-    const int tid = threadIdx.x;
-    if (tid < 3) { lo[tid] = -1e9; hi[tid] = 1e9; }
-    if (tid == 0) { prev = -1.0; stop = 0; }
-    __syncthreads();
-    for (int it = 0; it < 32; it++) {
-        if (tid < 48) {
-            const int a = tid >> 4, i = tid & 15;
-            const double step = (hi[a] - lo[a]) / 15.0;
-            ax[a][i] = i == 15 ? hi[a] : lo[a] + (double)i * step;
-        }
-        if (tid < 6) box[tid] = 0;
-        __syncthreads();
-        if (tid == 0) {
-            for (int a = 0; a < 3; a++) d[a] = ax[a][1] - ax[a][0];
-            const double t = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) / 2;
-            if (it > 0 && t == prev) stop = 1;
-            prev = t; thr = t;
-        }
-        __syncthreads();
-        if (stop) break;                                       // (every workgroup takes the same decision)
-        int b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
-#pragma unroll 1
-        for (int p0 = 0; p0 < PER_LANE; p0 += NS) {
-            Vec<T, NS> px, py, pz;
-            SDF_UNROLL
-            for (int k = 0; k < NS; k++) {
-                const int q = (int)blockIdx.x * PER_WG + (p0 + k) * BLOCK + tid;
-                px.v[k] = (T)ax[0][q >> 8]; py.v[k] = (T)ax[1][(q >> 4) & 15]; pz.v[k] = (T)ax[2][q & 15];
-            }
-            const Vec<T, NS> v = run_tape<T, FULL, NP, ND, NS>(code, consts, px, py, pz);
-            SDF_UNROLL
-            for (int k = 0; k < NS; k++) {
-                const int q = (int)blockIdx.x * PER_WG + (p0 + k) * BLOCK + tid;
-                const int i = q >> 8, j = (q >> 4) & 15, kk = q & 15;
-                if (fabs((double)v.v[k]) <= thr) {
-                    b0 = max(b0, 16 - i); b1 = max(b1, 16 - j); b2 = max(b2, 16 - kk);
-                    b3 = max(b3, i + 1); b4 = max(b4, j + 1); b5 = max(b5, kk + 1);
-                }
-            }
-        }
-        if (b3) {
-            atomicMax(&box[0], b0); atomicMax(&box[1], b1); atomicMax(&box[2], b2);
-            atomicMax(&box[3], b3); atomicMax(&box[4], b4); atomicMax(&box[5], b5);
-        }
-        __syncthreads();
-        if (NWG > 1) {
-            unsigned long long *slot = work + (size_t)it * NWG;
-            unsigned long long mine = 0;
-            if (tid == 0) {
-                mine = (1ull << 63) | (unsigned long long)box[0] | ((unsigned long long)box[1] << 5) | ((unsigned long long)box[2] << 10) |
-                       ((unsigned long long)box[3] << 15) | ((unsigned long long)box[4] << 20) | ((unsigned long long)box[5] << 25);
-                __hip_atomic_store(&slot[blockIdx.x], mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();                                    // (box is read above, merged into below)
-            if (tid < NWG && tid != (int)blockIdx.x) {
-                unsigned long long v = 0;
-                unsigned spins = 0;
-                while (!((v = __hip_atomic_load(&slot[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 63) && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(1);
-                // (a workgroup that gives up -- the others were not co-resident for seconds -- must not go on with a partial box)
-                if (!(v >> 63)) stop = 2;
-                for (int f = 0; f < 6; f++) atomicMax(&box[f], (int)((v >> (5 * f)) & 31ull));
-            }
-            __syncthreads();
-            if (stop == 2) { if (blockIdx.x == 0 && tid == 0) out[6] = 2.0; return; }
-        }
-        if (box[3] == 0) { if (blockIdx.x == 0 && tid == 0) out[6] = 1.0; return; }       // no probe within the threshold
-        if (tid < 3) {
-            const double l0 = lo[tid];
-            const int mn = 16 - box[tid], mx = box[3 + tid] - 1;
-            hi[tid] = l0 + (double)mx * d[tid] + d[tid] / 2;
-            lo[tid] = l0 + (double)mn * d[tid] - d[tid] / 2;
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) {
-        if (tid < 3) { out[tid] = lo[tid]; out[3 + tid] = hi[tid]; }
-        if (tid == 0) out[6] = 0.0;
-    }
-}
-
-// ---- the single-wave form (r05u) ------------------------------------------------------------------------------------------------
-// What a round costs is LATENCY, and a wave that shares its SIMD with three others waits for them at every instruction: the same 4096
-// probes as SIXTY-FOUR workgroups of ONE wave each -- a probe per lane, a wave per compute unit, nothing to share a SIMD with.  A
-// workgroup of one wave needs no `__syncthreads` at all: every lane carries the whole state (lo, hi, the previous threshold) in its own
+// The round's 4096 probes as SIXTY-FOUR workgroups of ONE wave each -- a probe per lane, a wave per compute unit.  A workgroup of one
+// wave needs no `__syncthreads` at all: every lane carries the whole state (lo, hi, the previous threshold) in its own
 // registers and does the round's scalar arithmetic itself -- the same operations in the same order on the same values in every lane of
 // every wave, so all of them take the same decisions.  The hit box travels as a BIT MASK (bit i of a 16-bit field per axis: some probe
 // with index i along that axis lies within the threshold), so that waves and lanes are combined by OR -- one wave reduction in the
@@ -181,11 +86,7 @@ __global__ __launch_bounds__(64) void k_estimate_bounds_w(const uint32_t *__rest
 
 template <typename T, bool FULL>
 static int launch_bounds_file(hipStream_t stream, const uint32_t *code, const T *consts, double *out, unsigned long long *work, unsigned tag) {
-    if (tag == 0) {   // the four-workgroup form (SDF_BOUNDS_WAVES=0: kept for A/B)
-        if (hipMemsetAsync(work, 0, 32 * 4 * sizeof(unsigned long long), stream) != hipSuccess) return (int)hipGetLastError();
-        hipLaunchKernelGGL((k_estimate_bounds<T, FULL, SDF_NP_SLOTS, SDF_ND_SLOTS, 1, 1024, 4>), dim3(4), dim3(1024), 0, stream, code, consts, out, work);
-    } else
-        hipLaunchKernelGGL((k_estimate_bounds_w<T, FULL, SDF_NP_SLOTS, SDF_ND_SLOTS>), dim3(BOUNDS_WAVES), dim3(64), 0, stream, code, consts, out, work, tag);
+    hipLaunchKernelGGL((k_estimate_bounds_w<T, FULL, SDF_NP_SLOTS, SDF_ND_SLOTS>), dim3(BOUNDS_WAVES), dim3(64), 0, stream, code, consts, out, work, tag);
     return (int)hipGetLastError();
 }
 

@@ -470,7 +470,6 @@ struct sdf_ctx {
     int cull_levels = 0;              // SDF_CULL_LEVELS=2 / 3: interval levels of k_cull (3: + sub-groups of 2^3 cells); 0: by the tape (see generate_impl)
     DevBuf bounds_work;               // k_estimate_bounds_w: the waves' exchange words (tagged per call, sdf_bounds.hip)
     unsigned bounds_tag = 0, bounds_tag0 = 0;
-    int bounds_waves = 1;             // SDF_BOUNDS_WAVES=0: the four-workgroup form of r05h (A/B)
 };
 
 struct sdf_tape {
@@ -638,7 +637,6 @@ static int ctx_init(sdf_ctx *c) {
     memcpy(t.mc33, MC33_FLAT, sizeof(t.mc33));
     if (c->mc.ensure(sizeof(t))) return 1;
     HIPCHK(hipMemcpy(c->mc.p, &t, sizeof(t), hipMemcpyHostToDevice));
-    if (const char *e = getenv("SDF_BOUNDS_WAVES")) c->bounds_waves = atoi(e);
     if (const char *e = getenv("SDF_BOUNDS_TAG0")) c->bounds_tag0 = (unsigned)atoi(e) & 0xFFFFu;   // (tests: the first tag of the exchange words)
     if (const char *e = getenv("SDF_MESH_SHAPE")) c->mesh_shape = atoi(e);
     if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
@@ -900,21 +898,16 @@ int sdf_estimate_bounds(sdf_tape *t, double *h_out6, int precision) {
     if (c->scratch_out.ensure(4096)) return 1;
     // the waves' exchange words are tagged per call instead of zeroed per call (sdf_bounds.hip): cleared when the buffer is new and when
     // the 16-bit tag wraps
-    unsigned tag = 0;
-    void *work = (char *)c->scratch_out.p + 64;
-    if (c->bounds_waves) {
-        if (!c->bounds_work.p || c->bounds_tag >= 65535u) {
-            if (c->bounds_work.ensure(SDF_BOUNDS_WORK_BYTES)) return 1;
-            HIPCHK(hipMemsetAsync(c->bounds_work.p, 0, SDF_BOUNDS_WORK_BYTES, c->stream));
-            c->bounds_tag = c->bounds_tag0; c->bounds_tag0 = 0;
-        }
-        tag = ++c->bounds_tag;
-        work = c->bounds_work.p;
+    if (!c->bounds_work.p || c->bounds_tag >= 65535u) {
+        if (c->bounds_work.ensure(SDF_BOUNDS_WORK_BYTES)) return 1;
+        HIPCHK(hipMemsetAsync(c->bounds_work.p, 0, SDF_BOUNDS_WORK_BYTES, c->stream));
+        c->bounds_tag = c->bounds_tag0; c->bounds_tag0 = 0;
     }
+    const unsigned tag = ++c->bounds_tag;
     {
         const int rc = sdf_launch_bounds(precision == SDF_PRECISION_F64 ? 1 : 0, t->full ? 1 : 0, c->stream, (const uint32_t *)t->d_code,
                                          precision == SDF_PRECISION_F64 ? (const void *)t->d_c64 : (const void *)t->d_c32, (double *)c->scratch_out.p,
-                                         work, tag);
+                                         c->bounds_work.p, tag);
         if (rc) return fail(std::string("k_estimate_bounds launch: ") + hipGetErrorString((hipError_t)rc));
     }
     // (the seven doubles land in pinned memory behind the call slots' staging: a copy into pageable memory goes through the runtime's

@@ -1297,10 +1297,8 @@ for rep in range(12):
         assert np.array_equal(np.array(core._estimate_bounds(f)), B[n]), (rep, n)
 print('ok')
 ''' % (ROOT, ROOT, GOLDEN)
-    for waves in ('1', '0'):
-        r = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, SDF_BOUNDS_TAG0='65530', SDF_BOUNDS_WAVES=waves),
-                           capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+    r = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, SDF_BOUNDS_TAG0='65530'), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
 
 
 # ---- the two meshing schemes (one kernel with look-back + parking / sample + number + emit) give the same soup ----
