@@ -134,7 +134,8 @@ struct ItemDesc {
 // kernel waiting for a slow predecessor of its oldest parked batch (SDF_MESH_PROF: placing 14.4 of 29.6 G cycles):
 // depth 4: 48.3 ms, 8: 33.6, 16: 27.7, 32: 27.1 ms; the example, gearlike, blobby, pawn do not care, knurling gains 4 %.
 enum { MESH_PARK_DEPTH = 16 };
-enum { MESH_LDS_NTRI = 128, MESH_LDS_AXES = 384, MESH_LDS_PEND = 1184, MESH_LDS_TRI = 1184 + 64 * MESH_PARK_DEPTH,
+// ([0, 64) and [128, 192): the two buffers the block scans of the count phase alternate between; [64, 128): bcast)
+enum { MESH_LDS_SUMS2 = 128, MESH_LDS_NTRI = 192, MESH_LDS_AXES = MESH_LDS_NTRI + 256, MESH_LDS_PEND = MESH_LDS_AXES + 800, MESH_LDS_TRI = MESH_LDS_PEND + 64 * MESH_PARK_DEPTH,
        MESH_LDS_VOL = MESH_LDS_TRI + 256 * 5 * 2 };   // PEND: per parked batch 6 doubles + 2 ints; TRI: the triangle table, one 16-bit word per (configuration, triangle)
 
 __device__ __forceinline__ void batch_origin(const GridDesc &g, int b, int &ox, int &oy, int &oz, int &lx, int &ly, int &lz) {
@@ -169,6 +170,27 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_sums, int &
     for (int w = 0; w < BLOCK / 64; w++) { const int s = wave_sums[w]; if (w < wid) base += s; tot += s; }
     total = tot;
     __syncthreads();
+    return base + inc - v;
+}
+
+// the same with ONE barrier: the caller alternates between two buffers from scan to scan (a thread that writes buffer A for scan i + 2 has
+// passed the barrier of scan i + 1, which every thread reaches only after its reads of scan i)
+template <int BLOCK>
+__device__ __forceinline__ int block_exclusive_scan1(int v, int *wave_sums, int &total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);
+    if (lane == 63) wave_sums[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) { const int s = wave_sums[w]; if (w < wid) base += s; tot += s; }
+    total = tot;
     return base + inc - v;
 }
 
@@ -336,13 +358,21 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
 #define MESH_FLAG_AGG (1ull << 62)
 #define MESH_FLAG_PFX (2ull << 62)
 #define MESH_VAL_MASK ((1ull << 62) - 1)
+__device__ __forceinline__ unsigned wave_sum_u32_dpp(unsigned x) {   // (every lane's x < 2^26: the sum of 64 fits)
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)v, d, 64), hi = __shfl_xor((unsigned)(v >> 32), d, 64);
-        v += ((unsigned long long)hi << 32) | lo;
-    }
-    return v;
+    // three limbs of 21 bits through the vector ALU's row shifts (v < 2^62: triangle counts) -- six `__shfl_xor` steps on both halves were
+    // twelve ds_bpermute round trips on the look-back's critical path, with fifteen waves waiting at the barrier behind it (r05ab)
+    const unsigned long long a = wave_sum_u32_dpp((unsigned)(v & 0x1FFFFFull)), b = wave_sum_u32_dpp((unsigned)((v >> 21) & 0x1FFFFFull)),
+                             c = wave_sum_u32_dpp((unsigned)((v >> 42) & 0xFFFFFull));
+    return a + (b << 21) + (c << 42);
 }
 __device__ __forceinline__ void publish_count(unsigned long long *status, int w, int w_begin, unsigned long long total) {
     if ((threadIdx.x & 63) == 0)
@@ -711,6 +741,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             tri_lds[i] = (unsigned short)(((unsigned)t3[0] & 15u) | (((unsigned)t3[1] & 15u) << 4) | (((unsigned)t3[2] & 15u) << 8));
         }
 
+    for (int i = tid; i < (int)((a.list_off - a.bits_off) >> 3); i += BLOCK) bits[i] = 0ull;   // (every round leaves them cleared for the next)
     const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
     if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x] = wall_clock64();        // (timeline of the workgroup, 100 MHz)
     if (tid == 0) {   // the kernel's start on the device's own clock (sdf_stats.ms_mesh_device, sclk_mhz)
@@ -837,6 +868,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             SDF_PROF(42);
             __syncthreads();
             w = bcast[0];
+
             // Items are handed out in list order, so that the predecessors of a batch are always held by running
             // workgroups -- except inside the tail, which goes by descending cost (MeshArgs::order): the r-th workgroup to
             // arrive there takes the item of rank r (every thread ranks one item among the tail's <= 255 costs; ties by
@@ -957,8 +989,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             // starts at 0; an evaluated sample owned by a decided sub-group has the sub-group's sign anyway.
             const int c0 = lx - 1, c1 = ly - 1, c2 = lz - 1;
             const int nwords = (nvox + 63) >> 6;
-            for (int i = tid; i < nwords + 2; i += BLOCK) bits[i] = 0ull;   // (+2: the row extraction reads one word ahead)
-            __syncthreads();
+            (void)nwords;   // (the words -- + 2: the row extraction reads one word ahead -- were cleared when the previous batch had been
+                            // counted, or at the kernel's start: below; until r05ab here, in front of a barrier of its own)
             // <cull-sign-fill>  (tests/native/cull_tasks_host.py cuts this loop out for the host test)
             // a thread per row of lz samples along z.  Sub-group h of the row owns samples 2 h and 2 h + 1 (the last one, hlast,
             // the boundary sample c2 too): its state sits at bits 2 h, 2 h + 1 of the row's word, "positive" = 01, so the
@@ -1070,6 +1102,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         };
         // ---- 2a. surface cells per row, their running count over the rows (the order of the soup) ----
         int ncells = 0;
+        // (the scans of this phase take ONE barrier each: they alternate between two buffers, block_exclusive_scan1)
+        int scan_ix = 0;
+        int *wave_sums_b = reinterpret_cast<int *>(smem + MESH_LDS_SUMS2);
+#define SDF_SCAN(V, TOT) block_exclusive_scan1<BLOCK>((V), (scan_ix++ & 1) ? wave_sums_b : wave_sums, (TOT))
         SDF_UNROLL
         for (int k = 0; k < RPT; k++) {
             const int r = tid + k * BLOCK;
@@ -1081,7 +1117,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
             row_mask[k] = mask;
             int tot;
-            row_cell0[k] = ncells + block_exclusive_scan<BLOCK>(__popc(mask), wave_sums, tot);
+            row_cell0[k] = ncells + SDF_SCAN(__popc(mask), tot);
             ncells += tot;
         }
         ncells = uni(ncells);
@@ -1135,7 +1171,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 }
                 int tot = 0;
                 coff[k] = total;
-                if (k * BLOCK < ncells) { coff[k] += block_exclusive_scan<BLOCK>(n, wave_sums, tot); total += tot; }   // (uniform)
+                if (k * BLOCK < ncells) { coff[k] += SDF_SCAN(n, tot); total += tot; }   // (uniform)
                 cinfo[k] = info; cn[k] = n;
             }
             if (TWOPASS) {
@@ -1171,11 +1207,14 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 }
                 row_tris[k] = n;
                 int tot;
-                row_off[k] = total + block_exclusive_scan<BLOCK>(n, wave_sums, tot);
+                row_off[k] = total + SDF_SCAN(n, tot);
                 total += tot;
             }
         }
         total = uni(total);
+        // the sign bits are dead from here on (the emission reads samples and the rows' strings in registers): cleared NOW, for the next
+        // culled tile's sign fill -- behind this round's remaining barriers instead of in front of a barrier of its own
+        for (int i = tid; i < (int)((a.list_off - a.bits_off) >> 3); i += BLOCK) bits[i] = 0ull;
         // ---- the batch's count is public from here on; bookkeeping that needs no position ----
         if (tid < 64 && !TWOPASS) publish_count(a.status, w, work_begin, (unsigned long long)total);
         if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
