@@ -149,21 +149,23 @@ def trace(msg):
 
 
 def watchdog(out):
-    """N > 1 only: the optional `other_configs` section must not take the headline line down with it.  If it has not
-    finished after SDF_BENCH_OTHER_TIMEOUT_S (default 600) seconds -- a rank stuck in a collective its peers never
-    entered -- rank 0 prints the line it already has (with the reason in `other_configs`) and every rank exits."""
+    """The optional `other_configs` section must not take the headline line down with it.  If it has not finished after
+    SDF_BENCH_OTHER_TIMEOUT_S seconds (default 600 for N > 1 -- a rank stuck in a collective its peers never entered --, 300 on one
+    GPU -- r05ae: a default run sat in this section until its caller's 600 s limit, no line printed; the section's host side runs
+    the CPU checker in up to 128 processes) rank 0 prints the line it already has (with the reason in `other_configs`) and every
+    rank exits."""
     import threading
-    if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
-        return None
-    limit = float(os.environ.get('SDF_BENCH_OTHER_TIMEOUT_S', '600'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    limit = float(os.environ.get('SDF_BENCH_OTHER_TIMEOUT_S', '600' if world > 1 else '300'))
 
     def fire():
         if out is not None:
             out['other_configs'] = [{'error': 'other_configs did not finish within %.0f s; skipped' % limit}]
-            out['stalled'] = ['other_configs']      # (a rank sat in a collective of the OPTIONAL section; the headline above it was measured)
+            out['stalled'] = ['other_configs']      # (the OPTIONAL section stalled; the headline above it was measured)
             print(json.dumps(out), flush=True)
         # exit code 0 on purpose: the headline measurement is complete and valid; the stall is in the line (`stalled`), and
         # the headline's own watchdog (below) exits with 3 when the measurement itself hangs
+        sys.stdout.flush()
         os._exit(0)
     t = threading.Timer(limit, fire)
     t.daemon = True
@@ -214,22 +216,33 @@ def stats3(v):
     return {'min': round(float(v.min()), 4), 'median': round(float(np.median(v)), 4), 'max': round(float(v.max()), 4), 'n': int(len(v))}
 
 
-def _oracle_chunk(job):
-    """worker of whole_soup_vs_oracle (its own process, no GPU): the checker's soup of batches [b0, b1) of a model's grid"""
-    model, bounds, log2, b0, b1 = job
+def _oracle_worker(jobs, wid, stride, outdir):
+    """worker of whole_soup_vs_oracle (its own process, no GPU): the checker's soup of every `stride`-th piece of a model's grid,
+    each left as a file of its own (written under another name, then renamed: the parent only ever sees whole files)"""
     import oracle
     from sdf_amd import core
-    f, _ = build_model(model)
-    X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** log2)
-    return b0, oracle.generate(f, X, Y, Z, 32, True, batch_range=(b0, b1)).points
+    f = X = None
+    for k in range(wid, len(jobs), stride):
+        model, bounds, log2, b0, b1 = jobs[k]
+        if f is None:
+            f, _ = build_model(model)
+            X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** log2)
+        pts = oracle.generate(f, X, Y, Z, 32, True, batch_range=(b0, b1)).points
+        tmp = os.path.join(outdir, 'w%d.tmp.npy' % wid)
+        np.save(tmp, pts)
+        os.replace(tmp, os.path.join(outdir, 'piece%d.npy' % k))
 
 
 def whole_soup_vs_oracle(model, bounds, log2, soup_host, n_batches, budget_cores=128, budget_s=240.0):
     """EVERY coordinate of a soup against the CPU checker's (oracle/sdf_oracle.c, the reference's algorithm restated): the checker
     meshes the grid's batches in pieces on the host's cores (processes of their own), the pieces come back in order and are
     compared with the soup where it stands.  Returns counts -- how many coordinates differ at all, the largest difference over
-    the grid's extent -- not a verdict: models that go through libm (sin / cos / atan2: gearlike, weave) are pinned by tolerance."""
+    the grid's extent -- not a verdict: models that go through libm (sin / cos / atan2: gearlike, weave) are pinned by tolerance.
+    (Plain processes that leave their pieces as files, polled against a deadline and killed at the end: nothing here can wait for a
+    queue, a lock or a pool's shutdown -- r05ae: a default run of this file never came back from its optional sections.)"""
     import multiprocessing as mp
+    import shutil
+    import tempfile
     cores = max(1, min(os.cpu_count() or 1, budget_cores))
     pieces = max(cores * 4, 8)
     cuts = [n_batches * i // pieces for i in range(pieces + 1)]
@@ -238,27 +251,50 @@ def whole_soup_vs_oracle(model, bounds, log2, soup_host, n_batches, budget_cores
     pos = differ = 0
     worst = 0.0
     t0 = time.perf_counter()
-    with mp.get_context('spawn').Pool(cores) as pool:
-        it = pool.imap(_oracle_chunk, jobs)
-        for _ in jobs:
-            try:
-                _, pts = it.next(timeout=max(5.0, budget_s - (time.perf_counter() - t0)))
-            except mp.TimeoutError:      # (out of time: what has been compared is a PREFIX of the soup, in reference order)
-                pool.terminate()
+    outdir = tempfile.mkdtemp(prefix='sdf_soup_', dir='/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None)
+    ctx = mp.get_context('spawn')
+    nproc = min(cores, len(jobs))
+    procs = [ctx.Process(target=_oracle_worker, args=(jobs, wid, nproc, outdir), daemon=True) for wid in range(nproc)]
+    err = None
+    try:
+        for p in procs:
+            p.start()
+        for k in range(len(jobs)):
+            path = os.path.join(outdir, 'piece%d.npy' % k)
+            deadline = t0 + max(budget_s, 5.0)
+            while not os.path.exists(path):
+                # (out of time, or the piece's worker died: what has been compared is a PREFIX of the soup, in reference order)
+                if time.perf_counter() > deadline or not procs[k % nproc].is_alive() and not os.path.exists(path):
+                    path = None
+                    break
+                time.sleep(0.005)
+            if path is None:
                 break
+            pts = np.load(path)
+            os.remove(path)
             n = len(pts)
             if pos + n > len(soup_host):
-                return {'error': 'the checker has more triangles than the soup', 'at_vertex': pos}
+                err = {'error': 'the checker has more triangles than the soup', 'at_vertex': pos}
+                break
             mine = soup_host[pos:pos + n]
             ne = mine != pts
             differ += int(ne.sum())
             if ne.any():
                 worst = max(worst, float(np.abs(mine - pts)[ne].max()))
             pos += n
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        for p in procs:
+            p.join(timeout=2.0)
+        shutil.rmtree(outdir, ignore_errors=True)
+    if err is not None:
+        return err
     return {'vertices': pos, 'vertices_expected': int(len(soup_host)), 'coordinates': 3 * pos, 'coordinates_that_differ': differ,
             'share_bit_equal': round(1.0 - differ / max(3 * pos, 1), 9), 'max_abs_diff_over_extent': worst / extent,
             'within_1e-5': bool(worst / extent <= 1e-5), 'whole_soup': bool(pos == len(soup_host)), 'checker_seconds': round(time.perf_counter() - t0, 1),
-            'host_processes': cores, 'what': 'every coordinate of the soup against oracle/sdf_oracle.c meshing the whole grid on the host'}
+            'host_processes': nproc, 'what': 'every coordinate of the soup against oracle/sdf_oracle.c meshing the whole grid on the host'}
 
 
 def main():
