@@ -53,7 +53,10 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 # BASELINE.json configs[2..4] at their real sizes: (model, log2 samples, triangles the reference / the golden runs give)
 # (+ timed steps: enough of them that filling and draining the four-deep pipeline does not dominate a millisecond job)
-OTHER_CONFIGS = [('gearlike', 30, 10204096, 24), ('weave', 33, 53943912, 6), ('blobby', 30, 4048520, 24)]
+# (weave LAST: its host-side comparison ends with up to 128 checker processes being killed, each holding a piece of a 3.9 GB soup -- the
+# millisecond job measured right behind that, blobby, came out at 1.28 - 1.52 ms per step with four calls in flight in two of five runs
+# (r05y, r05af) against 0.88 everywhere else)
+OTHER_CONFIGS = [('gearlike', 30, 10204096, 24), ('blobby', 30, 4048520, 24), ('weave', 33, 53943912, 6)]
 
 
 # DESIGN.md section 6, arithmetic for 8 GPUs (one GPU's measured stage times / 8 + fixed costs + 16 B per triangle (sdf_slab.h records) over one xGMI
