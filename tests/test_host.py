@@ -331,3 +331,23 @@ if __name__ == '__main__':
         os.remove(path)
     assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-1500:] + r.stderr[-3000:]
 
+
+
+def test_bench_optional_section_cannot_swallow_the_headline_line():
+    """bench.py runs its optional `other_configs` section under a watchdog -- on ONE GPU too (r05ae: a default run sat in that section
+    until its caller's limit, no line): when the section does not come back, the line that is already complete is printed, with the
+    reason in it, and the process exits with code 0"""
+    import json
+    import subprocess
+    import sys
+    script = ("import os, sys, time; sys.path.insert(0, %r); import bench\n"
+              "out = {'metric': 'm', 'value': 1.5, 'other_configs': None}\n"
+              "bench.watchdog(out)\n"
+              "time.sleep(20)\n"
+              "print('NOT REACHED')\n") % ROOT
+    env = dict(os.environ, SDF_BENCH_OTHER_TIMEOUT_S='0.3')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0 and 'NOT REACHED' not in r.stdout, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['value'] == 1.5 and line['stalled'] == ['other_configs'] and 'did not finish' in line['other_configs'][0]['error']
