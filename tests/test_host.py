@@ -351,3 +351,29 @@ def test_bench_optional_section_cannot_swallow_the_headline_line():
     assert r.returncode == 0 and 'NOT REACHED' not in r.stdout, r.stdout + r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['value'] == 1.5 and line['stalled'] == ['other_configs'] and 'did not finish' in line['other_configs'][0]['error']
+
+
+def test_bench_whole_soup_comparison_survives_dead_workers():
+    """whole_soup_vs_oracle's workers are plain processes that leave files: workers that die (here: a model they cannot build) make the
+    comparison stop with the prefix it has -- at once, not at the end of its time budget, and never in a pool's shutdown"""
+    import subprocess
+    import sys
+    import time
+    script = '''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, bench
+if __name__ == '__main__':
+    r = bench.whole_soup_vs_oracle('no_such_model', ((-1, -1, -1), (1, 1, 1)), 15, np.zeros((30, 3)), 8, budget_cores=3, budget_s=120.0)
+    assert r['vertices'] == 0 and not r['whole_soup'] and r['coordinates_that_differ'] == 0, r
+    print('ok', r['checker_seconds'])
+''' % ROOT
+    path = os.path.join(ROOT, 'tests', '_whole_soup_dead.py')
+    t0 = time.time()
+    try:
+        open(path, 'w').write(script)
+        r = subprocess.run([sys.executable, path], capture_output=True, text=True, timeout=100)
+    finally:
+        os.remove(path)
+    assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-1500:] + r.stderr[-3000:]
+    assert time.time() - t0 < 60
