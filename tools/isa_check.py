@@ -12,7 +12,9 @@ script takes the gfx950 code objects out of the library's offload bundles, disas
     k_cull* / k_prune_list dispatch through a switch and are listed only);
   * no kernel of the plain translation units (k_compact, k_scan_*, k_emit2, k_expand, k_pack_slab, k_mc_*, k_field_*, k_stl,
     k_cast_f32, k_collect_headers) contains one -- they must not have been built with the interpreters' option;
-  * every kernel the host launches is there at all.
+  * every kernel the host launches is there at all;
+  * the bounds estimate (k_estimate_bounds_w: 64 workgroups of ONE wave that meet through device memory, csrc/sdf_bounds.hip) contains no
+    `s_barrier`.
 
 It prints one line per kernel (instructions, s_setpc_b64, scratch_ instructions) and exits non-zero on a violation."""
 import os
@@ -54,7 +56,7 @@ def kernels(obj_bytes):
         m = re.match(r'^[0-9a-f]+ <([^>]+)>:$', line)
         if m:
             name = m.group(1)
-            stats[name] = [0, 0, 0]
+            stats[name] = [0, 0, 0, 0]
         elif name and '\t' in line:
             op = line.split('\t')[1].split()[0] if len(line.split('\t')) > 1 and line.split('\t')[1].strip() else ''
             if not op or op.startswith('.'):
@@ -62,6 +64,7 @@ def kernels(obj_bytes):
             stats[name][0] += 1
             stats[name][1] += op == 's_setpc_b64'
             stats[name][2] += op.startswith('scratch_')
+            stats[name][3] += op == 's_barrier'
     return stats
 
 
@@ -73,7 +76,7 @@ def main():
     names = subprocess.run(['c++filt'], input='\n'.join(allk), capture_output=True, text=True).stdout.split('\n')
     bad, seen = [], set()
     for mangled, name in zip(allk, names):
-        n, setpc, scratch = allk[mangled]
+        n, setpc, scratch, barriers = allk[mangled]
         base = re.sub(r'^void ', '', name).split('(')[0].split('<')[0].split('::')[-1]
         if not base.startswith('k_'):
             continue                                    # (outlined device functions: o_sin, mc33_triangle, ...)
@@ -82,6 +85,9 @@ def main():
         print('%-8s %-90s %7d instr  s_setpc_b64 %3d  scratch_ %4d' % (kind, name[:90], n, setpc, scratch))
         if kind == 'interp' and setpc == 0:
             bad.append('%s: a tape interpreter WITHOUT its jump-table dispatch (s_setpc_b64)' % name[:100])
+        if base == 'k_estimate_bounds_w' and barriers != 0:
+            bad.append('%s: the bounds estimate is built of single-wave workgroups that synchronise through device memory only: an s_barrier in it '
+                       'means its design was changed without this check' % name[:100])
         if kind == 'plain' and setpc != 0:
             bad.append('%s: a plain kernel WITH s_setpc_b64 (built with the interpreters\' structurizer option?)' % name[:100])
     for k in INTERP + INTERVAL + PLAIN:
