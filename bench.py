@@ -16,9 +16,11 @@ the same ordered soup on every rank).  The axes are the only input (3 x 512 floa
 inside the timed region (the PCIe-inclusive rate is reported separately as `value_incl_d2h`).  float64 sampling =
 the reference's NumPy precision.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (k_mesh), `cpu_baseline` = the
-reference's own CPU path (NumPy thread pool + skimage; live where the reference is installed, else the committed
-build-container run, see `kind`), `cpu_port` = the C oracle timed live on one host core, `isolated_calls` = what ONE
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (k_mesh), `cpu_baseline` = the CPU path
+TIMED ON THIS BOX IN THIS RUN: the reference's own (NumPy thread pool + skimage; kind "reference") where it is installed, else the C
+port of its algorithm that serves as checker, on one host core (kind "port": the GPU boxes have no reference);
+`cpu_reference_recorded` = the reference's numbers from the build container where it could not be timed here (another machine: said
+so in its `kind`), `cpu_port` = the C oracle timed live on one host core (always), `isolated_calls` = what ONE
 synchronous call costs (min / median / max over back-to-back calls with nothing else in flight: what a drop-in
 caller of f.generate() sees), `generate_e2e` = `f.generate(samples=2**27)` on a fresh model end to end (bounds estimate, tape,
 meshing, the copy of the soup to the host: like for like with `cpu_baseline`), `sustained` = the headline job over 2000 steps
@@ -850,7 +852,11 @@ def main():
                    'what': 'sha256 of the float64 soup of the last timed step (copied from its device buffer after the '
                            'timed region) vs the unmodified reference on the same grid (tests/golden/full_c2_example_s27.npz)'},
         'roofline': roofline,
-        'cpu_baseline': cpu_ref if cpu_ref is not None else cpu,
+        # `cpu_baseline` = what was TIMED ON THIS BOX IN THIS RUN: the unmodified reference where it is installed (the build container:
+        # kind 'reference'), else the C port of its algorithm used as checker (kind 'port', one core) -- the GPU boxes have no reference.
+        # The reference's own numbers from the build container travel next to it (`cpu_reference_recorded`: another machine, said so).
+        'cpu_baseline': cpu_ref if (cpu_ref is not None and cpu_ref.get('kind') == 'reference') else (cpu if cpu is not None else cpu_ref),
+        'cpu_reference_recorded': cpu_ref if (cpu_ref is not None and cpu_ref.get('kind') != 'reference') else None,
         'cpu_port': cpu,
         'other_configs': None,
     }
