@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 7
+#define SDF_ABI_VERSION 8
 
 #define SDF_PRECISION_F64 0 /* float64 evaluation like the reference's NumPy path: what every sdf_generate* entry point samples in */
 #define SDF_PRECISION_F32 1 /* float32 evaluation: sdf_eval_* and sdf_estimate_bounds only (the meshing path refuses it since round 5) */
@@ -59,6 +59,9 @@ typedef struct sdf_stats {
     double sclk_mhz;            /* shader clock that kernel ran at (its cycle counter against the constant one)    */
     double t_mesh_first_us;     /* when that kernel's first workgroup started / its last one ended, microseconds on the */
     double t_mesh_last_us;      /* device's constant-rate counter: calls in flight can be laid on ONE time axis          */
+    int64_t mesh_kernel;        /* which fused kernel meshed the call (ABI 8): 1 = k_mesh, one workgroup of 1024 threads per
+                                 * compute unit; 2 = k_mesh2, two of 512 (sdf_ctx_set_mesh2); 0 = neither (batch_size > 32,
+                                 * closures, adopted soups) */
 } sdf_stats;
 
 int sdf_abi_version(void);
@@ -96,6 +99,13 @@ int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
  * batch whose predecessors are not counted yet is parked in device memory and moved later (the r03 scheme).  Results are
  * identical either way. */
 int sdf_ctx_set_defer(sdf_ctx *ctx, int on);
+/* Which fused kernel meshes a call (ABI 8): k_mesh -- one persistent workgroup of 1024 threads per compute unit -- or k_mesh2 --
+ * two of 512 threads, each with half the CU's LDS, so that one workgroup's counting / look-back / emission overlaps the other's
+ * interpreter; it holds sparse tiles only.  -1 (default; SDF_MESH2 sets the initial state) = k_mesh2 when the previous call of
+ * the same tape on the same grid found every tile to be its (the first call takes k_mesh), 1 = k_mesh2 whenever the tape has a
+ * variant (a tile it does not hold is flagged on the device and the pass repeated with k_mesh), 0 = never.  Results are
+ * identical either way; sdf_stats.mesh_kernel says which one ran. */
+int sdf_ctx_set_mesh2(sdf_ctx *ctx, int mode);
 /* interval levels of the second interval pass: 2 = boxes of 8^3 and groups of 4^3 cells, 3 = + sub-groups of 2^3 cells,
  * 0 = the library's choice by the tape (default; SDF_CULL_LEVELS sets the initial state).  Results are identical. */
 int sdf_ctx_set_cull_levels(sdf_ctx *ctx, int levels);

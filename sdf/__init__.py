@@ -5,7 +5,7 @@ import sys as _sys
 
 import sdf_amd as _impl
 from sdf_amd import *  # noqa: F401,F403
-from sdf_amd import d2, d3, dn, ease, core, stl, util, text, mesh  # noqa: F401
+from sdf_amd import d2, d3, dn, ease, core, stl, util, text, mesh, progress  # noqa: F401
 
-for _name in ('d2', 'd3', 'dn', 'ease', 'core', 'stl', 'util', 'text', 'mesh'):
+for _name in ('d2', 'd3', 'dn', 'ease', 'core', 'stl', 'util', 'text', 'mesh', 'progress'):
     _sys.modules[__name__ + '.' + _name] = getattr(_impl, _name)

@@ -28,6 +28,70 @@ SAMPLES = 2 ** 22
 BATCH_SIZE = 32
 
 
+def _marching_cubes(volume, level=0):
+    """skimage's Lewiner marching cubes of a host volume, as the triangle soup (3T, 3) float32 in index
+    coordinates (reference sdf/core.py:16-18: `verts[faces].reshape((-1, 3))`), on the device
+    (`sdf_marching_cubes_host`: k_mc_rows / k_scan_rows / k_mc_emit).  Raises what skimage raises: ValueError
+    for a volume that is not 3-D, smaller than 2 x 2 x 2 or whose range does not contain `level`, RuntimeError
+    when no surface is found -- `_worker` turns any of them into an empty batch, like the reference's.
+    The reference only ever passes level 0; another level is subtracted in float64 on the float32-cast
+    volume (skimage's own order) and the result cast back to float32 for the device."""
+    from . import engine
+    vol = np.asarray(volume)
+    if vol.ndim != 3:
+        raise ValueError('Input volume should be a 3D numpy array.')
+    if min(vol.shape) < 2:
+        raise ValueError('Input array must be at least 2x2x2.')
+    level = float(level)
+    if level < vol.min() or level > vol.max():
+        raise ValueError('Surface level must be within volume data range.')
+    v32 = vol.astype(np.float32)
+    if level != 0.0:
+        v32 = (v32.astype(np.float64) - level).astype(np.float32)
+    soup = engine.get_engine().marching_cubes(v32)
+    if len(soup) == 0:
+        raise RuntimeError('No surface found at the given iso value.')
+    return soup
+
+
+def _skip(sdf, job):
+    """the sparse skip test of one batch (reference sdf/core.py:28-43): True when the batch cannot hold
+    surface.  The nine probes -- centre and the 8 corners of the batch's box -- are evaluated in one call of
+    `sdf` (on the device for the library's own nodes); the comparisons are the reference's.  `generate` itself
+    runs the same test for every batch of a grid in one launch (`k_skip`)."""
+    X, Y, Z = job
+    lo = np.array([X[0], Y[0], Z[0]])
+    hi = np.array([X[-1], Y[-1], Z[-1]])
+    mid = (lo + hi) / 2
+    sel = np.array([[i, j, k] for i in (0, 1) for j in (0, 1) for k in (0, 1)], dtype=bool)   # itertools.product order
+    probes = np.vstack([mid[None, :], np.where(sel, hi, lo)])
+    values = np.asarray(sdf(probes)).reshape(-1)
+    if abs(values[0]) <= np.linalg.norm(mid - lo):
+        return False
+    corners = values[1:]
+    return bool(np.all(corners > 0) if corners[0] > 0 else np.all(corners < 0))
+
+
+def _worker(sdf, job, step, sparse):
+    """one batch of `generate` (reference sdf/core.py:45-60): None when the skip test drops it, [] when it
+    has no surface, else its triangles `points * scale + offset` as a (3T, 3) float64 array.  The job is meshed
+    as a grid of its own whose first batch is the job (batch_size = its longest axis - 1; what lies behind it
+    are slivers one sample thick, which have no cells): the same fused kernels `generate` uses."""
+    from . import engine
+    X, Y, Z = (np.ascontiguousarray(a, dtype=np.float64) for a in job)
+    if min(len(X), len(Y), len(Z)) < 2:
+        return None if (sparse and len(X) and len(Y) and len(Z) and _skip(sdf, job)) else []
+    bs = max(len(X), len(Y), len(Z)) - 1
+    mesh = engine.get_engine().generate(sdf, X, Y, Z, bs, sparse)
+    try:
+        if sparse and mesh.kinds()[0] == 0:
+            return None
+        points = mesh.points()
+    finally:
+        mesh.close()
+    return points if len(points) else []
+
+
 def _cartesian_product(*arrays):
     """(N, d) points, first axis slowest (reference sdf/core.py:20-26); host helper kept
     for API compatibility -- the device generates grid points from the axes itself"""

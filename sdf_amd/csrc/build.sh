@@ -23,10 +23,13 @@ $HIPCC $FLAGS "-DSDF_BUILD_INFO=\"$INFO\"" -c -o build/sdf_hip.o sdf_hip.hip "$@
 $HIPCC $FLAGS -c -o build/sdf_bounds.o sdf_bounds.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f64 -c -o build/mesh_f64.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
 $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f64_full -c -o build/mesh_f64_full.o sdf_mesh_inst.hip "$@" & pids="$pids $!"
+# (k_mesh2, sdf_mesh2.h: the same rounds as two workgroups of 512 threads per compute unit)
+$HIPCC $FLAGS -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh2_f64 -c -o build/mesh2_f64.o sdf_mesh2_inst.hip "$@" & pids="$pids $!"
+$HIPCC $FLAGS -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh2_f64_full -c -o build/mesh2_f64_full.o sdf_mesh2_inst.hip "$@" & pids="$pids $!"
 # (every kernel that is not a tape interpreter: built WITHOUT the structurizer option, see sdf_plain.hip)
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -c -o build/sdf_plain.o sdf_plain.hip "$@" & pids="$pids $!"
 # (the weld uses hipCUB's radix sort and scan; it has no floating-point arithmetic of its own)
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c -o build/sdf_weld.o sdf_weld.hip "$@" & pids="$pids $!"
 for p in $pids; do wait $p; done
-exec $HIPCC --offload-arch=gfx950 -fPIC -shared -o libsdf_hip.so build/sdf_hip.o build/mesh_f64.o build/mesh_f64_full.o \
+exec $HIPCC --offload-arch=gfx950 -fPIC -shared -o libsdf_hip.so build/sdf_hip.o build/mesh_f64.o build/mesh_f64_full.o build/mesh2_f64.o build/mesh2_f64_full.o \
     build/sdf_bounds.o build/sdf_weld.o build/sdf_plain.o

@@ -58,9 +58,15 @@ struct MeshCounters {   // zeroed before every k_mesh run
     unsigned long long n_raw;         // compact output: triangles that went to the slab's raw area (sdf_slab.h)
     // written by k_compact (NOT cleared between meshing retries): the surviving-batch work list
     // and this shard's slice of it, so k_mesh can start without a host round trip
-    int nwork, work_begin, work_end, pad_;
+    int nwork, work_begin, work_end;
+    int not_mesh2;                    // k_cull: some tile of this shard is not k_mesh2's (left dense, or more than MESH2_NTL_MAX listed tasks)
 };
 enum { MESH_COUNTERS_RESET_BYTES = 112 };   // the part of MeshCounters cleared before every k_mesh run
+// overflow bits: 1 the soup (or an arena) was too small, 2 a look-back timed out, 16 k_mesh2 met a tile it does not hold (the call is
+// repeated with k_mesh; 4 and 8 are the slab header's own: items, raw area -- k_pack_slab)
+enum { MESH_OVERFLOW_NOT_MESH2 = 16 };
+// k_mesh2 (sdf_mesh2.h) takes tiles of at most this many listed tasks (their samples: 48 KB of its 64 KB region)
+enum { MESH2_NTL_MAX = 192 };
 
 struct GridDesc {
     const double *X, *Y, *Z;   // device copies of the np.arange axes
@@ -707,10 +713,13 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     // (the argument block is read from the kernel-argument segment where it is used -- a scalar load from constant memory, two
     // words of pointer to keep -- instead of living in ~ 80 scalar registers that the round structure then spills)
     typedef __attribute__((address_space(4))) const MeshArgs KArgs;
+    // (the block follows the two pointers in the kernel-argument segment: a new leading parameter, or an alignment of MeshArgs above
+    // 16 bytes, would move it)
+    static_assert(sizeof(const uint32_t *) + sizeof(const T *) == 16 && alignof(MeshArgs) <= 16, "MeshArgs sits at byte 16 of the kernel arguments");
     KArgs *ap = (KArgs *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + 16);
     (void)a_byval;
-#define a (*ap)
-#define SDF_SINK (Tri16Sink{a.out, a.raw, a.raw_cap, &a.ctr->n_raw})
+#define KA (*ap)
+#define SDF_SINK (Tri16Sink{KA.out, KA.raw, KA.raw_cap, &KA.ctr->n_raw})
     typedef Vec<T, NS> V;
     constexpr int RPT = 1024 / BLOCK;   // (i0, i1) rows of cells per thread (a tile has <= 32 x 32 rows)
     constexpr int MESH_CELL_CHUNKS = 2;
@@ -720,9 +729,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     unsigned char *ntri_lds = smem + MESH_LDS_NTRI;                 // 256 B: ntri | ambiguous << 7
     double *axes = reinterpret_cast<double *>(smem + MESH_LDS_AXES);  // 3 * 33 doubles (X, Y, Z of the tile)
     float *vol = reinterpret_cast<float *>(smem + MESH_LDS_VOL);    // (bs+1)^3 floats: the dense tile
-    unsigned long long *bits = reinterpret_cast<unsigned long long *>(smem + a.bits_off);   // 1 bit per sample: value > 0
+    unsigned long long *bits = reinterpret_cast<unsigned long long *>(smem + KA.bits_off);   // 1 bit per sample: value > 0
     // behind the sign bits: k_cull's record of the batch while it is sampled; the cell table and triangle list of a DENSE tile
-    unsigned *wlist = reinterpret_cast<unsigned *>(smem + a.list_off);
+    unsigned *wlist = reinterpret_cast<unsigned *>(smem + KA.list_off);
     // `tid` is made opaque to the optimiser at every phase boundary (SDF_FRESH): whatever a phase derives
     // from it is worked out again there instead of being kept -- i.e. spilled -- across the interpreter
     int tid = threadIdx.x;
@@ -733,36 +742,36 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     // device memory per triangle: 4.6 % of the kernel by knock-out (r04aj)
     unsigned short *tri_lds = reinterpret_cast<unsigned short *>(smem + MESH_LDS_TRI);
 
-    if (tid < 256) ntri_lds[tid] = (unsigned char)(a.mc->ntri[tid] | (a.mc->amb[tid] << 7));
+    if (tid < 256) ntri_lds[tid] = (unsigned char)(KA.mc->ntri[tid] | (KA.mc->amb[tid] << 7));
     if (!TWOPASS)
         for (int i = tid; i < 256 * 5; i += BLOCK) {
             const int cfg = i / 5, j = i - 5 * cfg;
-            const signed char *t3 = &a.mc->tri[cfg][3 * j];
+            const signed char *t3 = &KA.mc->tri[cfg][3 * j];
             tri_lds[i] = (unsigned short)(((unsigned)t3[0] & 15u) | (((unsigned)t3[1] & 15u) << 4) | (((unsigned)t3[2] & 15u) << 8));
         }
 
-    for (int i = tid; i < (int)((a.list_off - a.bits_off) >> 3); i += BLOCK) bits[i] = 0ull;   // (every round leaves them cleared for the next)
-    const int work_begin = a.ctr->work_begin, work_end = a.ctr->work_end;
-    if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x] = wall_clock64();        // (timeline of the workgroup, 100 MHz)
+    for (int i = tid; i < (int)((KA.list_off - KA.bits_off) >> 3); i += BLOCK) bits[i] = 0ull;   // (every round leaves them cleared for the next)
+    const int work_begin = KA.ctr->work_begin, work_end = KA.ctr->work_end;
+    if (KA.prof && tid == 0) KA.prof[64 + 4 * blockIdx.x] = wall_clock64();        // (timeline of the workgroup, 100 MHz)
     if (tid == 0) {   // the kernel's start on the device's own clock (sdf_stats.ms_mesh_device, sclk_mhz)
         const unsigned long long tw = wall_clock64();
-        atomicMax(&a.ctr->t_first_inv, ~tw);
-        if (blockIdx.x == 0) { a.ctr->clk_cycles = (unsigned long long)clock64(); a.ctr->clk_ticks = tw; }
+        atomicMax(&KA.ctr->t_first_inv, ~tw);
+        if (blockIdx.x == 0) { KA.ctr->clk_cycles = (unsigned long long)clock64(); KA.ctr->clk_ticks = tw; }
     }
-    long long tprev = a.prof ? clock64() : 0;
-#define SDF_PROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
+    long long tprev = KA.prof ? clock64() : 0;
+#define SDF_PROF(K) do { if (KA.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&KA.prof[K], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     // position-dependent bookkeeping of work item w_ (thread 0)
     auto settle = [&](int w_, unsigned long long excl, unsigned long long total_) {
-        if (excl == ~0ull) atomicOr(&a.ctr->overflow, 2u);           // look-back timed out (never expected)
-        else if (excl + total_ > a.out_cap) atomicOr(&a.ctr->overflow, 1u);
-        if (w_ == work_end - 1 && excl != ~0ull) a.ctr->total = excl + total_;
+        if (excl == ~0ull) atomicOr(&KA.ctr->overflow, 2u);           // look-back timed out (never expected)
+        else if (excl + total_ > KA.out_cap) atomicOr(&KA.ctr->overflow, 1u);
+        if (w_ == work_end - 1 && excl != ~0ull) KA.ctr->total = excl + total_;
     };
     // The parked batches of this workgroup: a FIFO of up to MESH_PARK_DEPTH, each in its own staging slot (all
     // values workgroup-uniform).  Sampling times differ a lot between batches (pruned tapes, culled tiles): with
     // ONE slot a workgroup that met a slow predecessor twice in a row stood still -- 12 % of the kernel's
     // cycles were spent in the look-back of the parked batch.  A batch is placed as soon as its predecessors
     // have published (checked once per batch of this workgroup, oldest first); only a full FIFO waits.
-    float *my_park = a.park ? a.park + (size_t)blockIdx.x * (size_t)MESH_PARK_DEPTH * (size_t)a.park_cap * 9 : nullptr;
+    float *my_park = KA.park ? KA.park + (size_t)blockIdx.x * (size_t)MESH_PARK_DEPTH * (size_t)KA.park_cap * 9 : nullptr;
     int pq_head = 0, pq_count = 0;
     unsigned char *pend_base = smem + MESH_LDS_PEND;   // entry k: double xf[6] (offset[3], scale[3]), int w, int total
     auto pend_xf = [&](int k) { return reinterpret_cast<double *>(pend_base + 64 * k); };
@@ -774,9 +783,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             const int pend_w = uni(pend_wt(pq_head)[0]), pend_total = uni(pend_wt(pq_head)[1]);
             const bool block = must || pq_count > MESH_PARK_DEPTH - need;
             if (tid < 64) {
-                const unsigned long long pre = first ? pre_pend : lookback_prefetch(a.status, pend_w, work_begin);
-                const unsigned long long excl = ordered_base(a.status, pend_w, work_begin, (unsigned long long)pend_total,
-                                                             block ? MESH_SPIN_FOREVER : a.park_spins, pre);
+                const unsigned long long pre = first ? pre_pend : lookback_prefetch(KA.status, pend_w, work_begin);
+                const unsigned long long excl = ordered_base(KA.status, pend_w, work_begin, (unsigned long long)pend_total,
+                                                             block ? MESH_SPIN_FOREVER : KA.park_spins, pre);
                 if (tid == 0) {
                     if (excl != MESH_NOT_READY) settle(pend_w, excl, (unsigned long long)pend_total);
                     reinterpret_cast<unsigned long long *>(bcast + 4)[0] = excl;
@@ -786,9 +795,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             __syncthreads();
             const unsigned long long pbase = uni64(reinterpret_cast<unsigned long long *>(bcast + 4)[0]);
             if (pbase == MESH_NOT_READY) { __syncthreads(); break; }   // (bcast is reused)
-            if (pbase != ~0ull && pbase + (unsigned long long)pend_total <= a.out_cap) {
-                double *dst0 = a.out + pbase * 9ull;
-                const float *src = my_park + (size_t)pq_head * (size_t)a.park_cap * 9;
+            if (pbase != ~0ull && pbase + (unsigned long long)pend_total <= KA.out_cap) {
+                double *dst0 = KA.out + pbase * 9ull;
+                const float *src = my_park + (size_t)pq_head * (size_t)KA.park_cap * 9;
                 const double *xf = pend_xf(pq_head);
                 const double pof0 = xf[0], pof1 = xf[1], pof2 = xf[2], psc0 = xf[3], psc1 = xf[4], psc2 = xf[5];
                 // consecutive lanes move consecutive coordinates (4-byte loads, 8-byte stores: whole cache lines per
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 const int n9 = pend_total * 9;
                 const double sc[3] = {psc0, psc1, psc2}, of[3] = {pof0, pof1, pof2};
                 constexpr int U = 8;
-                if (a.compact) {   // (uniform) the slab takes 16-byte records: a lane per parked triangle
+                if (KA.compact) {   // (uniform) the slab takes 16-byte records: a lane per parked triangle
                     for (int t = tid; t < pend_total; t += BLOCK) {
                         float f[9];
                         SDF_UNROLL for (int q = 0; q < 9; q++) f[q] = src[(size_t)t * 9 + q];
@@ -838,7 +847,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
     // phase -- was built and measured in r02: the time at the top of the loop did not move (it is the record / axis loads,
     // not the atomic), and the two values carried across the phases cost 6 - 9 more spilled registers: 0.288 -> 0.300 ms.
     // What does pay is below: a whole WAVE brings the item, its record and its axes into LDS during the emission.)
-    const int slot_bytes = TWOPASS ? 0 : a.slot_bytes;
+    const int slot_bytes = TWOPASS ? 0 : KA.slot_bytes;
     auto slot_base = [&](int s_) { return smem + MESH_LDS_VOL + (size_t)s_ * (size_t)slot_bytes; };
     int dq_slot = -1;          // the slot of the counted batch whose triangles are still to be written (-1: none)
     bool carry = false;        // the work item in `w` was taken in the previous round (which only wrote the waiting batch)
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (tid == 0) { const int idx = bcast[8]; bcast[0] = work_begin + idx; bcast[1] = idx; }
                 have = uni(bcast[11]) != 0;
             } else {
-                if (tid == 0) { const int idx = (int)atomicAdd(&a.ctr->work_counter, 1u); bcast[0] = work_begin + idx; bcast[1] = idx; }
+                if (tid == 0) { const int idx = (int)atomicAdd(&KA.ctr->work_counter, 1u); bcast[0] = work_begin + idx; bcast[1] = idx; }
                 have = false;
             }
             nx_valid = false;
@@ -877,10 +886,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             // park) holds one item of the tail at most that others wait for, and the tail has fewer items than there are
             // workgroups, hence some workgroup is always free to take the item everybody waits for.
             {
-                const int n_work = work_end - work_begin, tail = min(a.tail, n_work), r = bcast[1] - (n_work - tail);
-                if (a.order && r >= 0 && r < tail && !have) {   // (uniform; an item that came with its record is not of the tail)
+                const int n_work = work_end - work_begin, tail = min(KA.tail, n_work), r = bcast[1] - (n_work - tail);
+                if (KA.order && r >= 0 && r < tail && !have) {   // (uniform; an item that came with its record is not of the tail)
                     int *cost = reinterpret_cast<int *>(wlist), *rnk = cost + 256;   // (the work area is idle here)
-                    for (int i = tid; i < 256; i += BLOCK) { cost[i] = i < tail ? a.order[i] : -1; rnk[i] = 0; }
+                    for (int i = tid; i < 256; i += BLOCK) { cost[i] = i < tail ? KA.order[i] : -1; rnk[i] = 0; }
                     __syncthreads();
                     {   // item i = tid % 256 against a quarter (half) of the others, the partial ranks added up in LDS
                         constexpr int PARTS = BLOCK / 256, SPAN = 256 / PARTS;
@@ -901,7 +910,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         SDF_PROF(43);
         carry = false;
         const bool finished = w >= work_end;
-        if (finished && a.prof && tid == 0 && a.prof[64 + 4 * blockIdx.x + 1] == 0) a.prof[64 + 4 * blockIdx.x + 1] = wall_clock64();
+        if (finished && KA.prof && tid == 0 && KA.prof[64 + 4 * blockIdx.x + 1] == 0) KA.prof[64 + 4 * blockIdx.x + 1] = wall_clock64();
         if (finished && dq_slot < 0) break;
         // ---- what kind of tile?  (the header word of k_cull's record: a uniform load) ----
         bool flush_only = finished;   // this round only writes the waiting batch
@@ -912,8 +921,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             unsigned n0_v;
             if (have) { b_v = bcast[9]; n0_v = (unsigned)bcast[10]; }
             else {
-                b_v = a.worklist[w];                                                  // (both loads in flight before either is waited for)
-                n0_v = a.cull ? reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD)[0] : 0xFFFFu;
+                b_v = KA.worklist[w];                                                  // (both loads in flight before either is waited for)
+                n0_v = KA.cull ? reinterpret_cast<const unsigned *>(KA.cull + (size_t)w * CULL_RECORD)[0] : 0xFFFFu;
             }
             b = uni(b_v);
             const unsigned n0 = (unsigned)uni((int)n0_v) & 0xFFFFu;
@@ -928,7 +937,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         unsigned char *cs = slot_base(sparse ? cur_slot : 0);
         float *smp = reinterpret_cast<float *>(cs + MESH_SLOT_HDR);
         unsigned *clist = sparse ? reinterpret_cast<unsigned *>(cs + MESH_SLOT_HDR + 256 * ntl_cull) : wlist;
-        const int lcap = sparse ? min((slot_bytes - MESH_SLOT_HDR - 256 * ntl_cull) >> 2, 16384) : a.list_cap;
+        const int lcap = sparse ? min((slot_bytes - MESH_SLOT_HDR - 256 * ntl_cull) >> 2, 16384) : KA.list_cap;
         int lx = 2, ly = 2, lz = 2, lyz = 4;
         int row_tris[RPT], row_off[RPT], row_cell0[RPT];
         unsigned row_mask[RPT];
@@ -948,7 +957,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             if (sparse) for (int i = tid; i < 289; i += BLOCK) reinterpret_cast<unsigned *>(cs + MESH_SLOT_COLINFO)[i] = wlist[CULL_COLINFO / 4 + i];
         } else {
             if (culled) {
-                const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)w * CULL_RECORD);
+                const unsigned *rec = reinterpret_cast<const unsigned *>(KA.cull + (size_t)w * CULL_RECORD);
                 const int nwords = (CULL_ULIST + 16 * ntl_cull + 3) >> 2;
                 for (int i = tid; i < nwords; i += BLOCK) wlist[i] = rec[i];
                 for (int i = tid; i < 256; i += BLOCK) wlist[CULL_SSTATE / 4 + i] = rec[CULL_SSTATE / 4 + i];
@@ -965,9 +974,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // (with the interval prepass on, this batch has its own tape with the irrelevant instructions removed)
         // (`code` stays the base of every address so that the loads remain scalar loads from a read-only
         // kernel argument; b comes out of LDS, hence the readfirstlane)
-        const uint32_t *wcode = code + (size_t)__builtin_amdgcn_readfirstlane(b) * (size_t)a.tape_stride * 2;
-        if (a.tape_stride && tid == 0)
-            atomicAdd(&a.ctr->n_pruned, (unsigned long long)a.n_instr - reinterpret_cast<const unsigned long long *>(wcode)[a.tape_stride - 1]);
+        const uint32_t *wcode = code + (size_t)__builtin_amdgcn_readfirstlane(b) * (size_t)KA.tape_stride * 2;
+        if (KA.tape_stride && tid == 0)
+            atomicAdd(&KA.ctr->n_pruned, (unsigned long long)KA.n_instr - reinterpret_cast<const unsigned long long *>(wcode)[KA.tape_stride - 1]);
         const TileTasks tt(lx, ly, lz);
         const int nvox = tt.nvox;
         lyz = tt.lyz;
@@ -975,8 +984,8 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         constexpr int NWAVE = BLOCK / 64;
         // ---- 1a. sub-groups of 2^3 cells whose interval excludes the surface are not sampled: k_cull left the
         // list of units to evaluate and the sign of the decided sub-groups (cull_tasks) ----
-        long long tsub = a.prof ? clock64() : 0;
-#define SDF_SUBPROF(K) do { if (a.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&a.prof[K], (unsigned long long)(tn - tsub)); tsub = tn; } } while (0)
+        long long tsub = KA.prof ? clock64() : 0;
+#define SDF_SUBPROF(K) do { if (KA.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&KA.prof[K], (unsigned long long)(tn - tsub)); tsub = tn; } } while (0)
         const unsigned short *units = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(wlist) + CULL_ULIST);
         const unsigned *sstate = wlist + CULL_SSTATE / 4;   // 16 x 16 words of 16 two-bit states
         int ntl = tt.ntask;
@@ -1011,7 +1020,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             // </cull-sign-fill>
             // (no barrier: the evaluation below only ORs into the same words)
         }
-        if (tid == 0) atomicAdd(&a.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
+        if (tid == 0) atomicAdd(&KA.ctr->n_sampled, culled ? (unsigned long long)ntl * 64ull : (unsigned long long)nvox);
         SDF_SUBPROF(9);
         // ---- 1c. evaluate the listed tasks: NS per wave and pass.  A sparse tile keeps sample `lane` of task t at
         // smp[64 t + lane] (unit 8 t + lane / 8 of the list, sample lane % 8 of the unit: TileView::at) ----
@@ -1067,9 +1076,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         // (wave 0 first asks for the predecessors' status words -- of this batch, of the waiting one and of the oldest
         // parked one -- so that the answers arrive while the cells are counted)
         if (tid < 64 && !TWOPASS) {
-            if (!sparse) pre_own = lookback_prefetch(a.status, w, work_begin);   // (a sparse tile's batch waits a round: asked for then)
-            if (dq_slot >= 0) pre_dq = lookback_prefetch(a.status, reinterpret_cast<const int *>(slot_base(dq_slot) + 48)[0], work_begin);
-            if (pq_count > 0) pre_pend = lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin);
+            if (!sparse) pre_own = lookback_prefetch(KA.status, w, work_begin);   // (a sparse tile's batch waits a round: asked for then)
+            if (dq_slot >= 0) pre_dq = lookback_prefetch(KA.status, reinterpret_cast<const int *>(slot_base(dq_slot) + 48)[0], work_begin);
+            if (pq_count > 0) pre_pend = lookback_prefetch(KA.status, pend_wt(pq_head)[0], work_begin);
         }
         const int c0 = lx - 1, c2 = lz - 1;
         c1 = ly - 1;
@@ -1098,7 +1107,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             int off;
             cvw.cell(i0, i1, i2, c8);
             mc33_load_cell(c8, 4, 2, lv);
-            return mc33_cell(lv, a.mc->mc33, &off);
+            return mc33_cell(lv, KA.mc->mc33, &off);
         };
         // ---- 2a. surface cells per row, their running count over the rows (the order of the soup) ----
         int ncells = 0;
@@ -1214,20 +1223,20 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         total = uni(total);
         // the sign bits are dead from here on (the emission reads samples and the rows' strings in registers): cleared NOW, for the next
         // culled tile's sign fill -- behind this round's remaining barriers instead of in front of a barrier of its own
-        for (int i = tid; i < (int)((a.list_off - a.bits_off) >> 3); i += BLOCK) bits[i] = 0ull;
+        for (int i = tid; i < (int)((KA.list_off - KA.bits_off) >> 3); i += BLOCK) bits[i] = 0ull;
         // ---- the batch's count is public from here on; bookkeeping that needs no position ----
-        if (tid < 64 && !TWOPASS) publish_count(a.status, w, work_begin, (unsigned long long)total);
-        if (a.compact && tid == 0 && w - work_begin < a.xf_cap) {   // the batch's transform travels with the compact soup
-            double *xf = a.xf + (size_t)(w - work_begin) * 6;
+        if (tid < 64 && !TWOPASS) publish_count(KA.status, w, work_begin, (unsigned long long)total);
+        if (KA.compact && tid == 0 && w - work_begin < KA.xf_cap) {   // the batch's transform travels with the compact soup
+            double *xf = KA.xf + (size_t)(w - work_begin) * 6;
             xf[0] = axes[0]; xf[1] = axes[33]; xf[2] = axes[66];
             xf[3] = axes[1] - axes[0]; xf[4] = axes[34] - axes[33]; xf[5] = axes[67] - axes[66];
         }
         if (tid == 0) {
-            atomicAdd(total ? &a.ctr->n_nonempty : &a.ctr->n_empty, 1u);
-            atomicAdd(&a.ctr->n_eval, (unsigned long long)nvox);
-            a.kinds[b] = total ? 2 : 1;
+            atomicAdd(total ? &KA.ctr->n_nonempty : &KA.ctr->n_empty, 1u);
+            atomicAdd(&KA.ctr->n_eval, (unsigned long long)nvox);
+            KA.kinds[b] = total ? 2 : 1;
         }
-        if (my_amb) atomicAdd(&a.ctr->n_ambiguous, (unsigned long long)my_amb);
+        if (my_amb) atomicAdd(&KA.ctr->n_ambiguous, (unsigned long long)my_amb);
         if constexpr (TWOPASS) {
             // ---- two-pass meshing: this kernel stops at the classification.  What k_emit2 needs to produce the batch's
             // triangles -- per surface cell its configuration and 8 corner samples, per triangle which cell and which of
@@ -1237,10 +1246,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             if (tid == 0) {
                 unsigned long long cb = 0, lb = 0;
                 if (total) {
-                    cb = atomicAdd(&a.ctr->cell_cursor, (unsigned long long)ncells);
-                    lb = atomicAdd(&a.ctr->list_cursor, (unsigned long long)total);
-                    if (cb + (unsigned long long)ncells > a.cells_cap || lb + (unsigned long long)total > a.tlist_cap) {
-                        atomicOr(&a.ctr->overflow, 1u);
+                    cb = atomicAdd(&KA.ctr->cell_cursor, (unsigned long long)ncells);
+                    lb = atomicAdd(&KA.ctr->list_cursor, (unsigned long long)total);
+                    if (cb + (unsigned long long)ncells > KA.cells_cap || lb + (unsigned long long)total > KA.tlist_cap) {
+                        atomicOr(&KA.ctr->overflow, 1u);
                         cb = lb = ~0ull;
                     }
                 }
@@ -1250,14 +1259,14 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 d.ntri = (unsigned)total; d.ncells = (unsigned)ncells; d.list_off = lb; d.cell_off = cb;
                 d.xf[0] = axes[0]; d.xf[1] = axes[33]; d.xf[2] = axes[66];
                 d.xf[3] = axes[1] - axes[0]; d.xf[4] = axes[34] - axes[33]; d.xf[5] = axes[67] - axes[66];
-                a.desc[w] = d;
+                KA.desc[w] = d;
             }
             __syncthreads();
             const unsigned long long cell_base = reinterpret_cast<unsigned long long *>(bcast + 2)[0];
             const unsigned long long list_base = reinterpret_cast<unsigned long long *>(bcast + 4)[0];
             if (total && cell_base != ~0ull) {
                 auto put_cell = [&](unsigned long long idx, unsigned info, int i0, int i1, int i2) {
-                    unsigned *rec = a.cells + idx * 9ull;
+                    unsigned *rec = KA.cells + idx * 9ull;
                     float c8[8];
                     cvw.cell(i0, i1, i2, c8);
                     rec[0] = info;
@@ -1271,7 +1280,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         if (sidx < ncells) {
                             const int cell = (int)(cinfo[k] >> 13);
                             put_cell(cell_base + (unsigned long long)sidx, cinfo[k], cell >> 10, (cell >> 5) & 31, cell & 31);
-                            for (int j = 0; j < cn[k]; j++) a.tlist[list_base + (unsigned long long)(coff[k] + j)] = ((unsigned)sidx << 4) | (unsigned)j;
+                            for (int j = 0; j < cn[k]; j++) KA.tlist[list_base + (unsigned long long)(coff[k] + j)] = ((unsigned)sidx << 4) | (unsigned)j;
                         }
                     }
                 } else {
@@ -1290,7 +1299,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                             int n = (int)(en & 7u);
                             if (en & 128u) n = amb_count(i0, i1, i2);
                             put_cell(cell_base + (unsigned long long)sidx, ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((en & 128u) << 5) | (cfg << 4), i0, i1, i2);
-                            for (int j = 0; j < n; j++, pos++) a.tlist[list_base + (unsigned long long)pos] = ((unsigned)sidx << 4) | (unsigned)j;
+                            for (int j = 0; j < n; j++, pos++) KA.tlist[list_base + (unsigned long long)pos] = ((unsigned)sidx << 4) | (unsigned)j;
                             sidx++;
                         }
                     }
@@ -1322,10 +1331,10 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         const bool sparse_next = !flush_only && !emit_cur;   // this batch becomes the waiting one
         // ---- parked batches are older than anything here: their predecessors have long published, place them (and make room
         // for what this round may park: the waiting batch, this batch) ----
-        { const long long tp0 = a.prof ? clock64() : 0;
-        if (flush_only && pq_count > 0 && tid < 64) pre_pend = lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin);
+        { const long long tp0 = KA.prof ? clock64() : 0;
+        if (flush_only && pq_count > 0 && tid < 64) pre_pend = lookback_prefetch(KA.status, pend_wt(pq_head)[0], work_begin);
         place_parked(pre_pend, false, (emit_cur ? 1 : 0) + (dq_slot >= 0 ? 1 : 0));
-        if (a.prof && tid == 0) atomicAdd(&a.prof[6], (unsigned long long)(clock64() - tp0)); }
+        if (KA.prof && tid == 0) atomicAdd(&KA.prof[6], (unsigned long long)(clock64() - tp0)); }
         SDF_PROF(47);
         // (two copies of this code, one per kind of batch, rather than one loop over both: the rows' sign strings and offsets
         // that only a list built in passes needs would otherwise stay in registers through the waiting batch's emission)
@@ -1345,12 +1354,12 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             const double *exf = reinterpret_cast<const double *>(ds);
             const double of0 = is_dq ? exf[0] : axes[0], of1 = is_dq ? exf[1] : axes[33], of2 = is_dq ? exf[2] : axes[66];
             const double sc0 = is_dq ? exf[3] : axes[1] - of0, sc1 = is_dq ? exf[4] : axes[34] - of1, sc2 = is_dq ? exf[5] : axes[67] - of2;
-            const bool may_park = a.park && e_total <= a.park_cap;
+            const bool may_park = KA.park && e_total <= KA.park_cap;
             const bool block = !may_park || (is_dq && finished);   // (at the end of the list there is nothing else to do but wait)
             if (tid < 64) {
-                const unsigned long long pre = is_dq ? (flush_only ? lookback_prefetch(a.status, e_w, work_begin) : pre_dq)
-                                                     : (sparse ? lookback_prefetch(a.status, e_w, work_begin) : pre_own);
-                const unsigned long long excl = ordered_base(a.status, e_w, work_begin, (unsigned long long)e_total, block ? MESH_SPIN_FOREVER : a.park_spins, pre);
+                const unsigned long long pre = is_dq ? (flush_only ? lookback_prefetch(KA.status, e_w, work_begin) : pre_dq)
+                                                     : (sparse ? lookback_prefetch(KA.status, e_w, work_begin) : pre_own);
+                const unsigned long long excl = ordered_base(KA.status, e_w, work_begin, (unsigned long long)e_total, block ? MESH_SPIN_FOREVER : KA.park_spins, pre);
                 if (tid == 0) {
                     if (excl != MESH_NOT_READY) settle(e_w, excl, (unsigned long long)e_total);
                     reinterpret_cast<unsigned long long *>(bcast + 2)[0] = excl;
@@ -1359,21 +1368,21 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             }
             __syncthreads();
             // ---- the last wave takes the next work item while the others start on the triangles (see `nx_valid` above) ----
-            const bool prefetch = is_dq && !finished && !carry && a.stage_off > 0;   // (uniform; `carry`: the next item is in hand already)
+            const bool prefetch = is_dq && !finished && !carry && KA.stage_off > 0;   // (uniform; `carry`: the next item is in hand already)
             if (prefetch && tid >= BLOCK - 64) {
                 const int ln = tid & 63;
                 int idx = 0;
-                if (ln == 0) idx = (int)atomicAdd(&a.ctr->work_counter, 1u);
+                if (ln == 0) idx = (int)atomicAdd(&KA.ctr->work_counter, 1u);
                 idx = uni(idx);
                 const int nw_ = work_begin + idx;
-                const int n_work = work_end - work_begin, tail = min(a.tail, n_work);
-                const bool in_tail = a.order && idx >= n_work - tail;
+                const int n_work = work_end - work_begin, tail = min(KA.tail, n_work);
+                const bool in_tail = KA.order && idx >= n_work - tail;
                 int loaded = 0, nb_ = 0;
                 unsigned nn0 = 0xFFFFu;
                 if (nw_ < work_end && !in_tail) {   // (wave-uniform)
-                    const unsigned *rec = reinterpret_cast<const unsigned *>(a.cull + (size_t)nw_ * CULL_RECORD);
-                    const int nbv = a.worklist[nw_];
-                    const unsigned n0v = a.cull ? rec[0] : 0xFFFFu;
+                    const unsigned *rec = reinterpret_cast<const unsigned *>(KA.cull + (size_t)nw_ * CULL_RECORD);
+                    const int nbv = KA.worklist[nw_];
+                    const unsigned n0v = KA.cull ? rec[0] : 0xFFFFu;
                     nb_ = uni(nbv);
                     nn0 = (unsigned)uni((int)n0v) & 0xFFFFu;
                     int nox, noy, noz, nlx, nly, nlz;
@@ -1394,7 +1403,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
             const unsigned long long base = uni64(reinterpret_cast<unsigned long long *>(bcast + 2)[0]);
             SDF_PROF(48);
             const bool parking = base == MESH_NOT_READY;
-            const bool fits = parking || (base != ~0ull && base + (unsigned long long)e_total <= a.out_cap);
+            const bool fits = parking || (base != ~0ull && base + (unsigned long long)e_total <= KA.out_cap);
             const int park_slot = (pq_head + pq_count) % MESH_PARK_DEPTH;   // (the FIFO has room: a full one was waited for above)
             if (parking) {
                 if (tid == 0) {
@@ -1403,9 +1412,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     pend_wt(park_slot)[0] = e_w; pend_wt(park_slot)[1] = e_total;
                 }
                 pq_count++;
-                if (a.prof && tid == 0) atomicAdd(&a.prof[7], 1ull);
+                if (KA.prof && tid == 0) atomicAdd(&KA.prof[7], 1ull);
             }
-            if (a.prof && tid == 0 && is_dq) atomicAdd(&a.prof[12], 1ull);
+            if (KA.prof && tid == 0 && is_dq) atomicAdd(&KA.prof[12], 1ull);
             for (int lo = 0; fits && lo < e_total; lo += e_lcap) {
                 const int ecn = min(e_lcap, e_total - lo);
                 SDF_UNROLL
@@ -1427,7 +1436,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                             int off;
                             vw.cell(i0, i1, i2, c8);
                             mc33_load_cell(c8, 4, 2, lv);
-                            n = mc33_cell(lv, a.mc->mc33, &off);
+                            n = mc33_cell(lv, KA.mc->mc33, &off);
                         }
                         // entry: cell (15 bits) | ambiguous (1) | configuration (8) | triangle in cell (4)
                         const unsigned e = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((en & 128u) << 5) | (cfg << 4);
@@ -1438,9 +1447,9 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                 if (!is_dq) __syncthreads();   // (the list rebuilt above; a waiting batch's list has been in its slot for a round --
                                                // and the last wave, busy with the next work item, must not be waited for here)
                 SDF_PROF(3);
-                double *dst0 = a.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
-                float *park0 = my_park + ((size_t)park_slot * (size_t)a.park_cap + (size_t)lo) * 9;
-                const bool staged = is_dq && a.stage_off > 0 && !parking;   // (uniform)
+                double *dst0 = KA.out + (parking ? 0ull : base + (unsigned long long)lo) * 9ull;
+                float *park0 = my_park + ((size_t)park_slot * (size_t)KA.park_cap + (size_t)lo) * 9;
+                const bool staged = is_dq && KA.stage_off > 0 && !parking;   // (uniform)
                 // (whole waves: the transposition below is wave-wide.  The waiting batch's triangles go to the waves in chunks of 64
                 // as they come for them -- the last wave joins late, it has taken the next work item first)
                 for (int t0 = tid & ~63;; t0 += BLOCK) {
@@ -1462,7 +1471,7 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         // r04h: a quarter of the kernel's write traffic)
                         float c8[8], oa[9];
                         vw.cell(i0, i1, i2, c8);
-                        mc33_triangle(c8, 4, 2, i0, i1, i2, a.mc->mc33, j, oa);
+                        mc33_triangle(c8, 4, 2, i0, i1, i2, KA.mc->mc33, j, oa);
                         SDF_UNROLL for (int q = 0; q < 9; q++) o[q] = oa[q];
                     } else {
                         const unsigned tt3 = tri_lds[5 * cfg + min(j, 4)];
@@ -1470,13 +1479,13 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                         mc_vertex_view(vw, i0, i1, i2, (int)((tt3 >> 4) & 15u), o + 3);
                         mc_vertex_view(vw, i0, i1, i2, (int)(tt3 >> 8), o + 6);
                     }
-                    if (a.compact && !parking) {   // (uniform) the exchange's 16-byte record, straight from the registers
+                    if (KA.compact && !parking) {   // (uniform) the exchange's 16-byte record, straight from the registers
                         if (live) store_tri16(SDF_SINK, base + (unsigned long long)(lo + t), o);
                     } else if (staged) {
                         // through LDS: lane l holds triangle t0 + l (9 floats); afterwards lane l stores coordinates 64 k + l,
                         // k = 0 .. 8, of the wave's 576: consecutive lanes, consecutive addresses.  Coordinate c belongs to axis
                         // c % 3 and 64 % 3 == 1: the axis of a lane's k-th coordinate is (l + k) % 3.
-                        float *stg = reinterpret_cast<float *>(smem + a.stage_off) + (tid >> 6) * (MESH_STAGE_BYTES / 4);
+                        float *stg = reinterpret_cast<float *>(smem + KA.stage_off) + (tid >> 6) * (MESH_STAGE_BYTES / 4);
                         const int ln = tid & 63;
                         const int a0 = ln % 3;
                         const double s_[3] = {a0 == 0 ? sc0 : (a0 == 1 ? sc1 : sc2), a0 == 0 ? sc1 : (a0 == 1 ? sc2 : sc0), a0 == 0 ? sc2 : (a0 == 1 ? sc0 : sc1)};
@@ -1522,18 +1531,18 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
         if (finished) break;
     }
     SDF_FRESH();
-    place_parked(pq_count > 0 && tid < 64 ? lookback_prefetch(a.status, pend_wt(pq_head)[0], work_begin) : 0ull, true, 0);
+    place_parked(pq_count > 0 && tid < 64 ? lookback_prefetch(KA.status, pend_wt(pq_head)[0], work_begin) : 0ull, true, 0);
     SDF_PROF(5);
-    if (a.prof && tid == 0) a.prof[64 + 4 * blockIdx.x + 2] = wall_clock64();
+    if (KA.prof && tid == 0) KA.prof[64 + 4 * blockIdx.x + 2] = wall_clock64();
     if (tid == 0) {
         const unsigned long long tw = wall_clock64();
-        atomicMax(&a.ctr->t_last, tw);
-        if (blockIdx.x == 0) { a.ctr->clk_cycles = (unsigned long long)clock64() - a.ctr->clk_cycles; a.ctr->clk_ticks = tw - a.ctr->clk_ticks; }
+        atomicMax(&KA.ctr->t_last, tw);
+        if (blockIdx.x == 0) { KA.ctr->clk_cycles = (unsigned long long)clock64() - KA.ctr->clk_cycles; KA.ctr->clk_ticks = tw - KA.ctr->clk_ticks; }
     }
 #undef SDF_FRESH
 #undef SDF_PROF
 }
-#undef a
+#undef KA
 #undef SDF_SINK
 
 // host-side launcher of one (T, FULL) family, defined in sdf_mesh_inst.hip (one translation

@@ -44,6 +44,7 @@
 #include "../../include/sdf_hip.h"
 #include "mc_table.h"
 #include "sdf_device.h"
+#include "sdf_mesh2.h"
 #include "sdf_prune.h"
 #include "sdf_slab.h"
 #include "sdf_plain.h"
@@ -231,6 +232,8 @@ __device__ __forceinline__ void cull_body(const uint32_t *__restrict__ code, con
     const int ntl = cull_tasks<CB, FULL, RARE>(wcode, consts, n_instr_w, lx, ly, lz, axes, ia_state, ia_bytes, scratch, wave_sums, ia_np, ia_nd, prof, levels);
     const long long tw = prof ? clock64() : 0;
     if (tid == 0 && ntl < 0) reinterpret_cast<unsigned short *>(scratch)[0] = (unsigned short)0xFFFF;   // (else: the number of listed units, cull_tasks)
+    // (what the host needs to know before it may hand the NEXT call of this tape on this grid to k_mesh2: rarely written)
+    if (tid == 0 && (ntl > MESH2_NTL_MAX || (ntl < 0 && lx > 1 && ly > 1 && lz > 1))) const_cast<MeshCounters *>(ctr)->not_mesh2 = 1;
     __syncthreads();
     {   // the record: header + the listed units (whole tasks), and the sub-group states
         unsigned *rec = reinterpret_cast<unsigned *>(out + (size_t)w * CULL_RECORD);
@@ -448,7 +451,9 @@ struct sdf_ctx {
     DevBuf scratch_in, scratch_out, rows, rows_off, mc;
     DevBuf ext;                       // closure points / values of sdf_eval_*extern* (L_EXTERN leaves)
     DevBuf field_vals, field_vol, field_tiles;   // sdf_generate_field: a chunk's sampled values (f64), volumes (f32), tile table
-    int mesh_shape = -1;              // SDF_MESH_SHAPE override of the k_mesh launch shape (tuning)
+    int mesh2 = -1;                   // SDF_MESH2: k_mesh2 (two workgroups of 512 threads per CU) 0 never / 1 whenever the tape has a variant
+                                      // (a tile it does not hold is flagged and the call repeated) / -1 when the last call of the tape
+                                      // on the same grid says every tile is its (default)
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int prune = 1;                    // SDF_PRUNE=0 switches the interval prepass off (diagnostics)
     int parking = 1;                  // SDF_PARK=0: k_mesh waits for its predecessors instead of parking a batch (diagnostics)
@@ -485,6 +490,10 @@ struct sdf_tape {
     bool ia_rare = false;                                // ... one of them a leaf of ia_leaf_rare (the k_cull variant that knows them)
     uint32_t n_extern = 0;                               // user closures the tape reads through L_EXTERN leaves (sdf_eval_points_extern_*)
     unsigned long long hint_key = 0, hint_total_tris = 0;   // arena sizing: last call of this tape
+    // which meshing kernel the next call on the same grid takes (k_mesh2: two workgroups per CU): 0 unknown, 1 every tile of the
+    // last call was k_mesh2's (k_cull's verdict, MeshCounters::not_mesh2), 2 not so, 3 k_mesh2 ran and flagged a tile (sticky)
+    unsigned long long mesh2_key = 0;
+    int mesh2_state = 0;
     unsigned long long content_hash = 0;                    // FNV-1a of the code words and the constants' bits: what identifies the MODEL,
                                                             // on every rank alike and whatever address the tape object lands on (sdf_comm.inc)
 };
@@ -497,6 +506,7 @@ struct sdf_mesh {
     DevBuf desc, cellrecs, trilist;   // two-pass meshing: per work item / per surface cell / per triangle (sdf_device.h ItemDesc)
     DevBuf blockidx;                  // ... and per 256 triangles of the soup: the work item of the first of them
     bool pruned = false;
+    bool used_mesh2 = false;       // the meshing pass was k_mesh2's (two workgroups per CU)
     hipStream_t stream = nullptr;  // the stream the generating call ran on (the context's, or a call slot's lane)
     DevBuf counters;               // this call's MeshCounters block (pooled in the context)
     int work_begin = 0, work_end = 0;
@@ -638,7 +648,7 @@ static int ctx_init(sdf_ctx *c) {
     if (c->mc.ensure(sizeof(t))) return 1;
     HIPCHK(hipMemcpy(c->mc.p, &t, sizeof(t), hipMemcpyHostToDevice));
     if (const char *e = getenv("SDF_BOUNDS_TAG0")) c->bounds_tag0 = (unsigned)atoi(e) & 0xFFFFu;   // (tests: the first tag of the exchange words)
-    if (const char *e = getenv("SDF_MESH_SHAPE")) c->mesh_shape = atoi(e);
+    if (const char *e = getenv("SDF_MESH2")) c->mesh2 = atoi(e);
     if (const char *e = getenv("SDF_MESH_SLOTS")) c->mesh_slots = atoi(e);
     if (const char *e = getenv("SDF_PRUNE")) c->prune = atoi(e);
     if (const char *e = getenv("SDF_PARK")) c->parking = atoi(e);
@@ -692,6 +702,12 @@ int sdf_ctx_set_cull(sdf_ctx *c, int enabled) {
 int sdf_ctx_set_defer(sdf_ctx *c, int on) {
     if (!c) return fail("sdf_ctx_set_defer: ctx is NULL");
     c->defer = on ? 1 : 0;
+    return 0;
+}
+int sdf_ctx_set_mesh2(sdf_ctx *c, int mode) {
+    if (!c) return fail("sdf_ctx_set_mesh2: ctx is NULL");
+    if (mode < -1 || mode > 1) return fail("sdf_ctx_set_mesh2: -1 (by the previous call), 0 (never) or 1 (whenever the tape has a variant)");
+    c->mesh2 = mode;
     return 0;
 }
 int sdf_ctx_set_cull_levels(sdf_ctx *c, int levels) {
@@ -1047,14 +1063,32 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     for (int k = 5; k >= 0; k--) if (np <= kFile[k][0] && nd <= kFile[k][1]) slots = k;
     if (c->mesh_slots >= 0 && c->mesh_slots <= 5 && np <= kFile[c->mesh_slots][0] && nd <= kFile[c->mesh_slots][1])
         slots = c->mesh_slots;                                                        // (tuning: another file that fits)
-    // measured (profiles/r02b_shapes.txt): 4 waves per SIMD beat 2, and two samples per lane beat one
-    // wherever that shape exists; the 8-slot file runs 1024 x 1
-    int shape = slots <= 4 ? 3 : 0;
-    if (c->mesh_shape >= 0) shape = std::min(c->mesh_shape, 3);
+    // (one shape per register file: 1024 threads x 2 samples per lane, the 8-slot file 1024 x 1 -- sdf_mesh_inst.hip)
     if (precision != SDF_PRECISION_F64) return fail("k_mesh: float64 only");
-    const int rc = t->full ? sdf_launch_mesh_f64_full(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a)
-                           : sdf_launch_mesh_f64(slots, shape, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a);
+    const int rc = t->full ? sdf_launch_mesh_f64_full(slots, 0, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a)
+                           : sdf_launch_mesh_f64(slots, 0, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a);
     if (rc) return fail(std::string("k_mesh launch: ") + hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+// k_mesh2 (sdf_mesh2.h): the register file of the tape, or -1 when none of its variants holds it
+static int mesh2_slots(const sdf_tape *t) {
+    const uint32_t np = std::max(t->n_p, 1u), nd = std::max(t->n_d, 1u);
+    return (np <= 1 && nd <= 1) ? 0 : ((np <= 2 && nd <= 2) ? 1 : ((np <= 2 && nd <= 4) ? 3 : -1));
+}
+// ... and its launch: two workgroups per compute unit, each with half of the CU's LDS -- the fixed areas and ONE region that the
+// batch being sampled and the batch that waits share from its two ends
+static int launch_mesh2(sdf_tape *t, const void *code, MeshArgs &a, int nb, hipStream_t st) {
+    sdf_ctx *c = t->ctx;
+    const size_t lds = (c->lds_max / 2) & ~(size_t)1023;
+    if (lds < (size_t)M2_REGION + 16384) return fail("k_mesh2: device LDS too small");
+    a.slot_bytes = (int)((lds - M2_REGION) & ~(size_t)15);
+    a.bits_off = a.list_off = a.list_cap = a.stage_off = 0;      // (k_mesh's layout: not used)
+    a.order = nullptr; a.tail = 0; a.park = nullptr; a.park_cap = 0;
+    const int grid = std::min(nb, 2 * c->n_cu);
+    const int rc = t->full ? sdf_launch_mesh2_f64_full(mesh2_slots(t), grid, lds, st, (const uint32_t *)code, t->d_c64, a)
+                           : sdf_launch_mesh2_f64(mesh2_slots(t), grid, lds, st, (const uint32_t *)code, t->d_c64, a);
+    if (rc) return fail(std::string("k_mesh2 launch: ") + (rc < 0 ? "no variant for this tape" : hipGetErrorString((hipError_t)rc)));
     return 0;
 }
 
@@ -1095,8 +1129,10 @@ static void finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb
     m->st.t_mesh_first_us = h.t_first_inv ? (double)(~h.t_first_inv) * 0.01 : 0.0;
     m->st.t_mesh_last_us = (double)h.t_last * 0.01;
     m->pruned = pruning;
+    m->st.mesh_kernel = m->used_mesh2 ? 2 : 1;
     m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
+    if (!(t->mesh2_key == key && t->mesh2_state == 3)) { t->mesh2_key = key; t->mesh2_state = h.not_mesh2 ? 2 : 1; }
     m->st.ms_prepass = ms_prepass;
     m->st.ms_total = ms_total;
 }
@@ -1310,6 +1346,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         }
     }
     float ms = 0;
+    bool mesh2_failed = false;
     for (int attempt = 0;; attempt++) {
         MeshArgs a;
         a.compact = 0; a.xf = nullptr; a.xf_cap = 0; a.raw = nullptr; a.raw_cap = 0;
@@ -1351,7 +1388,11 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const bool twopass = c->twopass >= 0 ? c->twopass != 0 : n_instr > 96;
         DevBuf &park = async_mode ? cs.park : c->park;   // (k_mesh kernels of calls in flight may overlap in time, whichever
                                                          // streams they run on: each call slot has its own staging slots)
-        const bool parks = c->parking && !twopass;
+        // k_mesh or k_mesh2?  (k_mesh2 holds sparse tiles only: culled batches of a tape with a variant, one pass; what it meets and
+        // does not hold it flags, and the pass is repeated with k_mesh)
+        const bool use_mesh2 = culling && !twopass && !mesh2_failed && c->defer && c->mesh2 != 0 && !a.prof && mesh2_slots(t) >= 0 &&
+                               !(t->mesh2_key == key && t->mesh2_state >= 2) && (c->mesh2 > 0 || (t->mesh2_key == key && t->mesh2_state == 1));
+        const bool parks = c->parking && !twopass && !use_mesh2;
         if (parks && !park.p) { quiet = false; if (park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
         a.park = parks ? (float *)park.p : nullptr; a.park_cap = a.park ? SDF_PARK_TRIS : 0;
         a.park_spins = (unsigned)c->park_spins;
@@ -1380,7 +1421,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         const bool own_start = attempt > 0 || a.prof || !quiet;   // (something was enqueued, or the host waited, since ev[2])
         if (own_start) HIPCHK(hipEventRecord(cs.e3, st));
-        if (launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs, st)) return 1;
+        if (use_mesh2 ? launch_mesh2(t, pruning ? m->tapes.p : (const void *)t->d_code, a, nb, st)
+                      : launch_mesh(t, pruning ? m->tapes.p : (const void *)t->d_code, precision, a, grid, bs, st))
+            return 1;
+        m->used_mesh2 = use_mesh2;
         if (a.twopass) {
             const unsigned long long emit_blocks = (a.out_cap + 255ull) / 256ull;
             if (emit_blocks > 0x7fffffffull) return fail("sdf_generate: soup capacity too large for one k_emit2 launch");
@@ -1441,6 +1485,12 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         }
         m->st.n_retries = attempt;
         if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
+        if (h.overflow & (unsigned)MESH_OVERFLOW_NOT_MESH2) {   // k_mesh2 met a tile it does not hold: the same pass again, with k_mesh
+            if (!use_mesh2 || attempt >= 3) return fail("sdf_generate: a tile was flagged as not k_mesh2's by a pass that did not run k_mesh2");
+            t->mesh2_key = key; t->mesh2_state = 3;
+            mesh2_failed = true;
+            continue;
+        }
         if (h.overflow) {
             if (attempt >= 3) return fail("sdf_generate: soup buffer overflow persists");
             to_caller = false;                       // the exact need is known now: h.total
@@ -1514,6 +1564,9 @@ static int generate_big(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const
         return 1;
     int *d_org = reinterpret_cast<int *>((char *)c->field_tiles.p + sizeof(FieldTile) * CH);
     unsigned long long total = 0;
+    // the look-back words of the fused path, written by the host here: per work item its inclusive triangle prefix, so that
+    // sdf_mesh_batch_offsets serves these meshes too (the counts come back per chunk anyway)
+    std::vector<unsigned long long> prefix((size_t)std::max(h.work_end - h.work_begin, 1));
     for (int w0 = h.work_begin; w0 < h.work_end; w0 += CH) {
         const int nt = std::min(CH, h.work_end - w0);
         size_t npts = 0, big = 0;
@@ -1550,6 +1603,7 @@ static int generate_big(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const
             const unsigned long long cnt = offs[(size_t)j + 1] - offs[(size_t)j];
             kinds[(size_t)work[(size_t)(w0 + j)]] = cnt ? 2 : 1;
             if (cnt) m->st.n_nonempty++; else m->st.n_empty++;
+            prefix[(size_t)(w0 + j - h.work_begin)] = MESH_FLAG_PFX | (total + offs[(size_t)j + 1]);
         }
         if (chunk_total) {
             if ((total + chunk_total) * 72 > m->out.bytes) {       // grow the soup (geometric), keeping what is there
@@ -1574,6 +1628,8 @@ static int generate_big(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const
     m->st.n_batch_instrs = (int64_t)(t->n_words / 2 - 1) * (h.work_end - h.work_begin);
     // (work items of other shards stay 255 = "other shard", like the fused path)
     HIPCHK(hipMemcpyAsync(m->kinds.p, kinds.data(), (size_t)nb, hipMemcpyHostToDevice, st));
+    if (h.work_end > h.work_begin)
+        HIPCHK(hipMemcpyAsync((unsigned long long *)m->status.p + h.work_begin, prefix.data(), (size_t)(h.work_end - h.work_begin) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(stream_wait(st));
     float ms_pre = 0, ms_tot = 0;
     HIPCHK(hipEventElapsedTime(&ms_pre, c->ev[0], c->ev[1]));
@@ -1846,7 +1902,15 @@ int sdf_mesh_wait(sdf_mesh *m, int *emitted) {
         m->st.ms_mesh = ms;
         cs.busy = false; cs.owner = nullptr;      // (everything the slot held for this mesh has been read)
         if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
-        if (h.overflow && pd.compact) {
+        if (h.overflow & (unsigned)MESH_OVERFLOW_NOT_MESH2) { pd.tape->mesh2_key = pd.key; pd.tape->mesh2_state = 3; }   // (the repeat takes k_mesh)
+        if ((h.overflow & (unsigned)MESH_OVERFLOW_NOT_MESH2) && !pd.compact) {
+            // k_mesh2 met a tile it does not hold: the call is repeated synchronously, into the caller's buffer, with k_mesh
+            const double *X = pd.axes.data(), *Y = X + pd.nx, *Z = Y + pd.ny;
+            if (generate_impl(pd.tape, m, X, pd.nx, Y, pd.ny, Z, pd.nz, pd.bs, pd.sparse, pd.shard_index, pd.shard_count, pd.precision,
+                              pd.d_out, pd.cap_out, false))
+                return 1;
+            m->st.n_retries += 1;
+        } else if (h.overflow && pd.compact) {
             // a slab that was too small: the exchange protocol retries with larger slabs on EVERY rank (sdf_amd/dist.py)
             finish_stats(pd.tape, m, h, pd.nb, pd.pruning, pd.n_instr, pd.key, ms_pre, ms_tot);
             m->emitted_to = nullptr;

@@ -48,7 +48,7 @@ class SdfStats(ctypes.Structure):
         ('ms_prepass', ctypes.c_double), ('ms_mesh', ctypes.c_double), ('ms_emit', ctypes.c_double),
         ('ms_total', ctypes.c_double), ('n_pruned_instrs', _c_i64), ('n_batch_instrs', _c_i64),
         ('n_sampled_voxels', _c_i64), ('ms_mesh_device', ctypes.c_double), ('sclk_mhz', ctypes.c_double),
-        ('t_mesh_first_us', ctypes.c_double), ('t_mesh_last_us', ctypes.c_double),
+        ('t_mesh_first_us', ctypes.c_double), ('t_mesh_last_us', ctypes.c_double), ('mesh_kernel', ctypes.c_int64),
     ]
 
 
@@ -68,6 +68,7 @@ ABI = {
     'sdf_ctx_set_twopass': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_tail_order': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_defer': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'sdf_ctx_set_mesh2': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_set_cull_levels': (ctypes.c_int, [_vp, ctypes.c_int]),
     'sdf_ctx_synchronize': (ctypes.c_int, [_vp]),
     'sdf_ctx_trim': (ctypes.c_int, [_vp]),
@@ -136,7 +137,7 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def build_info():
@@ -521,6 +522,12 @@ class Engine:
     def set_defer(self, on):
         """one-kernel meshing: sparse tiles + deferred emission (default) or dense tiles + parking; same results"""
         _check(self.lib, self.lib.sdf_ctx_set_defer(self.ctx, int(bool(on))))
+
+    def set_mesh2(self, mode):
+        """which fused kernel meshes a call: -1 k_mesh2 (two workgroups of 512 threads per CU) when the previous call of the tape on
+        the same grid found every tile to be its, else k_mesh (default); 1 k_mesh2 whenever the tape has a variant; 0 never.  Same
+        results; `stats()['mesh_kernel']` says which ran"""
+        _check(self.lib, self.lib.sdf_ctx_set_mesh2(self.ctx, int(mode)))
 
     def set_cull_levels(self, levels):
         """interval levels of the culling pass: 2, 3 or 0 = the library's choice by the tape (default); same results"""

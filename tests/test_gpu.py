@@ -154,6 +154,8 @@ def test_batch_size_above_32_goes_through_device_memory(bs, ns, oracle_lib, eng)
         assert np.array_equal(m.points(), o.points) and np.array_equal(m.kinds(), o.kinds)
         assert (st['skipped'], st['empty'], st['nonempty']) == tuple(int((o.kinds == k).sum()) for k in (0, 1, 2))
         assert st['n_eval_voxels'] == o.n_eval and st['triangles'] == len(o.points) // 3
+        offs = m.batch_offsets()                                 # (r05 advisor: these meshes had no look-back words)
+        assert offs[0] == 0 and offs[-1] == len(o.points) // 3 and np.array_equal(np.diff(offs) > 0, o.kinds == 2)
         m.close()
     # shards concatenate to the whole; a caller buffer is not filled but the soup is there; the asynchronous entry point too
     parts = []
@@ -1770,3 +1772,98 @@ def test_native_exchange_between_processes_on_one_device(world, skip_shard, firs
         assert any(r[2] >= 1 for r in out[0][2])                     # the tiny first capacity was flagged and repeated
     else:
         assert all(r[2] == 0 for r in out[0][2])
+
+
+def test_core_module_seams_are_the_batch_loop(ns, eng):
+    """`core._skip`, `core._worker`, `core._marching_cubes` (reference sdf/core.py:16-18, 28-43, 45-60): the module-level
+    functions a reference user can call on ONE job return what `generate` computes for that batch -- the skip verdict, None /
+    [] / the batch's slice of the soup bit for bit -- and the marching-cubes seam returns skimage's soup and raises like it"""
+    f = fixtures.build('ex_example', ns)
+    X, Y, Z, _ = core.grid_axes(((-0.85, -0.85, -0.85), (0.85, 0.85, 0.85)), samples=2 ** 18)
+    mesh = eng.generate(f, X, Y, Z, 32, True)
+    pts, offs, kinds = mesh.points(), mesh.batch_offsets(), mesh.kinds()
+    mesh.close()
+    b = seen = 0
+    for xs in range(0, len(X), 32):
+        for ys in range(0, len(Y), 32):
+            for zs in range(0, len(Z), 32):
+                job = (X[xs:xs + 33], Y[ys:ys + 33], Z[zs:zs + 33])
+                assert core._skip(f, job) == (kinds[b] == 0)
+                r = core._worker(f, job, None, True)
+                if kinds[b] == 0:
+                    assert r is None
+                elif kinds[b] == 1:
+                    assert len(r) == 0
+                else:
+                    assert np.array_equal(r, pts[3 * offs[b]:3 * offs[b + 1]])
+                    seen += 1
+                assert core._worker(f, job, None, False) is not None       # sparse=False never skips
+                b += 1
+    assert b == len(kinds) and seen >= 8
+    name = MC_NAMES[0]
+    got = core._marching_cubes(MC['vol_' + name])
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), MC['soup_' + name].view(np.uint32))
+    with pytest.raises(RuntimeError):
+        core._marching_cubes(np.full((4, 4, 4), 0.0, np.float32))            # no surface
+    with pytest.raises(ValueError):
+        core._marching_cubes(np.ones((4, 4, 4)))                             # level outside the volume's range
+    with pytest.raises(ValueError):
+        core._marching_cubes(np.ones((4, 4)))
+
+
+@pytest.mark.parametrize('name,samples', [('ex_example', 2 ** 24), ('ex_example', 1500000), ('ex_example', 2 ** 27), ('ex_blobby', 2 ** 23),
+                                          ('ex_gearlike', 2 ** 22), ('ex_knurling', 2 ** 21), ('ex_pawn', 2 ** 22), ('ex_weave', 2 ** 20)])
+def test_two_workgroups_per_cu_same_soup(name, samples, ns, eng):
+    """k_mesh2 (csrc/sdf_mesh2.h: the fused kernel as two workgroups of 512 threads per compute unit, sparse tiles in ONE region of LDS
+    shared from its two ends, no parking) against k_mesh: the same soup, per-batch offsets, verdicts and counters bit for bit -- forced
+    (sdf_ctx_set_mesh2(1): a tile the kernel does not hold is flagged on the device and the pass repeated with k_mesh), synchronous,
+    into a caller buffer and asynchronously with calls in flight; and by default the SECOND call of a tape on a grid takes it when
+    k_cull found every tile to be its."""
+    import torch
+    f = fixtures.build(name, ns)
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, BOUNDS[name])), samples=samples)
+    keys = ('triangles', 'skipped', 'empty', 'nonempty', 'n_eval_voxels', 'n_ambiguous_cells', 'n_pruned_instrs', 'n_sampled_voxels')
+    try:
+        eng.set_mesh2(0)
+        m = eng.generate(f, X, Y, Z, 32, True)
+        ref = (m.points(), m.kinds(), m.batch_offsets(), m.stats())
+        m.close()
+        assert ref[3]['mesh_kernel'] == 1 and ref[3]['triangles'] > 1000
+        eng.set_mesh2(1)
+        ran2 = 0
+        for rep in range(2):
+            m = eng.generate(f, X, Y, Z, 32, True)
+            got = (m.points(), m.kinds(), m.batch_offsets(), m.stats())
+            m.close()
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+            for k in keys:
+                assert got[3][k] == ref[3][k], (rep, k)
+            ran2 += got[3]['mesh_kernel'] == 2
+            if got[3]['mesh_kernel'] == 1 and rep == 0:
+                assert got[3]['n_retries'] >= 1 or name == 'ex_weave'      # flagged and repeated (weave: two passes, never k_mesh2's)
+        # calls in flight into caller buffers
+        nt = len(ref[0]) // 3
+        bufs = [torch.full((9 * nt + 9,), -7.0, dtype=torch.float64, device='cuda:0') for _ in range(3)]
+        ms = [eng.generate(f, X, Y, Z, 32, True, out_ptr=b.data_ptr(), out_cap=nt, wait=False) for b in bufs]
+        for m, b in zip(ms, bufs):
+            m.wait()
+            assert m.n_triangles == nt and float(b[-1]) == -7.0
+            host = b[:9 * nt].cpu().numpy().reshape(-1, 3) if m.emitted else m.points()
+            assert np.array_equal(host, ref[0])
+            m.close()
+        # the default: the tape's previous call on this grid decides
+        eng.set_mesh2(-1)
+        f2 = fixtures.build(name, ns)                    # (a tape object of its own: no verdict yet)
+        kernels = []
+        for rep in range(3):
+            m = eng.generate(f2, X, Y, Z, 32, True)
+            st = m.stats()
+            assert np.array_equal(m.points(), ref[0]) and np.array_equal(m.batch_offsets(), ref[2])
+            kernels.append(st['mesh_kernel'])
+            m.close()
+        assert kernels[0] == 1 or ran2 == 2              # (the engine caches device tapes by content: f2 may find f's verdict)
+        assert kernels[1] == kernels[2]
+        if ran2 == 2:
+            assert kernels[1] == 2
+    finally:
+        eng.set_mesh2(-1)

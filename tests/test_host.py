@@ -134,8 +134,8 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.sdf_abi_version() == engine.ABI_VERSION
-    # struct layout of sdf_stats: 11 int64 + 4 double + 3 int64 + 4 double; sdf_exchange_stats: 14 int64 + 4 double + 64 int64
-    assert ctypes.sizeof(engine.SdfStats) == 22 * 8
+    # struct layout of sdf_stats: 11 int64 + 4 double + 3 int64 + 4 double + 1 int64 (ABI 8: mesh_kernel); sdf_exchange_stats: 14 int64 + 4 double + 64 int64
+    assert ctypes.sizeof(engine.SdfStats) == 23 * 8
     assert ctypes.sizeof(engine.SdfExchangeStats) == (14 + 4 + 64) * 8
 
 

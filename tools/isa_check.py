@@ -24,7 +24,25 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+
+
+def find_objdump():
+    """llvm-objdump of the toolchain that built the library: next to $HIPCC's clang, under $ROCM_PATH, /opt/rocm, or on PATH"""
+    import shutil
+    cands = []
+    hipcc = os.environ.get('HIPCC') or shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+    for r in (root, os.environ.get('ROCM_PATH'), '/opt/rocm'):
+        if r:
+            cands += [os.path.join(r, 'lib', 'llvm', 'bin', 'llvm-objdump'), os.path.join(r, 'llvm', 'bin', 'llvm-objdump')]
+    cands.append(shutil.which('llvm-objdump'))
+    for c in cands:
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+OBJDUMP = find_objdump()
 INTERP = ('k_mesh', 'k_skip', 'k_eval_points', 'k_eval_grid', 'k_eval_tiles', 'k_estimate_bounds')
 INTERVAL = ('k_cull', 'k_prune_list')       # the interval-arithmetic interpreters (sdf_interval.h): a switch, no jump table
 PLAIN = ('k_compact', 'k_scan_rows', 'k_scan_items', 'k_emit2', 'k_expand', 'k_pack_slab', 'k_mc_rows', 'k_mc_emit', 'k_field_rows',
@@ -70,6 +88,10 @@ def kernels(obj_bytes):
 
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'sdf_amd', 'csrc', 'libsdf_hip.so')
+    import shutil
+    if OBJDUMP is None or shutil.which('c++filt') is None:   # nothing to check WITH is not a failed check
+        print('isa_check: WARNING: %s not found -- the library was NOT checked' % ('llvm-objdump' if OBJDUMP is None else 'c++filt'), file=sys.stderr)
+        return 0
     allk = {}
     for co in code_objects(path):
         allk.update(kernels(co))
@@ -95,7 +117,7 @@ def main():
             bad.append('%s: kernel missing from the library' % k)
     print('%d kernels in %s' % (len([1 for m in allk if re.search(r'k_[a-z]', m)]), path))
     for b in bad:
-        print('ISA CHECK FAILED: ' + b)
+        print('ISA CHECK FAILED: ' + b, file=sys.stderr)
     return 1 if bad else 0
 
 
