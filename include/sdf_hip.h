@@ -101,10 +101,11 @@ int sdf_ctx_set_twopass(sdf_ctx *ctx, int mode);
 int sdf_ctx_set_defer(sdf_ctx *ctx, int on);
 /* Which fused kernel meshes a call (ABI 8): k_mesh -- one persistent workgroup of 1024 threads per compute unit -- or k_mesh2 --
  * two of 512 threads, each with half the CU's LDS, so that one workgroup's counting / look-back / emission overlaps the other's
- * interpreter; it holds sparse tiles only.  -1 (default; SDF_MESH2 sets the initial state) = k_mesh2 when the previous call of
- * the same tape on the same grid found every tile to be its (the first call takes k_mesh), 1 = k_mesh2 whenever the tape has a
- * variant (a tile it does not hold is flagged on the device and the pass repeated with k_mesh), 0 = never.  Results are
- * identical either way; sdf_stats.mesh_kernel says which one ran. */
+ * interpreter; it holds sparse tiles only.  0 (default; SDF_MESH2 sets the initial state) = never: measured in round 6, k_mesh2
+ * is bit-identical and 4 - 6 % slower at 512^3 (profiles/r06e_two_wg.json); -1 = k_mesh2 when the previous call of the same tape
+ * on the same grid found every tile to be its (the first call takes k_mesh), 1 = k_mesh2 whenever the tape has a variant (a tile
+ * it does not hold is flagged on the device and the pass repeated with k_mesh).  Results are identical either way;
+ * sdf_stats.mesh_kernel says which one ran. */
 int sdf_ctx_set_mesh2(sdf_ctx *ctx, int mode);
 /* interval levels of the second interval pass: 2 = boxes of 8^3 and groups of 4^3 cells, 3 = + sub-groups of 2^3 cells,
  * 0 = the library's choice by the tape (default; SDF_CULL_LEVELS sets the initial state).  Results are identical. */

@@ -451,9 +451,10 @@ struct sdf_ctx {
     DevBuf scratch_in, scratch_out, rows, rows_off, mc;
     DevBuf ext;                       // closure points / values of sdf_eval_*extern* (L_EXTERN leaves)
     DevBuf field_vals, field_vol, field_tiles;   // sdf_generate_field: a chunk's sampled values (f64), volumes (f32), tile table
-    int mesh2 = -1;                   // SDF_MESH2: k_mesh2 (two workgroups of 512 threads per CU) 0 never / 1 whenever the tape has a variant
+    int mesh2 = 0;                    // SDF_MESH2: k_mesh2 (two workgroups of 512 threads per CU) 0 never (default: measured in r06, bit-identical
+                                      // and 4 - 6 % slower than k_mesh at 512^3, profiles/r06e_two_wg.json) / 1 whenever the tape has a variant
                                       // (a tile it does not hold is flagged and the call repeated) / -1 when the last call of the tape
-                                      // on the same grid says every tile is its (default)
+                                      // on the same grid says every tile is its
     DevBuf prof;                      // SDF_MESH_PROF=1: per-phase cycle counters of k_mesh (diagnostics)
     int prune = 1;                    // SDF_PRUNE=0 switches the interval prepass off (diagnostics)
     int parking = 1;                  // SDF_PARK=0: k_mesh waits for its predecessors instead of parking a batch (diagnostics)
@@ -1390,7 +1391,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                                                          // streams they run on: each call slot has its own staging slots)
         // k_mesh or k_mesh2?  (k_mesh2 holds sparse tiles only: culled batches of a tape with a variant, one pass; what it meets and
         // does not hold it flags, and the pass is repeated with k_mesh)
-        const bool use_mesh2 = culling && !twopass && !mesh2_failed && c->defer && c->mesh2 != 0 && !a.prof && mesh2_slots(t) >= 0 &&
+        const bool use_mesh2 = culling && !twopass && !mesh2_failed && c->defer && c->mesh2 != 0 && mesh2_slots(t) >= 0 &&
                                !(t->mesh2_key == key && t->mesh2_state >= 2) && (c->mesh2 > 0 || (t->mesh2_key == key && t->mesh2_state == 1));
         const bool parks = c->parking && !twopass && !use_mesh2;
         if (parks && !park.p) { quiet = false; if (park.ensure((size_t)c->n_cu * MESH_PARK_DEPTH * SDF_PARK_TRIS * 36)) return 1; }
@@ -1417,7 +1418,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             a.block_item = (const int *)m->blockidx.p;
             a.cells_cap = a.tlist_cap = (unsigned long long)cap_t;
         }
-        if (a.prof) HIPCHK(hipMemsetAsync(a.prof, 0, 128, st));   // (words 16.. are k_cull's: cleared before the prepass)
+        if (a.prof) {   // (words 16.. are k_cull's: cleared before the prepass; behind byte 512: the workgroups' timelines)
+            HIPCHK(hipMemsetAsync(a.prof, 0, 128, st));
+            HIPCHK(hipMemsetAsync((unsigned char *)a.prof + 512, 0, 4096 * 32, st));
+        }
         const int grid = std::min(nb, c->n_cu);   // persistent workgroups; surplus ones find the list empty
         const bool own_start = attempt > 0 || a.prof || !quiet;   // (something was enqueued, or the host waited, since ev[2])
         if (own_start) HIPCHK(hipEventRecord(cs.e3, st));
@@ -1460,6 +1464,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             unsigned long long pc[64];
             HIPCHK(hipMemcpy(pc, c->prof.p, 512, hipMemcpyDeviceToHost));
             {   // timeline of the workgroups: when each ran out of work and when it was done, relative to the first start
+                const int grid = use_mesh2 ? std::min(nb, 2 * c->n_cu) : std::min(nb, c->n_cu);
                 std::vector<unsigned long long> tl((size_t)4 * grid);
                 HIPCHK(hipMemcpy(tl.data(), (unsigned char *)c->prof.p + 512, tl.size() * 8, hipMemcpyDeviceToHost));
                 unsigned long long t0 = ~0ull, t_end = 0;
@@ -1469,8 +1474,10 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
                     const double o = (double)(tl[4 * i + 1] - t0) * 0.01, d = (double)(tl[4 * i + 2] - t0) * 0.01;   // us
                     s_out += o; s_done += d; mn_out = std::min(mn_out, o); mx_out = std::max(mx_out, o); t_end = std::max(t_end, tl[4 * i + 2]);
                 }
-                fprintf(stderr, "[k_mesh prof] %d workgroups; out of work after min %.1f avg %.1f max %.1f us; done after avg %.1f, last %.1f us\n",
-                        grid, mn_out, s_out / grid, mx_out, s_done / grid, (double)(t_end - t0) * 0.01);
+                double first_hi = 0;   // the latest start: workgroups that were not resident from the beginning start late
+                for (int i = 0; i < grid; i++) first_hi = std::max(first_hi, (double)(tl[4 * i] - t0) * 0.01);
+                fprintf(stderr, "[k_mesh prof] %d workgroups (kernel %d), last of them started after %.1f us; out of work after min %.1f avg %.1f max %.1f us; done after avg %.1f, last %.1f us\n",
+                        grid, use_mesh2 ? 2 : 1, first_hi, mn_out, s_out / grid, mx_out, s_done / grid, (double)(t_end - t0) * 0.01);
             }
             fprintf(stderr, "[k_cull prof] work items by listed tasks (of 563; bins of 64, last: not culled): %llu %llu %llu %llu %llu %llu %llu %llu %llu | %llu\n",
                     pc[32], pc[33], pc[34], pc[35], pc[36], pc[37], pc[38], pc[39], pc[40], pc[41]);
@@ -1487,6 +1494,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
         if (h.overflow & 2u) return fail("sdf_generate: ordered-allocation look-back timed out");
         if (h.overflow & (unsigned)MESH_OVERFLOW_NOT_MESH2) {   // k_mesh2 met a tile it does not hold: the same pass again, with k_mesh
             if (!use_mesh2 || attempt >= 3) return fail("sdf_generate: a tile was flagged as not k_mesh2's by a pass that did not run k_mesh2");
+            if (getenv("SDF_MESH2_DEBUG")) fprintf(stderr, "[k_mesh2] flagged: overflow word 0x%x (32 dense tile, 64 tasks, 128 region, 256 cells, 512 list)\n", h.overflow);
             t->mesh2_key = key; t->mesh2_state = 3;
             mesh2_failed = true;
             continue;

@@ -25,7 +25,7 @@
 
 namespace sdfk {
 
-enum { M2_BLOCK = 512, M2_NWAVE = 8, M2_NTL_MAX = MESH2_NTL_MAX, M2_UNIT_CAP = 8 * M2_NTL_MAX, M2_CELL_CHUNKS = 4,
+enum { M2_BLOCK = 512, M2_NWAVE = 8, M2_NTL_MAX = MESH2_NTL_MAX, M2_UNIT_CAP = 8 * M2_NTL_MAX,
        // dynamic LDS: scan buffers | bcast | scan buffers 2 | ntri table | axes | two batch headers | triangle table |
        // two sets of column words | sign bits (= transposition area) | work area (k_cull's record) | the region
        M2_SUMS = 0, M2_BCAST = 64, M2_SUMS2 = 128, M2_NTRI = 192, M2_AXES = 448, M2_HDR = 1248, M2_TRI = 1376,
@@ -73,6 +73,12 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
     }
     for (int i = tid; i < M2_BITS_BYTES / 8; i += BLOCK) bits[i] = 0ull;   // (every round leaves them cleared for the next)
     const int work_begin = KA.ctr->work_begin, work_end = KA.ctr->work_end;
+    // SDF_MESH_PROF=1: cycles of thread 0 per phase, summed over the workgroups (k_mesh's words: 0 taking + loading the item, 1 sampling,
+    // 2 counting, 48 look-back, 4 emission, 5 the rest; 7 rounds counted twice, 12 emissions, 13 rounds that wrote the waiting batch first),
+    // and the workgroup's timeline (start / out of work / done on the 100 MHz counter)
+    if (KA.prof && tid == 0) KA.prof[64 + 4 * blockIdx.x] = wall_clock64();
+    long long tprev = KA.prof ? clock64() : 0;
+#define M2_PROF(K) do { if (KA.prof && tid == 0) { const long long tn = clock64(); atomicAdd(&KA.prof[K], (unsigned long long)(tn - tprev)); tprev = tn; } } while (0)
     if (tid == 0) {   // the kernel's start on the device's own clock (sdf_stats.ms_mesh_device, sclk_mhz)
         const unsigned long long tw = wall_clock64();
         atomicMax(&KA.ctr->t_first_inv, ~tw);
@@ -114,6 +120,7 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
         const bool was_recount = recount;
         hold = false; recount = false;
         const bool finished = w >= work_end;
+        if (finished && KA.prof && tid == 0 && KA.prof[64 + 4 * blockIdx.x + 1] == 0) KA.prof[64 + 4 * blockIdx.x + 1] = wall_clock64();
         if (finished && wait_side < 0) break;
         // ---- what kind of tile?  where does it go? ----
         bool flush_only = finished;       // this round only writes the waiting batch
@@ -137,9 +144,10 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
         if (!finished) batch_origin(g, b, ox, oy, oz, lx, ly, lz);
         const int smp_bytes = 256 * ntl;
         bool unsupported = false;
+        unsigned why = 0;                 // (diagnostics: which limit a flagged tile met -- bits 5.. of the overflow word, SDF_MESH2_DEBUG)
         if (!finished) {
-            if (degenerate && lx > 1 && ly > 1 && lz > 1) unsupported = true;              // a tile k_cull left dense
-            if (ntl > M2_NTL_MAX || smp_bytes + M2_MIN_LIST > R) unsupported = true;
+            if (degenerate && lx > 1 && ly > 1 && lz > 1) { unsupported = true; why = 32u; }              // a tile k_cull left dense
+            if (ntl > M2_NTL_MAX || smp_bytes + M2_MIN_LIST > R) { unsupported = true; why = ntl > M2_NTL_MAX ? 64u : 128u; }
             if (!unsupported && !was_recount && wait_side >= 0 && wait_bytes + smp_bytes + M2_MIN_LIST > R) { flush_only = true; hold = true; }
         }
         const int side = was_recount ? held_side : (wait_side == 0 ? 1 : 0);
@@ -152,7 +160,7 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
         if (!flush_only && (unsupported || degenerate)) {
             // ---- nothing to mesh here: an empty batch (or one the host will mesh with k_mesh: flagged) ----
             if (tid == 0) {
-                if (unsupported) atomicOr(&KA.ctr->overflow, (unsigned)MESH_OVERFLOW_NOT_MESH2);
+                if (unsupported) atomicOr(&KA.ctr->overflow, (unsigned)MESH_OVERFLOW_NOT_MESH2 | why);
                 atomicAdd(&KA.ctr->n_empty, 1u);
                 atomicAdd(&KA.ctr->n_eval, (unsigned long long)(lx * ly * lz));
                 atomicAdd(&KA.ctr->n_sampled, (unsigned long long)(lx * ly * lz));
@@ -197,6 +205,7 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
                     else if (tid >= 128 && tid < 128 + lz) axes[66 + tid - 128] = g.Z[oz + tid - 128];
                 }
                 __syncthreads();
+                M2_PROF(0);
                 if (KA.tape_stride && tid == 0)
                     atomicAdd(&KA.ctr->n_pruned, (unsigned long long)KA.n_instr - reinterpret_cast<const unsigned long long *>(wcode)[KA.tape_stride - 1]);
                 // ---- 1a. sign bits of the decided sub-groups, straight from their two-bit states (k_mesh: cull-sign-fill) ----
@@ -244,6 +253,7 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
                 }
                 __syncthreads();
                 SDF_FRESH();
+                M2_PROF(1);
             }
             const TileView cvw{smp, col_of(side), lyz, lz, true};
             // ---- 2. count (wave 0 first asks for the waiting batch's predecessors: the answer arrives meanwhile) ----
@@ -284,32 +294,37 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
                 ncells += tot;
             }
             ncells = uni(ncells);
-            // the cell table, then the triangle list, behind the samples (side 0: upwards from their end; side 1: downwards to their start)
-            bool fits = ncells <= M2_CELL_CHUNKS * BLOCK && 4 * ncells <= list_free;
+            // The free area behind the samples, F entries, numbered AWAY from the samples (side 0: upwards from their end; side 1:
+            // downwards from their start): the triangle list grows from entry 0, the cell table -- one entry per surface cell, needed
+            // only until the cell's triangles are listed -- lies at its far end.  The cells go through in chunks of BLOCK (a thread per
+            // cell); a chunk's triangles are listed right behind its scan, as long as the list stays below the table's unread part.
+            unsigned *fa0 = reinterpret_cast<unsigned *>(side == 0 ? cs + smp_bytes : cs);
+            const int fdir = side == 0 ? 1 : -1, foff = side == 0 ? 0 : -1;
+#define M2_FA(D) fa0[fdir * (D) + foff]
+            const int F = list_free >> 2;
+            bool fits = ncells <= F;
             int my_amb = 0;
-            unsigned cinfo[M2_CELL_CHUNKS];
-            int cn[M2_CELL_CHUNKS], coff[M2_CELL_CHUNKS];
             if (fits) {   // (uniform)
-                unsigned *ctab = reinterpret_cast<unsigned *>(side == 0 ? cs + smp_bytes : cs - 4 * ncells);
+                const int tab0 = F - ncells;
                 SDF_UNROLL
                 for (int k = 0; k < RPT; k++) {
                     const int r = tid + k * BLOCK;
                     unsigned m = row_mask[k];
-                    int pos = row_cell0[k];
+                    int pos = tab0 + row_cell0[k];
                     while (m) {
                         const int i2 = __ffs((int)m) - 1;
                         m &= m - 1u;
-                        ctab[pos++] = (unsigned)r | ((unsigned)i2 << 10);
+                        M2_FA(pos) = (unsigned)r | ((unsigned)i2 << 10);
+                        pos++;
                     }
                 }
                 __syncthreads();
-                SDF_UNROLL
-                for (int k = 0; k < M2_CELL_CHUNKS; k++) {
-                    const int sidx = tid + k * BLOCK;
+                for (int s0 = 0; s0 < ncells; s0 += BLOCK) {   // (uniform)
+                    const int sidx = s0 + tid;
                     int n = 0;
                     unsigned info = 0;
                     if (sidx < ncells) {
-                        const unsigned ce = ctab[sidx];
+                        const unsigned ce = M2_FA(tab0 + sidx);
                         const int r = (int)(ce & 1023u), i2 = (int)((ce >> 10) & 31u), i0 = fast_div(r, inv_c1), i1 = r - i0 * c1;
                         unsigned long long rb[4];
                         row_signs(i0, i1, rb);
@@ -327,20 +342,16 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
                         // entry: cell (15 bits) | ambiguous (1) | configuration (8) | triangle in cell (4)
                         info = ((unsigned)((i0 << 10) | (i1 << 5) | i2) << 13) | ((e & 128u) << 5) | (cfg << 4);
                     }
-                    int tot = 0;
-                    coff[k] = total;
-                    if (k * BLOCK < ncells) { coff[k] += M2_SCAN(n, tot); total += tot; }   // (uniform)
-                    cinfo[k] = info; cn[k] = n;
+                    int tot;
+                    const int off = total + M2_SCAN(n, tot);
+                    const int t_new = uni(total + tot);
+                    if (t_new > min(F, tab0 + s0 + BLOCK)) { fits = false; break; }   // (uniform) the list would run into the table's unread part
+                    for (int j = 0; j < n; j++) M2_FA(off + j) = info | (unsigned)j;
+                    total = t_new;
                 }
-                total = uni(total);
-                fits = 4 * total <= list_free;
             }
 #undef M2_SCAN
             if (fits) {   // (uniform)
-                unsigned *lst = reinterpret_cast<unsigned *>(side == 0 ? cs + smp_bytes : cs - ((4 * total + 15) & ~15));
-                SDF_UNROLL
-                for (int k = 0; k < M2_CELL_CHUNKS; k++)
-                    for (int j = 0; j < cn[k]; j++) lst[coff[k] + j] = cinfo[k] | (unsigned)j;
                 // the sign bits are dead from here on: cleared NOW for the next tile's sign fill (behind this round's remaining barriers)
                 for (int i = tid; i < M2_BITS_BYTES / 8; i += BLOCK) bits[i] = 0ull;
                 if (tid < 64) publish_count(KA.status, w, work_begin, (unsigned long long)total);
@@ -349,7 +360,7 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
                     xf[0] = axes[0]; xf[1] = axes[33]; xf[2] = axes[66];
                     xf[3] = axes[1] - axes[0]; xf[4] = axes[34] - axes[33]; xf[5] = axes[67] - axes[66];
                     int *m = hdr_i(side);
-                    m[0] = w; m[1] = total; m[2] = (int)(cs - region); m[3] = (int)(reinterpret_cast<unsigned char *>(lst) - region);
+                    m[0] = w; m[1] = total; m[2] = (int)(cs - region); m[3] = (int)(reinterpret_cast<unsigned char *>(fa0) - region);
                     if (KA.compact && w - work_begin < KA.xf_cap) {   // the batch's transform travels with the compact soup
                         double *x2 = KA.xf + (size_t)(w - work_begin) * 6;
                         SDF_UNROLL for (int q = 0; q < 6; q++) x2[q] = xf[q];
@@ -364,22 +375,26 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
                 // the list does not fit next to the waiting batch: that one is written first, then this batch is counted again with
                 // the region to itself (its samples and sign bits stay where they are)
                 hold = true; recount = true; held_side = side; total = 0;
+                if (KA.prof && tid == 0) atomicAdd(&KA.prof[7], 1ull);
             } else {
                 // ... nor alone: not this kernel's (flagged; the host repeats the call with k_mesh)
                 for (int i = tid; i < M2_BITS_BYTES / 8; i += BLOCK) bits[i] = 0ull;
                 if (tid < 64) publish_count(KA.status, w, work_begin, 0ull);
-                if (tid == 0) { atomicOr(&KA.ctr->overflow, (unsigned)MESH_OVERFLOW_NOT_MESH2); KA.kinds[b] = 1; }
+                if (tid == 0) { atomicOr(&KA.ctr->overflow, (unsigned)MESH_OVERFLOW_NOT_MESH2 | (ncells > F ? 256u : 512u)); KA.kinds[b] = 1; }
                 total = 0;
             }
         }
         SDF_FRESH();
         __syncthreads();   // (the header, the list)
+        M2_PROF(2);
+        if (KA.prof && tid == 0 && hold && !recount) atomicAdd(&KA.prof[13], 1ull);
 
         // ---- 3 + 4. the waiting batch's triangles, one round after it was counted ----
         if (wait_side >= 0) {   // (uniform)
             const int e_w = uni(hdr_i(wait_side)[0]), e_total = uni(hdr_i(wait_side)[1]);
             const float *e_smp = reinterpret_cast<const float *>(region + uni(hdr_i(wait_side)[2]));
-            const unsigned *lst = reinterpret_cast<const unsigned *>(region + uni(hdr_i(wait_side)[3]));
+            const unsigned *e_fa0 = reinterpret_cast<const unsigned *>(region + uni(hdr_i(wait_side)[3]));   // triangle t at e_fa0[e_dir * t + e_off]
+            const int e_dir = wait_side == 0 ? 1 : -1, e_off = wait_side == 0 ? 0 : -1;
             const TileView vw{e_smp, col_of(wait_side), 0, 0, true};
             const double *exf = hdr_xf(wait_side);
             const double of0 = exf[0], of1 = exf[1], of2 = exf[2], sc0 = exf[3], sc1 = exf[4], sc2 = exf[5];
@@ -428,6 +443,8 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
             }
             if (prefetch) nx_valid = true;
             const unsigned long long base = uni64(reinterpret_cast<unsigned long long *>(bcast + 2)[0]);
+            M2_PROF(48);
+            if (KA.prof && tid == 0) atomicAdd(&KA.prof[12], 1ull);
             const bool fits = base != ~0ull && base + (unsigned long long)e_total <= KA.out_cap;
             // the transposition area: the sign bits' (cleared above, cleared again below) -- or, while a held batch's sign bits must
             // survive (recount), the work area (no item is taken then, and the held batch's record has served)
@@ -440,7 +457,7 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
                 if (t0 >= e_total) break;
                 const int t = t0 + (tid & 63);
                 const bool live = t < e_total;
-                const unsigned e = lst[live ? t : e_total - 1];
+                const unsigned e = e_fa0[e_dir * (live ? t : e_total - 1) + e_off];
                 const int j = (int)(e & 15u), cfg = (int)((e >> 4) & 255u), cell = (int)(e >> 13);
                 const int i0 = cell >> 10, i1 = (cell >> 5) & 31, i2 = cell & 31;
                 float o[9];
@@ -480,6 +497,7 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
                 }
             }
             __syncthreads();   // (the region, bcast, the transposition area are reused)
+            M2_PROF(4);
             if (!recount && !KA.compact) {   // the sign bits' area served as the transposition area: cleared for the next sign fill
                 for (int i = tid; i < M2_BITS_BYTES / 8; i += BLOCK) bits[i] = 0ull;
                 __syncthreads();
@@ -487,13 +505,17 @@ void k_mesh2(const uint32_t *__restrict__ code, const T *__restrict__ consts, Me
         }
         if (counted) { wait_side = side; wait_bytes = smp_bytes + ((4 * total + 15) & ~15); }
         else { wait_side = -1; wait_bytes = 0; }
+        M2_PROF(5);
         if (finished) break;
     }
+    if (KA.prof && tid == 0) KA.prof[64 + 4 * blockIdx.x + 2] = wall_clock64();
     if (tid == 0) {
         const unsigned long long tw = wall_clock64();
         atomicMax(&KA.ctr->t_last, tw);
         if (blockIdx.x == 0) { KA.ctr->clk_cycles = (unsigned long long)clock64() - KA.ctr->clk_cycles; KA.ctr->clk_ticks = tw - KA.ctr->clk_ticks; }
     }
+#undef M2_FA
+#undef M2_PROF
 #undef SDF_FRESH
 #undef KA
 }

@@ -524,9 +524,9 @@ class Engine:
         _check(self.lib, self.lib.sdf_ctx_set_defer(self.ctx, int(bool(on))))
 
     def set_mesh2(self, mode):
-        """which fused kernel meshes a call: -1 k_mesh2 (two workgroups of 512 threads per CU) when the previous call of the tape on
-        the same grid found every tile to be its, else k_mesh (default); 1 k_mesh2 whenever the tape has a variant; 0 never.  Same
-        results; `stats()['mesh_kernel']` says which ran"""
+        """which fused kernel meshes a call: 0 always k_mesh (default: k_mesh2 measured slower, profiles/r06e_two_wg.json); -1 k_mesh2
+        (two workgroups of 512 threads per CU) when the previous call of the tape on the same grid found every tile to be its; 1 k_mesh2
+        whenever the tape has a variant.  Same results; `stats()['mesh_kernel']` says which ran"""
         _check(self.lib, self.lib.sdf_ctx_set_mesh2(self.ctx, int(mode)))
 
     def set_cull_levels(self, levels):

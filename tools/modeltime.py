@@ -25,8 +25,8 @@ for job in jobs:
             m = eng.generate(f, X, Y, Z, BS, True); st = m.stats(); m.close()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        print('%-9s 2^%s %dx%dx%d passes %d: wall %.2f ms, prepass %.3f mesh %.3f ms; batches %d work %d tris %d; sampled %.1f%% pruned %.1f%%'
-              % (name, k, len(X), len(Y), len(Z), on, 1e3 * best, st['ms_prepass'], st['ms_mesh'], st['batches'],
+        print('%-9s 2^%s %dx%dx%d passes %d: wall %.2f ms, prepass %.3f mesh %.3f ms (kernel %d, %d retries); batches %d work %d tris %d; sampled %.1f%% pruned %.1f%%'
+              % (name, k, len(X), len(Y), len(Z), on, 1e3 * best, st['ms_prepass'], st['ms_mesh'], st['mesh_kernel'], st['n_retries'], st['batches'],
                  st['empty'] + st['nonempty'], st['triangles'], 100.0 * st['n_sampled_voxels'] / max(st['n_eval_voxels'], 1),
                  100.0 * st['n_pruned_instrs'] / max(st['n_batch_instrs'], 1)), flush=True)
 eng.set_prune(1); eng.set_cull(1)

@@ -10,8 +10,8 @@ export TMPDIR=/tmp
 echo "tests rc=$?"; tail -15 $O/tests.txt
 for rep in 1 2; do
   for v in 0 1; do
-    SDF_MESH2=$v timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-other-configs > $O/bench_m2${v}_$rep.txt 2> $O/bench_m2${v}_$rep.err
-    SDF_MESH2=$v timeout 300 python tools/modeltime.py --on-only example:27 pawn:27 blobby:30 gearlike:30 knurling:27 > $O/models_m2${v}_$rep.txt 2>&1
+    SDF_MESH2_DEBUG=1 SDF_MESH2=$v timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-other-configs > $O/bench_m2${v}_$rep.txt 2> $O/bench_m2${v}_$rep.err
+    SDF_MESH2_DEBUG=1 SDF_MESH2=$v timeout 300 python tools/modeltime.py --on-only example:24 example:27 pawn:27 blobby:30 > $O/models_m2${v}_$rep.txt 2>&1
   done
 done
 python - "$O" <<'PY'
@@ -22,5 +22,5 @@ for f in sorted(glob.glob(sys.argv[1]+'/bench_*.txt')):
             r=json.loads(l)
             print(f.split('/')[-1], 'ms/step', r['ms_per_step'], 'lat', r['latency_ms_per_call'], 'k_mesh', r['isolated_calls']['k_mesh_ms_hip_events']['median'], 'parity', r['parity_check'])
 PY
-grep -h passes $O/models_*.txt | sort | cut -c1-110
+grep -H "passes\|k_mesh2" $O/models_*.txt | cut -c1-160
 tail -3 $O/bench_m21_1.err
