@@ -316,12 +316,23 @@ if __name__ == '__main__':
     X, Y, Z, _ = core.grid_axes(bounds, samples=2 ** 19)
     nb = (-(-len(X) // 32)) * (-(-len(Y) // 32)) * (-(-len(Z) // 32))
     ref = oracle.generate(f, X, Y, Z, 32, True).points
-    a = bench.whole_soup_vs_oracle('gearlike', bounds, 19, ref, nb, budget_cores=3)
+    offs = np.zeros(nb + 1, np.int64)          # where each batch's triangles start (the device's Mesh.batch_offsets())
+    for b in range(nb):
+        offs[b + 1] = offs[b] + len(oracle.generate(f, X, Y, Z, 32, True, batch_range=(b, b + 1)).points) // 3
+    assert 3 * offs[-1] == len(ref)
+    a = bench.whole_soup_vs_oracle('gearlike', bounds, 19, ref, offs, budget_cores=3)
     host = ref.copy(); host[len(host) // 2, 1] += 1e-7
-    b = bench.whole_soup_vs_oracle('gearlike', bounds, 19, host, nb, budget_cores=3)
-    assert a['coordinates_that_differ'] == 0 and a['whole_soup'] and a['within_1e-5'] and a['vertices'] == len(ref), a
+    b = bench.whole_soup_vs_oracle('gearlike', bounds, 19, host, offs, budget_cores=3)
+    assert a['coordinates_that_differ'] == 0 and a['whole_soup'] and a['within_1e-5'] and a['coordinates'] == 3 * len(ref) and a['coverage'] == 1.0, a
     assert b['coordinates_that_differ'] == 1 and abs(b['max_abs_diff_over_extent'] * 4.2 - 1e-7) < 1e-12 and b['whole_soup'], b
-    print('ok', a['vertices'])
+    # out of time before a piece came back: no verdict, coverage 0 (a comparison of nothing must not say "true")
+    c = bench.soup_verdict(0, 3 * len(ref), 0, 0.0)
+    assert c['coverage'] == 0.0 and c['within_1e-5'] is None and c['share_bit_equal'] is None and not c['whole_soup'], c
+    # a soup with a triangle too many in one batch is an error, not a shifted comparison
+    offs2 = offs.copy(); offs2[nb // 2 + 1:] += 1
+    d = bench.whole_soup_vs_oracle('gearlike', bounds, 19, np.concatenate([ref, ref[:3]]), offs2, budget_cores=3)
+    assert 'error' in d, d
+    print('ok', a['coordinates'])
 ''' % ROOT
     path = os.path.join(ROOT, 'tests', '_whole_soup_check.py')
     try:
@@ -355,7 +366,7 @@ def test_bench_optional_section_cannot_swallow_the_headline_line():
 
 def test_bench_whole_soup_comparison_survives_dead_workers():
     """whole_soup_vs_oracle's workers are plain processes that leave files: workers that die (here: a model they cannot build) make the
-    comparison stop with the prefix it has -- at once, not at the end of its time budget, and never in a pool's shutdown"""
+    comparison stop with what it has (coverage 0, no verdict) -- at once, not at the end of its time budget, and never in a pool's shutdown"""
     import subprocess
     import sys
     import time
@@ -364,8 +375,8 @@ import sys
 sys.path.insert(0, %r)
 import numpy as np, bench
 if __name__ == '__main__':
-    r = bench.whole_soup_vs_oracle('no_such_model', ((-1, -1, -1), (1, 1, 1)), 15, np.zeros((30, 3)), 8, budget_cores=3, budget_s=120.0)
-    assert r['vertices'] == 0 and not r['whole_soup'] and r['coordinates_that_differ'] == 0, r
+    r = bench.whole_soup_vs_oracle('no_such_model', ((-1, -1, -1), (1, 1, 1)), 15, np.zeros((30, 3)), np.arange(9) * 10 // 8, budget_cores=3, budget_s=120.0)
+    assert r['coordinates'] == 0 and r['coverage'] == 0.0 and not r['whole_soup'] and r['within_1e-5'] is None and r['coordinates_that_differ'] is None, r
     print('ok', r['checker_seconds'])
 ''' % ROOT
     path = os.path.join(ROOT, 'tests', '_whole_soup_dead.py')
