@@ -31,7 +31,7 @@ SDF_DECLARE_MESH_LAUNCH(MESH_NAME, MESH_T) {
         switch (slots) {
         case 0: return launch_one<1, 1, 2, 1024, true>(grid, lds, stream, code, consts, a);
         case 1: return launch_one<2, 2, 2, 1024, true>(grid, lds, stream, code, consts, a);
-        case 2: return launch_one<4, 2, 2, 1024, true>(grid, lds, stream, code, consts, a);
+        case 2: return launch_one<4, 2, 2, 1024, true>(grid, lds, stream, code, consts, a);   // (one sample per lane: 8 spilled registers instead of 184 and 43 % slower, profiles/r06f_weave_ns1.json)
         case 3: return launch_one<2, 4, 2, 1024, true>(grid, lds, stream, code, consts, a);
         case 4: return launch_one<4, 4, 2, 1024, true>(grid, lds, stream, code, consts, a);
         default: return launch_one<8, 8, 1, 1024, true>(grid, lds, stream, code, consts, a);
