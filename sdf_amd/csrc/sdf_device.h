@@ -233,6 +233,9 @@ __device__ __forceinline__ unsigned cell_config(const unsigned long long *rb, in
     return cfg;
 }
 
+#ifndef SDF_TAPE_WARM
+#define SDF_TAPE_WARM 1
+#endif
 #ifndef SDF_FAST_VERTEX
 #define SDF_FAST_VERTEX 1
 #endif
@@ -1385,6 +1388,17 @@ __global__ __launch_bounds__(BLOCK) void k_mesh(const uint32_t *__restrict__ cod
                     const unsigned n0v = KA.cull ? rec[0] : 0xFFFFu;
                     nb_ = uni(nbv);
                     nn0 = (unsigned)uni((int)n0v) & 0xFFFFu;
+#if SDF_TAPE_WARM
+                    // the next batch's own tape (interval prepass, one copy per batch in device memory) through the scalar cache NOW:
+                    // the interpreter asks for one instruction ahead only, so every new 64-byte line -- 8 instructions -- would
+                    // otherwise be a round trip to L2 that all sixteen waves of the workgroup sit out together
+                    if (KA.tape_stride) {
+                        const unsigned long long *tw = reinterpret_cast<const unsigned long long *>(code + (size_t)nb_ * (size_t)KA.tape_stride * 2);
+                        unsigned long long acc_w = 0;
+                        for (int l = 0; l < KA.tape_stride; l += 8) acc_w ^= tw[l];
+                        asm volatile("" :: "s"(acc_w));
+                    }
+#endif
                     int nox, noy, noz, nlx, nly, nlz;
                     batch_origin(g, nb_, nox, noy, noz, nlx, nly, nlz);
                     if (ln < nlx) axes[ln] = g.X[nox + ln];                       // (the waiting batch's transform sits in its slot)
