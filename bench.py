@@ -610,7 +610,7 @@ def main():
     e2e = None
     if world == 1 and args.model == 'example' and args.precision == 'f64':
         trace('generate end to end')
-        tt, tb, tl = [], [], []
+        tt, tb, tl, tg, tp = [], [], [], [], []
         for i in range(12):
             f2, _ = build_model(args.model)
             t1 = time.perf_counter()
@@ -618,14 +618,23 @@ def main():
             tt.append(1e3 * (time.perf_counter() - t1))
             n_e2e = len(pts) // 3
             del pts
+            # (its two device-side parts on their own: meshing into 16-byte records, and records -> float64 rows on the host threads)
+            t1 = time.perf_counter(); mesh = eng.generate(tape, X, Y, Z, 32, True, records=True); tg.append(1e3 * (time.perf_counter() - t1))
+            t1 = time.perf_counter(); pts = mesh.points(core.WORKERS); tp.append(1e3 * (time.perf_counter() - t1))
+            mesh.close()
+            del pts
             f3, _ = build_model(args.model)
             t1 = time.perf_counter(); core._estimate_bounds(f3); tb.append(1e3 * (time.perf_counter() - t1))
             f4, _ = build_model(args.model)
             t1 = time.perf_counter(); eng.tape_for(f4); tl.append(1e3 * (time.perf_counter() - t1))
         e2e = {'wall_ms': stats3(tt[2:]), 'triangles': n_e2e, 'voxels_per_sec_median': round(grid_voxels / (1e-3 * float(np.median(tt[2:]))), 1),
-               'of_which_ms': {'estimate_bounds': stats3(tb[2:]), 'lower_and_upload_tape': stats3(tl[2:])},
+               'of_which_ms': {'estimate_bounds': stats3(tb[2:]), 'lower_and_upload_tape': stats3(tl[2:]),
+                               'meshing_into_records': stats3(tg[2:]), 'records_to_float64_rows_on_host_threads': stats3(tp[2:])},
+               'host_threads': min(core.WORKERS, 64),
                'what': 'f.generate(samples=2**%d, verbose=False) on a fresh model object, 10 calls after 2 warm-up calls: bounds + tape + grid + '
-                       'meshing + D2H of the float64 soup (pinned blocks) + the (n, 3) ndarray' % args.samples_log2}
+                       'meshing into 16-byte triangle records (sdf_generate_records) + D2H of the records (47 MB instead of the 212 MB of the '
+                       'float64 soup) while `workers` host threads write the (n, 3) float64 ndarray from them (pinned blocks); '
+                       'until round 5: D2H of the float64 soup, 4.4 ms' % args.samples_log2}
 
     # ---- a SUSTAINED run of the headline job: >= 2000 steps (>= 0.4 s of kernels back to back), same steps in flight, with the
     # shader clock the kernels measured themselves -- the 20-step headline is a 5 ms burst that the clocks could flatter ----

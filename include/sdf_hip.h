@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SDF_ABI_VERSION 8
+#define SDF_ABI_VERSION 9
 
 #define SDF_PRECISION_F64 0 /* float64 evaluation like the reference's NumPy path: what every sdf_generate* entry point samples in */
 #define SDF_PRECISION_F32 1 /* float32 evaluation: sdf_eval_* and sdf_estimate_bounds only (the meshing path refuses it since round 5) */
@@ -210,6 +210,16 @@ int sdf_generate_to_device_async(sdf_tape *tape, const double *X, int nx, const 
                                  int batch_size, int sparse, int64_t shard_index, int64_t shard_count, int precision,
                                  void *d_out, int64_t cap_tris, sdf_mesh **out);
 int sdf_mesh_wait(sdf_mesh *mesh, int *emitted);
+/* `generate` for a caller who wants the soup ON THE HOST -- the list of points the reference's generate() returns
+ * (reference sdf/core.py:131-141): like sdf_generate (one device, the whole work list), but the triangles are written as
+ * 16-byte records into a slab of the library's (the exchange unit below: marching cubes' local float32 coordinates + one
+ * transform per work item) instead of as 72-byte float64 triangles, and sdf_mesh_emit_host_workers makes the float64 soup
+ * on host threads while the records arrive: 47 MB over PCIe instead of 212 MB at 512^3, the same bits (it performs
+ * k_expand's `double(local) * scale + offset` on the same operands).  The slab is sized from the last call of the same
+ * model on the same grid; the first such call, batch_size > 32 and tapes with user closures are served by sdf_generate.
+ * Every reader of the mesh works: those that need the float64 soup on the device get it from k_expand on demand. */
+int sdf_generate_records(sdf_tape *tape, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
+                         int batch_size, int sparse, int precision, sdf_mesh **out);
 /* Multi-GPU exchange (north_star: "batches shard naturally over the 8 GPUs of one node with an RCCL all-gather of
  * triangle buffers"; the reference itself has no distributed path).  A rank meshes its shard of the surviving-batch
  * work list into a SLAB of fixed capacity in caller-owned device memory -- header (counts, statistics, overflow
@@ -284,6 +294,10 @@ int64_t sdf_mesh_triangles(sdf_mesh *mesh);
  * reference sdf/core.py:58-60) into caller-owned device / host memory of 9*T doubles */
 int sdf_mesh_emit_device(sdf_mesh *mesh, void *d_out);
 int sdf_mesh_emit_host(sdf_mesh *mesh, double *h_out);
+/* the same with the reference's `workers=` (sdf/core.py:87, 131): the number of host threads that expand the records of a
+ * mesh of sdf_generate_records into the float64 soup (<= 0: the machine's, at most 64); ignored by any other mesh, whose
+ * soup is copied as it is.  sdf_mesh_emit_host = workers 0. */
+int sdf_mesh_emit_host_workers(sdf_mesh *mesh, double *h_out, int workers);
 /* triangles [first_tri, first_tri + n_tris) of the soup only (9 doubles each) */
 int sdf_mesh_emit_host_range(sdf_mesh *mesh, int64_t first_tri, int64_t n_tris, double *h_out);
 /* n_batches + 1 entries: h_out[b] = index (within this shard's soup) of the first triangle of batch b in

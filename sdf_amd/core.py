@@ -11,7 +11,9 @@ Differences a caller can observe:
 * ``generate`` returns ONE float64 ndarray of shape (3*T, 3) instead of a Python list of
   3*T tiny arrays (same ``len``, indexing, ``write_binary_stl`` and ``np.unique``
   behaviour).
-* ``workers`` is accepted and ignored (the device runs every batch concurrently).
+* ``workers`` does not drive the sampling (the device runs every batch concurrently); it is the
+  number of host threads that turn the device's 16-byte triangle records into the float64 rows
+  of the returned array (``sdf_mesh_emit_host_workers``; at most 64).
 * when ``torch.distributed`` is initialised with world_size > 1 the surviving batches are
   sharded over the ranks and the triangle buffers all-gathered (sdf_amd/dist.py), so
   every rank still returns the complete soup in reference order.
@@ -198,7 +200,9 @@ def generate(
         else:
             points = soup.cpu().numpy().reshape(-1, 3)
     else:
-        mesh = eng.generate(tape, X, Y, Z, batch_size, sparse)
+        # (the soup is wanted on the host: it travels as 16-byte records and `workers` host threads make the float64
+        # rows from them -- the one place the reference's `workers=` still means something here)
+        mesh = eng.generate(tape, X, Y, Z, batch_size, sparse, records=not (_stl or _weld))
         try:
             stats = mesh.stats()
             if _stl:
@@ -208,7 +212,7 @@ def generate(
                 welded = mesh.weld()
                 points = np.empty((3 * mesh.n_triangles, 0))
             else:
-                points = mesh.points()
+                points = mesh.points(workers)
         finally:
             mesh.close()
 

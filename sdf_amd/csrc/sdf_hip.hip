@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@
 #include "sdf_mesh2.h"
 #include "sdf_prune.h"
 #include "sdf_slab.h"
+#include "sdf_expand_host.h"
 #include "sdf_plain.h"
 #include "sdf_bounds.h"
 
@@ -476,6 +478,13 @@ struct sdf_ctx {
     int cull_levels = 0;              // SDF_CULL_LEVELS=2 / 3: interval levels of k_cull (3: + sub-groups of 2^3 cells); 0: by the tape (see generate_impl)
     DevBuf bounds_work;               // k_estimate_bounds_w: the waves' exchange words (tagged per call, sdf_bounds.hip)
     unsigned bounds_tag = 0, bounds_tag0 = 0;
+    // sdf_generate_records: what the last call of a MODEL (content hash) on a grid needed -- triangles, raw-area triangles -- so that the
+    // next one, possibly through a fresh tape object of the same model, can size its slab without a host round trip
+    struct RecHint { unsigned long long tris = 0, raw = 0; };
+    std::map<std::pair<unsigned long long, unsigned long long>, RecHint> rec_hints;
+    void *h_rec = nullptr;            // pinned staging of sdf_mesh_emit_host_workers: a slab's head, raw area and records on their way to the host threads
+    size_t h_rec_bytes = 0;
+    std::vector<hipEvent_t> rec_ev;   // ... one event per piece of the copy
 };
 
 struct sdf_tape {
@@ -528,6 +537,13 @@ struct sdf_mesh {
     double *weld_pts = nullptr;    // sdf_mesh_weld: unique rows / row -> unique row (hipMalloc'ed by sdf_weld.hip)
     long long *weld_inv = nullptr;
     long long weld_n = -1;
+    // sdf_generate_records: the triangles were written as 16-byte records into a slab of the library's (sdf_slab.h); the float64 soup
+    // is made on the host threads (sdf_mesh_emit_host_workers) or, for the readers that want it on the device, by k_expand on demand
+    bool records = false;
+    DevBuf slab;
+    long long slab_items = 0, slab_tris = 0, n_raw = 0;
+    bool rec_overflow = false;     // the slab (or its raw area) was too small: rec_need_tris is the capacity that holds the call
+    long long rec_need_tris = 0;
 };
 
 namespace sdfk {
@@ -677,6 +693,8 @@ int sdf_ctx_destroy(sdf_ctx *c) {
     for (auto &cs : c->slots) for (hipEvent_t e : {cs.e0, cs.e2, cs.e3, cs.e4, cs.done}) if (e) (void)hipEventDestroy(e);
     for (auto &cs : c->slots) if (cs.stream) (void)hipStreamDestroy(cs.stream);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
+    for (hipEvent_t e : c->rec_ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -1133,9 +1151,22 @@ static void finish_stats(sdf_tape *t, sdf_mesh *m, const MeshCounters &h, int nb
     m->st.mesh_kernel = m->used_mesh2 ? 2 : 1;
     m->st.n_batch_instrs = (int64_t)(n_instr - 1) * (h.work_end - h.work_begin);
     t->hint_key = key; t->hint_total_tris = std::max<unsigned long long>(h.total, 1);
+    {   // (per MODEL and grid, for sdf_generate_records; a handful of entries per job -- the map is emptied when it grows past 4096)
+        auto &rh = t->ctx->rec_hints;
+        if (rh.size() > 4096) rh.clear();
+        sdf_ctx::RecHint &e = rh[std::make_pair(t->content_hash, key)];
+        e.tris = std::max<unsigned long long>(h.total, 1); e.raw = h.n_raw;
+    }
     if (!(t->mesh2_key == key && t->mesh2_state == 3)) { t->mesh2_key = key; t->mesh2_state = h.not_mesh2 ? 2 : 1; }
     m->st.ms_prepass = ms_prepass;
     m->st.ms_total = ms_total;
+}
+
+// what identifies "the same job on the same grid" for the capacity hints (sdf_tape::hint_key, sdf_ctx::rec_hints)
+static unsigned long long grid_key(int nx, int ny, int nz, int bs, int sparse, int64_t shard_index, int64_t shard_count) {
+    return ((unsigned long long)nx << 42) ^ ((unsigned long long)ny << 21) ^ (unsigned long long)nz ^
+           ((unsigned long long)shard_index << 56) ^ ((unsigned long long)shard_count << 48) ^
+           ((unsigned long long)bs << 36) ^ (sparse ? 1ull << 63 : 0ull);
 }
 
 static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, const double *Y, int ny, const double *Z, int nz,
@@ -1279,9 +1310,7 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
     // workgroups -- counts RESIDENT workgroups, and a k_mesh that shares the device with another call's k_mesh may have
     // fewer of them for a while; the neighbours fill the tail of such a call anyway)
     const bool tail_order = culling && c->tail_order && tail_max >= 2 && !async_mode;
-    const unsigned long long key = ((unsigned long long)nx << 42) ^ ((unsigned long long)ny << 21) ^ (unsigned long long)nz ^
-                                   ((unsigned long long)shard_index << 56) ^ ((unsigned long long)shard_count << 48) ^
-                                   ((unsigned long long)bs << 36) ^ (sparse ? 1ull << 63 : 0ull);
+    const unsigned long long key = grid_key(nx, ny, nz, bs, sparse, shard_index, shard_count);
     if (culling) {
         if (c->prof.p) HIPCHK(hipMemsetAsync((unsigned char *)c->prof.p + 128, 0, 384, st));
         if (m->cull.ensure((size_t)nb * CULL_RECORD) || (tail_order && m->order.ensure(MESH_TAIL_MAX * sizeof(int)))) return 1;
@@ -1499,6 +1528,15 @@ static int generate_impl(sdf_tape *t, sdf_mesh *m, const double *X, int nx, cons
             mesh2_failed = true;
             continue;
         }
+        if (compact) {   // (the synchronous records mode, sdf_generate_records: its caller sizes the slab again and repeats the call)
+            const SlabLayout L(slab_items, cap_out);
+            const bool raw_over = (long long)h.n_raw > L.raw_cap;
+            m->n_raw = (long long)h.n_raw;
+            m->rec_overflow = (h.overflow & 1u) != 0 || raw_over || (long long)(h.work_end - h.work_begin) > (long long)slab_items;
+            m->rec_need_tris = std::max<long long>((long long)h.total, raw_over ? (long long)h.n_raw * SLAB_RAW_DIV : 0ll);
+            m->emitted_to = nullptr;
+            break;
+        }
         if (h.overflow) {
             if (attempt >= 3) return fail("sdf_generate: soup buffer overflow persists");
             to_caller = false;                       // the exact need is known now: h.total
@@ -1710,6 +1748,51 @@ int sdf_generate_to_device_async(sdf_tape *t, const double *X, int nx, const dou
                                  int64_t cap_tris, sdf_mesh **out) {
     if (!d_out || cap_tris <= 0) return fail("sdf_generate_to_device_async: output buffer is NULL or empty");
     return generate_entry(t, X, nx, Y, ny, Z, nz, bs, sparse, shard_index, shard_count, precision, d_out, cap_tris, out, true);
+}
+
+// `generate` for a caller who wants the soup ON THE HOST (what the reference's `generate` returns, sdf/core.py:131-141): the triangles
+// are written as 16-byte records into a slab of the library's (sdf_slab.h: local float32 coordinates + a transform per work item,
+// the multi-GPU exchange unit) instead of as 72-byte float64 triangles, and sdf_mesh_emit_host_workers makes the float64 soup on host
+// threads while the records are still arriving: 47 MB over PCIe instead of 212 MB at 512^3.  The slab is sized from what the last
+// call of the same MODEL on the same grid needed (sdf_ctx::rec_hints, keyed by the tape's content: a fresh tape object of the same
+// model finds it); without such a hint -- the first call -- the call is an ordinary sdf_generate, which leaves the hint.  A slab that
+// turns out too small is sized again and the call repeated.  The mesh answers every reader: those that want the float64 soup on
+// the device (STL records, weld, sdf_mesh_emit_device, ranges) get it from k_expand on demand.
+int sdf_generate_records(sdf_tape *t, const double *X, int nx, const double *Y, int ny, const double *Z, int nz, int bs,
+                         int sparse, int precision, sdf_mesh **out) {
+    if (!t || !X || !Y || !Z || !out) return fail("sdf_generate_records: NULL argument");
+    sdf_ctx *c = t->ctx;
+    const unsigned long long key = grid_key(nx, ny, nz, bs, sparse, 0, 1);
+    const auto it = c->rec_hints.find(std::make_pair(t->content_hash, key));
+    const long long nb64 = (long long)((nx + std::max(bs, 1) - 1) / std::max(bs, 1)) * ((ny + std::max(bs, 1) - 1) / std::max(bs, 1)) * ((nz + std::max(bs, 1) - 1) / std::max(bs, 1));
+    if (bs < 1 || bs > 32 || t->n_extern || it == c->rec_hints.end() || nb64 <= 0 || nb64 > 0x7fffffffLL || precision != SDF_PRECISION_F64)
+        return generate_entry(t, X, nx, Y, ny, Z, nz, bs, sparse, 0, 1, precision, nullptr, 0, out);     // (every check and message of sdf_generate)
+    HIPCHK(set_device(c->device));
+    long long cap_tris = (long long)(it->second.tris + it->second.tris / 64 + 1024);
+    if ((long long)it->second.raw > cap_tris / SLAB_RAW_DIV + SLAB_RAW_MIN) cap_tris = std::max<long long>(cap_tris, (long long)(it->second.raw + it->second.raw / 8) * SLAB_RAW_DIV);
+    *out = nullptr;
+    sdf_mesh *m = new sdf_mesh();
+    m->ctx = c;
+    m->records = true;
+    int attempt = 0;
+    for (;; attempt++) {
+        m->slab_items = nb64; m->slab_tris = cap_tris;
+        const SlabLayout L(m->slab_items, m->slab_tris);
+        int rc = m->slab.ensure(L.bytes);
+        if (!rc) rc = generate_impl(t, m, X, nx, Y, ny, Z, nz, bs, sparse, 0, 1, precision, m->slab.p, cap_tris, false, m->slab_items);
+        if (!rc && m->rec_overflow && attempt >= 3) rc = fail("sdf_generate_records: slab overflow persists");
+        if (rc) {
+            const std::string keep = g_err;
+            sdf_mesh_destroy(m);
+            g_err = keep;
+            return 1;
+        }
+        if (!m->rec_overflow) break;
+        cap_tris = m->rec_need_tris + m->rec_need_tris / 64 + 1024;
+    }
+    m->st.n_retries = attempt;
+    *out = m;
+    return 0;
 }
 
 // The batch loop of `generate` (reference sdf/core.py:114-141) around a field that lives on the HOST: a user-written
@@ -1961,9 +2044,23 @@ int64_t sdf_mesh_triangles(sdf_mesh *m) {
 // where the soup of a mesh lives: the caller's buffer of sdf_generate_to_device, or the library's
 static const void *mesh_soup(const sdf_mesh *m) { return m->emitted_to ? m->emitted_to : m->out.p; }
 
+// a mesh of sdf_generate_records holds 16-byte records; a reader that wants the float64 soup on the device gets it from k_expand, once
+static int ensure_soup(sdf_mesh *m) {
+    if (!m->records || m->out.p || m->st.n_triangles == 0) return 0;
+    sdf_ctx *c = m->ctx;
+    HIPCHK(set_device(c->device));
+    if (m->out.ensure((size_t)m->st.n_triangles * 72)) return 1;
+    SlabPtrs ptrs = {};
+    ptrs.p[0] = (const unsigned char *)m->slab.p;
+    HIPCHK((hipError_t)sdf_launch_expand(c->stream, ptrs, 1, m->slab_items, m->slab_tris, (double *)m->out.p, (unsigned long long)m->st.n_triangles));
+    return 0;
+}
+#define MESH_SOUP_READY(m) do { if (ensure_soup(m)) return 1; } while (0)
+
 int sdf_mesh_emit_device(sdf_mesh *m, void *d_out) {
     if (!m || !d_out) return fail("sdf_mesh_emit_device: NULL argument");
     MESH_READY(m);
+    MESH_SOUP_READY(m);
     sdf_ctx *c = m->ctx;
     if (m->st.n_triangles == 0 || d_out == mesh_soup(m)) return 0;
     HIPCHK(set_device(c->device));
@@ -1987,19 +2084,108 @@ static int copy_to_host(sdf_ctx *c, void *h_dst, const void *d_src, size_t bytes
     return 0;
 }
 
-int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) {
+// The soup on the host.  A mesh of sdf_generate_records sends its RECORDS (16 bytes per triangle + a transform per work item) and the
+// float64 soup is made where it is wanted, by `workers` host threads (<= 0: as many as the machine has, at most 64; the reference's
+// `workers=` argument, sdf/core.py:87) -- block by block while the later records are still on the link: the pieces of the copy are
+// followed by events, the calling thread publishes how far the records have arrived and takes blocks itself in between.  The
+// arithmetic is k_expand's (`double(local) * scale + offset` on the same operands): the soup is the one the device would write.
+// Any other mesh: one copy of the float64 soup, as before (`workers` is ignored).
+int sdf_mesh_emit_host_workers(sdf_mesh *m, double *h_out, int workers) {
     if (!m || !h_out) return fail("sdf_mesh_emit_host: NULL argument");
     MESH_READY(m);
     if (m->st.n_triangles == 0) return 0;
-    HIPCHK(set_device(m->ctx->device));
-    return copy_to_host(m->ctx, h_out, mesh_soup(m), (size_t)m->st.n_triangles * 72);
+    sdf_ctx *c = m->ctx;
+    HIPCHK(set_device(c->device));
+    if (!m->records || m->out.p) return copy_to_host(c, h_out, mesh_soup(m), (size_t)m->st.n_triangles * 72);
+    const long long nt = m->st.n_triangles, ni = (long long)m->work_end - m->work_begin, nraw = std::min<long long>(m->n_raw, SlabLayout(m->slab_items, m->slab_tris).raw_cap);
+    const SlabLayout L(m->slab_items, m->slab_tris);
+    // pinned staging: [prefix ni x 8 | transforms ni x 48 | raw area nraw x 36 | records nt x 16]
+    const size_t off_xf = (size_t)ni * 8, off_raw = off_xf + (size_t)ni * 48, off_rec = (off_raw + (size_t)nraw * 36 + 63) & ~(size_t)63;
+    const size_t need = off_rec + (size_t)nt * 16;
+    if (c->h_rec_bytes < need) {
+        if (c->h_rec) (void)hipHostFree(c->h_rec);
+        c->h_rec = nullptr; c->h_rec_bytes = 0;
+        const size_t want = need + need / 8 + (1u << 20);
+        if (host_malloc(&c->h_rec, want) != hipSuccess) { c->h_rec = nullptr; return fail("sdf_mesh_emit_host: pinned staging for the records"); }
+        c->h_rec_bytes = want;
+    }
+    char *hs = (char *)c->h_rec;
+    const char *slab = (const char *)m->slab.p;
+    // the pieces: head (prefix, transforms, raw area) first, then the records in ~ 12 pieces of whole blocks
+    sdfhost::ExpandJob job;
+    static const long long rec_block = [] { const char *e = getenv("SDF_REC_BLOCK"); return e && atoll(e) >= 64 ? atoll(e) : 8192ll; }();     // (tuning)
+    static const long long rec_pieces = [] { const char *e = getenv("SDF_REC_PIECES"); return e && atoll(e) >= 1 ? std::min(atoll(e), 64ll) : 12ll; }();
+    job.block = rec_block;
+    const long long nblk = (nt + job.block - 1) / job.block;
+    const long long blk_per_piece = std::max<long long>(8, (nblk + rec_pieces - 1) / rec_pieces);
+    const int npieces = (int)((nblk + blk_per_piece - 1) / blk_per_piece);
+    while ((int)c->rec_ev.size() < npieces + 1) {
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->rec_ev.push_back(e);
+    }
+    hipStream_t st = c->stream;
+    static const bool rec_trace = getenv("SDF_REC_TRACE") != nullptr;   // (diagnostics: when the pieces arrived, when the last block was written)
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); };
+    int nthreads = workers > 0 ? workers : (int)std::thread::hardware_concurrency();
+    nthreads = std::max(1, std::min(nthreads, 64));
+    nthreads = (int)std::min<long long>(nthreads, std::max<long long>(nblk, 1));
+    job.prefix = (const unsigned long long *)hs; job.xf = (const double *)(hs + off_xf);
+    job.raw = (const float *)(hs + off_raw); job.raw_cap = std::max<long long>(nraw, 1);
+    job.recs = (const Tri16 *)(hs + off_rec);
+    job.n_items = ni; job.n_tris = nt; job.out = h_out;
+    std::vector<float> blk_trace;
+    if (rec_trace) { blk_trace.assign((size_t)2 * nblk, 0.0f); job.trace = blk_trace.data(); job.t_origin = tr0; }
+    sdfhost::Pool &pool = sdfhost::Pool::get();
+    // (from here on the helpers hold the job: an error lets them go before it returns)
+#define RECCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { job.abort.store(1); pool.wait(job); return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    pool.start(job, nthreads - 1);                       // (the helpers wake up while the copies are enqueued; this thread is one of the workers too)
+    RECCHK(hipMemcpyAsync(hs, slab + L.prefix_off, (size_t)ni * 8, hipMemcpyDeviceToHost, st));
+    RECCHK(hipMemcpyAsync(hs + off_xf, slab + L.xf_off, (size_t)ni * 48, hipMemcpyDeviceToHost, st));
+    if (nraw) RECCHK(hipMemcpyAsync(hs + off_raw, slab + L.raw_off, (size_t)nraw * 36, hipMemcpyDeviceToHost, st));
+    RECCHK(hipEventRecord(c->rec_ev[0], st));
+    for (int k = 0; k < npieces; k++) {
+        const long long t0 = (long long)k * blk_per_piece * job.block, t1 = std::min(nt, t0 + blk_per_piece * job.block);
+        RECCHK(hipMemcpyAsync(hs + off_rec + (size_t)t0 * 16, slab + L.tris_off + (size_t)t0 * 16, (size_t)(t1 - t0) * 16, hipMemcpyDeviceToHost, st));
+        RECCHK(hipEventRecord(c->rec_ev[(size_t)k + 1], st));
+    }
+#undef RECCHK
+    const double t_enq = tr_us();
+    double t_piece[16] = {};
+    hipError_t err = event_wait(c->rec_ev[0]);
+    const double t_head = tr_us();
+    for (int k = 0; k < npieces && err == hipSuccess; k++) {
+        err = event_wait(c->rec_ev[(size_t)k + 1]);
+        if (err == hipSuccess) job.avail.store(std::min(nt, (long long)(k + 1) * blk_per_piece * job.block), std::memory_order_release);
+        if (k < 16) t_piece[k] = tr_us();
+    }
+    if (err != hipSuccess) job.abort.store(1);
+    else sdfhost::expand_work(job);
+    const double t_own = tr_us();
+    pool.wait(job);
+    if (rec_trace) {
+        fprintf(stderr, "[records] %lld triangles, %d threads, %d pieces: enqueued %.0f us, head %.0f, pieces", nt, nthreads, npieces, t_enq, t_head);
+        for (int k = 0; k < npieces && k < 16; k++) fprintf(stderr, " %.0f", t_piece[k]);
+        fprintf(stderr, "; own share done %.0f, all done %.0f us\n", t_own, tr_us());
+        double dur = 0, dmax = 0;
+        for (long long b = 0; b < nblk; b++) { const double d = blk_trace[2 * b + 1] - blk_trace[2 * b]; dur += d; dmax = std::max(dmax, d); }
+        fprintf(stderr, "[records] %lld blocks of %lld triangles: %.0f us each on average (max %.0f); block: started / written, every %lld-th:", nblk, job.block, dur / std::max<long long>(nblk, 1), dmax, std::max<long long>(nblk / 24, 1));
+        for (long long b = 0; b < nblk; b += std::max<long long>(nblk / 24, 1)) fprintf(stderr, " %lld: %.0f / %.0f", b, blk_trace[2 * b], blk_trace[2 * b + 1]);
+        fprintf(stderr, "\n");
+    }
+    if (err != hipSuccess) return fail(std::string("sdf_mesh_emit_host: copying the records: ") + hipGetErrorString(err));
+    return 0;
 }
+
+int sdf_mesh_emit_host(sdf_mesh *m, double *h_out) { return sdf_mesh_emit_host_workers(m, h_out, 0); }
 
 int sdf_mesh_emit_host_range(sdf_mesh *m, int64_t first_tri, int64_t n_tris, double *h_out) {
     if (!m || !h_out) return fail("sdf_mesh_emit_host_range: NULL argument");
     MESH_READY(m);
     if (first_tri < 0 || n_tris < 0 || first_tri + n_tris > m->st.n_triangles) return fail("sdf_mesh_emit_host_range: range outside the soup");
     if (n_tris == 0) return 0;
+    MESH_SOUP_READY(m);
     HIPCHK(set_device(m->ctx->device));
     HIPCHK(hipMemcpyAsync(h_out, (const char *)mesh_soup(m) + (size_t)first_tri * 72, (size_t)n_tris * 72, hipMemcpyDeviceToHost, m->ctx->stream));
     HIPCHK(stream_wait(m->ctx->stream));
@@ -2051,6 +2237,7 @@ int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
     MESH_READY(m);
     const long long nt = m->st.n_triangles;
     if (nt == 0) return 0;
+    MESH_SOUP_READY(m);
     sdf_ctx *c = m->ctx;
     HIPCHK(set_device(c->device));
     if (c->scratch_out.ensure((size_t)nt * 50)) return 1;
@@ -2063,6 +2250,7 @@ int sdf_mesh_emit_stl_host(sdf_mesh *m, void *h_out) {
 int sdf_mesh_weld(sdf_mesh *m, int64_t *n_unique) {
     if (!m || !n_unique) return fail("sdf_mesh_weld: NULL argument");
     MESH_READY(m);
+    MESH_SOUP_READY(m);
     sdf_ctx *c = m->ctx;
     HIPCHK(set_device(c->device));
     if (m->weld_n < 0) {
@@ -2192,7 +2380,7 @@ int sdf_mesh_destroy(sdf_mesh *m) {
         m->out.p = nullptr; m->out.bytes = 0;
     }
     if (m->counters.p) { c->counter_pool.push_back(m->counters); m->counters.p = nullptr; m->counters.bytes = 0; }
-    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->order, &m->desc, &m->cellrecs, &m->trilist, &m->blockidx}) b->release();
+    for (DevBuf *b : {&m->axes, &m->kinds, &m->worklist, &m->status, &m->prune, &m->tapes, &m->cull, &m->order, &m->desc, &m->cellrecs, &m->trilist, &m->blockidx, &m->slab}) b->release();
     (void)hipFree(m->weld_pts); (void)hipFree(m->weld_inv);
     delete m;
     return 0;

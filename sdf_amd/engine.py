@@ -101,6 +101,8 @@ ABI = {
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                     ctypes.c_int, _vp, ctypes.c_int64, ctypes.POINTER(_vp)]),
     'sdf_mesh_wait': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
+    'sdf_generate_records': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     'sdf_slab_bytes': (ctypes.c_size_t, [_c_i64, _c_i64]),
     'sdf_generate_compact_async': (ctypes.c_int, [_vp, _f64p, ctypes.c_int, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, _vp, _c_i64,
@@ -125,6 +127,7 @@ ABI = {
     'sdf_mesh_triangles': (_c_i64, [_vp]),
     'sdf_mesh_emit_device': (ctypes.c_int, [_vp, _vp]),
     'sdf_mesh_emit_host': (ctypes.c_int, [_vp, _f64p]),
+    'sdf_mesh_emit_host_workers': (ctypes.c_int, [_vp, _f64p, ctypes.c_int]),
     'sdf_mesh_emit_host_range': (ctypes.c_int, [_vp, _c_i64, _c_i64, _f64p]),
     'sdf_mesh_batch_offsets': (ctypes.c_int, [_vp, ctypes.POINTER(_c_i64)]),
     'sdf_mesh_emit_stl_host': (ctypes.c_int, [_vp, _vp]),
@@ -137,7 +140,7 @@ ABI = {
     'sdf_mesh_prune_masks': (ctypes.c_int, [_vp, _u32p]),
     'sdf_mesh_destroy': (ctypes.c_int, [_vp]),
 }
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def build_info():
@@ -337,12 +340,14 @@ class Mesh:
         _check(self.engine.lib, self.engine.lib.sdf_mesh_prune_masks(self.handle, _dp(out, _u32p)))
         return out[:n]
 
-    def points(self):
-        """(3T, 3) float64 world-space soup in reference order, copied to the host"""
+    def points(self, workers=0):
+        """(3T, 3) float64 world-space soup in reference order, on the host.  A mesh of `generate(records=True)`
+        sends its 16-byte records and `workers` host threads (0: the machine's, at most 64) make the soup
+        from them (`sdf_mesh_emit_host_workers`); any other mesh copies its float64 soup"""
         t = self.n_triangles
         out = pinned_empty(self.engine.lib, (3 * t, 3), np.float64)
         if t:
-            _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_host(self.handle, _dp(out, _f64p)))
+            _check(self.engine.lib, self.engine.lib.sdf_mesh_emit_host_workers(self.handle, _dp(out, _f64p), int(workers or 0)))
         return out
 
     def points_range(self, first_tri, n_tris):
@@ -642,8 +647,10 @@ class Engine:
                 return out[:nt.value].reshape(-1, 3)
             cap = nt.value
 
-    def generate(self, sdf, X, Y, Z, batch_size=32, sparse=True, shard=(0, 1), out_ptr=None, out_cap=0, wait=True):
-        """mesh the grid X x Y x Z.  With out_ptr / out_cap (device memory for 9 * out_cap float64)
+    def generate(self, sdf, X, Y, Z, batch_size=32, sparse=True, shard=(0, 1), out_ptr=None, out_cap=0, wait=True, records=False):
+        """mesh the grid X x Y x Z.  records=True (one device, the whole work list, no output buffer): for a
+        caller who wants the soup on the HOST -- the triangles are kept as 16-byte records and `mesh.points(workers)`
+        expands them on host threads (`sdf_generate_records`).  With out_ptr / out_cap (device memory for 9 * out_cap float64)
         the ordered soup is gathered into it inside the same submission (`mesh.emitted` tells
         whether it fitted); otherwise it stays in the mesh until `points()` / `emit_device()`.
         wait=False (needs out_ptr): the call is only enqueued; `mesh.wait()` -- or any read of the
@@ -668,7 +675,11 @@ class Engine:
             m._tape = dt
             m.emitted = None          # unknown until wait()
             return m
-        if out_ptr:
+        if records and not out_ptr and tuple(shard) == (0, 1):
+            _check(self.lib, self.lib.sdf_generate_records(dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y),
+                                                           _dp(Z, _f64p), len(Z), int(batch_size), 1 if sparse else 0,
+                                                           self.precision, ctypes.byref(h)))
+        elif out_ptr:
             _check(self.lib, self.lib.sdf_generate_to_device(
                 dt.handle, _dp(X, _f64p), len(X), _dp(Y, _f64p), len(Y), _dp(Z, _f64p), len(Z), int(batch_size),
                 1 if sparse else 0, int(shard[0]), int(shard[1]), self.precision, _vp(out_ptr), int(out_cap),

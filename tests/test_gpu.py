@@ -1865,3 +1865,81 @@ def test_two_workgroups_per_cu_same_soup(name, samples, ns, eng):
             assert kernels[1] == 2
     finally:
         eng.set_mesh2(0)
+
+
+# ---- `generate` for a host caller: 16-byte records over PCIe, the float64 soup made on host threads (sdf_generate_records) ----
+REC_CASES = [('ex_example', 'gen_example_s17'), ('ex_example', 'gen_example_s22'), ('ex_blobby', 'gen_blobby_s20'), ('ex_gearlike', 'gen_gearlike_s20'),
+             ('ex_weave', 'gen_weave_s19'), ('ex_pawn', 'gen_pawn_s16'), ('ex_knurling', 'gen_knurling_s16')]
+
+
+@pytest.mark.parametrize('name,gold', REC_CASES, ids=[g for _, g in REC_CASES])
+def test_records_mode_gives_the_same_soup_and_serves_every_reader(name, gold, ns, eng):
+    """the second call of a model on a grid takes the records path (the first leaves the capacity hint): the soup the host threads
+    make is the device's float64 soup bit for bit, for 1, 3 and all workers; STL records, the weld, ranges, batch offsets and
+    sdf_mesh_emit_device of such a mesh are those of an ordinary one"""
+    import torch
+    d = np.load(os.path.join(GOLDEN, gold + '.npz'))
+    f = fixtures.build(name, ns)
+    X, Y, Z, _ = core.grid_axes(tuple(map(tuple, d['bounds'])), d['step'].tolist())
+    m0 = eng.generate(f, X, Y, Z, 32, True)
+    want, st0 = m0.points(), m0.stats()
+    stl0, (wp0, wc0), off0 = m0.stl_records().copy(), m0.weld(), m0.batch_offsets()
+    m0.close()
+    if name not in TRIG:
+        assert hashlib.sha256(want.tobytes()).digest() == d['sha256'].tobytes()
+    for workers in (1, 3, 0):
+        m = eng.generate(f, X, Y, Z, 32, True, records=True)
+        got = m.points(workers)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        st = m.stats()
+        assert all(st[k] == st0[k] for k in ('triangles', 'skipped', 'empty', 'nonempty', 'n_eval_voxels', 'n_ambiguous_cells')) and st['n_retries'] == 0
+        if workers == 3:       # the readers that want the float64 soup on the device (k_expand on demand), before and after points()
+            assert np.array_equal(m.batch_offsets(), off0)
+            t = m.n_triangles
+            assert np.array_equal(m.points_range(t // 3, t // 2 - t // 3), want[3 * (t // 3):3 * (t // 2)])
+            assert m.stl_records().tobytes() == stl0.tobytes()
+            wp, wc = m.weld()
+            assert np.array_equal(wp, wp0) and np.array_equal(wc, wc0)
+            buf = torch.zeros(9 * t, dtype=torch.float64, device='cuda:0')
+            m.emit_device(buf.data_ptr())
+            assert np.array_equal(buf.cpu().numpy().reshape(-1, 3), want)
+            assert np.array_equal(m.points(2), want)               # (now a plain copy of the expanded soup)
+        m.close()
+    m = eng.generate(f, X, Y, Z, 32, True, records=True)           # a reader first, points() never
+    assert m.stl_records().tobytes() == stl0.tobytes()
+    m.close()
+
+
+def test_records_mode_slab_that_is_too_small_is_sized_again(ns, eng):
+    """the capacity hint is keyed by model and grid SHAPE: the same shape over other bounds needs more triangles than the hint
+    says -- the slab overflows on the device, is sized from the count and the call repeated"""
+    f = fixtures.build('ex_example', ns)
+    n = 97
+    far = np.linspace(0.55, 1.6, n)            # a corner of the model: few triangles
+    A = np.linspace(-1.1, 1.1, n)
+    m = eng.generate(f, far, far, far, 32, True); few = m.n_triangles; m.close()
+    m = eng.generate(f, A, A, A, 32, True); want = m.points(); m.close()
+    assert 0 < few < len(want) // 3 // 4
+    m = eng.generate(f, far, far, far, 32, True); m.close()          # (the hint of this shape says `few` again)
+    m = eng.generate(f, A, A, A, 32, True, records=True)
+    assert m.stats()['n_retries'] >= 1 and np.array_equal(m.points(), want)
+    m.close()
+    m = eng.generate(f, A, A, A, 32, True, records=True)             # ... and the next call fits at once
+    assert m.stats()['n_retries'] == 0 and np.array_equal(m.points(5), want)
+    m.close()
+
+
+def test_generate_drop_in_returns_the_reference_soup_through_records(ns):
+    """f.generate() on fresh model objects: the second call finds the first one's hint (keyed by the tape's CONTENT) and goes through
+    the records; both return the reference's points"""
+    d = np.load(os.path.join(GOLDEN, 'gen_example_s22.npz'))
+    for workers in (1, 4, 8):
+        f = fixtures.build('ex_example', ns)
+        pts = f.generate(samples=2 ** 22, workers=workers, verbose=False)
+        assert hashlib.sha256(pts.tobytes()).digest() == d['sha256'].tobytes()
+    # a model with centre vertices (Lewiner's tilings with a vertex inside the cell: the slab's raw area)
+    d = np.load(os.path.join(GOLDEN, 'gen_blobby_s20.npz'))
+    for _ in range(2):
+        f = fixtures.build('ex_blobby', ns)
+        pts = f.generate(samples=2 ** 20, verbose=False)
+        assert hashlib.sha256(pts.tobytes()).digest() == d['sha256'].tobytes()

@@ -1,5 +1,5 @@
 #!/bin/sh
-# development build: recompile ONLY the named translation units of csrc/ (hip bounds f64 f64full plain weld) and relink;
+# development build: recompile ONLY the named translation units of csrc/ (hip bounds f64 f64full m2 m2full plain weld) and relink;
 # build.sh (what build() runs) always rebuilds everything.   tools/devbuild.sh hip plain
 set -e
 cd "$(dirname "$0")/../sdf_amd/csrc"
@@ -13,11 +13,13 @@ for u in "$@"; do
     bounds) $HIPCC $FLAGS -c -o build/sdf_bounds.o sdf_bounds.hip & pids="$pids $!" ;;
     f64) $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh_f64 -c -o build/mesh_f64.o sdf_mesh_inst.hip & pids="$pids $!" ;;
     f64full) $HIPCC $FLAGS -DMESH_T=double -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh_f64_full -c -o build/mesh_f64_full.o sdf_mesh_inst.hip & pids="$pids $!" ;;
+    m2) $HIPCC $FLAGS -DMESH_FULL=0 -DMESH_NAME=sdf_launch_mesh2_f64 -c -o build/mesh2_f64.o sdf_mesh2_inst.hip & pids="$pids $!" ;;
+    m2full) $HIPCC $FLAGS -DMESH_FULL=1 -DMESH_NAME=sdf_launch_mesh2_f64_full -c -o build/mesh2_f64_full.o sdf_mesh2_inst.hip & pids="$pids $!" ;;
     plain) $HIPCC $PLAIN -c -o build/sdf_plain.o sdf_plain.hip & pids="$pids $!" ;;
     weld) $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c -o build/sdf_weld.o sdf_weld.hip & pids="$pids $!" ;;
     *) echo "unknown unit $u"; exit 2 ;;
   esac
 done
 for p in $pids; do wait $p; done
-exec $HIPCC --offload-arch=gfx950 -fPIC -shared -o libsdf_hip.so build/sdf_hip.o build/mesh_f64.o build/mesh_f64_full.o \
+exec $HIPCC --offload-arch=gfx950 -fPIC -shared -o libsdf_hip.so build/sdf_hip.o build/mesh_f64.o build/mesh_f64_full.o build/mesh2_f64.o build/mesh2_f64_full.o \
     build/sdf_bounds.o build/sdf_weld.o build/sdf_plain.o
