@@ -620,7 +620,7 @@ def main():
             del pts
             # (its two device-side parts on their own: meshing into 16-byte records, and records -> float64 rows on the host threads)
             t1 = time.perf_counter(); mesh = eng.generate(tape, X, Y, Z, 32, True, records=True); tg.append(1e3 * (time.perf_counter() - t1))
-            t1 = time.perf_counter(); pts = mesh.points(core.WORKERS); tp.append(1e3 * (time.perf_counter() - t1))
+            t1 = time.perf_counter(); pts = mesh.points(min(core.WORKERS, 32)); tp.append(1e3 * (time.perf_counter() - t1))
             mesh.close()
             del pts
             f3, _ = build_model(args.model)
@@ -630,7 +630,7 @@ def main():
         e2e = {'wall_ms': stats3(tt[2:]), 'triangles': n_e2e, 'voxels_per_sec_median': round(grid_voxels / (1e-3 * float(np.median(tt[2:]))), 1),
                'of_which_ms': {'estimate_bounds': stats3(tb[2:]), 'lower_and_upload_tape': stats3(tl[2:]),
                                'meshing_into_records': stats3(tg[2:]), 'records_to_float64_rows_on_host_threads': stats3(tp[2:])},
-               'host_threads': min(core.WORKERS, 64),
+               'host_threads': min(core.WORKERS, 32),
                'what': 'f.generate(samples=2**%d, verbose=False) on a fresh model object, 10 calls after 2 warm-up calls: bounds + tape + grid + '
                        'meshing into 16-byte triangle records (sdf_generate_records) + D2H of the records (47 MB instead of the 212 MB of the '
                        'float64 soup) while `workers` host threads write the (n, 3) float64 ndarray from them (pinned blocks); '

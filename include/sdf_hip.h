@@ -295,7 +295,7 @@ int64_t sdf_mesh_triangles(sdf_mesh *mesh);
 int sdf_mesh_emit_device(sdf_mesh *mesh, void *d_out);
 int sdf_mesh_emit_host(sdf_mesh *mesh, double *h_out);
 /* the same with the reference's `workers=` (sdf/core.py:87, 131): the number of host threads that expand the records of a
- * mesh of sdf_generate_records into the float64 soup (<= 0: the machine's, at most 64); ignored by any other mesh, whose
+ * mesh of sdf_generate_records into the float64 soup (<= 0: the machine's, at most 32; a caller's number: at most 64); ignored by any other mesh, whose
  * soup is copied as it is.  sdf_mesh_emit_host = workers 0. */
 int sdf_mesh_emit_host_workers(sdf_mesh *mesh, double *h_out, int workers);
 /* triangles [first_tri, first_tri + n_tris) of the soup only (9 doubles each) */

@@ -13,7 +13,7 @@ Differences a caller can observe:
   behaviour).
 * ``workers`` does not drive the sampling (the device runs every batch concurrently); it is the
   number of host threads that turn the device's 16-byte triangle records into the float64 rows
-  of the returned array (``sdf_mesh_emit_host_workers``; at most 64).
+  of the returned array (``sdf_mesh_emit_host_workers``; at most 32 -- more were measured to be no faster).
 * when ``torch.distributed`` is initialised with world_size > 1 the surviving batches are
   sharded over the ranks and the triangle buffers all-gathered (sdf_amd/dist.py), so
   every rank still returns the complete soup in reference order.
@@ -212,7 +212,7 @@ def generate(
                 welded = mesh.weld()
                 points = np.empty((3 * mesh.n_triangles, 0))
             else:
-                points = mesh.points(workers)
+                points = mesh.points(min(int(workers), 32) if workers else 0)
         finally:
             mesh.close()
 

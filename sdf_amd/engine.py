@@ -342,7 +342,7 @@ class Mesh:
 
     def points(self, workers=0):
         """(3T, 3) float64 world-space soup in reference order, on the host.  A mesh of `generate(records=True)`
-        sends its 16-byte records and `workers` host threads (0: the machine's, at most 64) make the soup
+        sends its 16-byte records and `workers` host threads (0: the machine's, at most 32; at most 64) make the soup
         from them (`sdf_mesh_emit_host_workers`); any other mesh copies its float64 soup"""
         t = self.n_triangles
         out = pinned_empty(self.engine.lib, (3 * t, 3), np.float64)
