@@ -59,6 +59,10 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 # millisecond job measured right behind that, blobby, came out at 1.28 - 1.52 ms per step with four calls in flight in two of five runs
 # (r05y, r05af) against 0.88 everywhere else)
 OTHER_CONFIGS = [('gearlike', 30, 10204096, 24), ('blobby', 30, 4048520, 24), ('weave', 33, 53943912, 6)]
+# (diagnostics: SDF_BENCH_SKIP=incl,e2e,sustained leaves optional single-GPU sections out; SDF_BENCH_OTHER_ORDER=blobby,gearlike reorders / selects the other configs)
+SKIP = set(filter(None, os.environ.get('SDF_BENCH_SKIP', '').split(',')))
+if os.environ.get('SDF_BENCH_OTHER_ORDER'):
+    OTHER_CONFIGS = [c for n in os.environ['SDF_BENCH_OTHER_ORDER'].split(',') for c in OTHER_CONFIGS if c[0] == n]
 
 
 # DESIGN.md section 6, arithmetic for 8 GPUs (one GPU's measured stage times / 8 + fixed costs + 16 B per triangle (sdf_slab.h records) over one xGMI
@@ -593,7 +597,7 @@ def main():
 
     # PCIe-inclusive variant (single GPU): same step + D2H of the soup into the ndarray `generate` returns (a recycled pinned block)
     incl = None
-    if world == 1:
+    if world == 1 and 'incl' not in SKIP:
         n_incl = max(1, min(args.steps, 5))
         for i in range(2 + n_incl):          # (two untimed passes: the result blocks are pinned once, then recycled)
             if i == 2:
@@ -608,7 +612,7 @@ def main():
     # reference's signature returns -- next to its parts; comparable like for like with the reference's generate() of
     # cpu_baseline (which includes `_estimate_bounds` too).  Never `value`. ----
     e2e = None
-    if world == 1 and args.model == 'example' and args.precision == 'f64':
+    if world == 1 and args.model == 'example' and args.precision == 'f64' and 'e2e' not in SKIP:
         trace('generate end to end')
         tt, tb, tl, tg, tp = [], [], [], [], []
         for i in range(12):
@@ -639,7 +643,7 @@ def main():
     # ---- a SUSTAINED run of the headline job: >= 2000 steps (>= 0.4 s of kernels back to back), same steps in flight, with the
     # shader clock the kernels measured themselves -- the 20-step headline is a 5 ms burst that the clocks could flatter ----
     sustained = None
-    if world == 1 and args.model == 'example' and not args.sync:
+    if world == 1 and args.model == 'example' and not args.sync and 'sustained' not in SKIP:
         trace('sustained run')
         rs = measure(args.model, args.samples_log2, 2000, 0, DEPTH)
         sustained = {'steps': 2000, 'seconds': round(rs['dt'], 4), 'ms_per_step': round(1e3 * rs['dt'] / 2000, 4),
@@ -660,7 +664,12 @@ def main():
                 # (at most four in flight here: a 2^33 job keeps 6 GB per call on the device, and the long two-pass jobs gain
                 # nothing from deeper queues)
                 depth_o = min(DEPTH, 4) if world == 1 else 2
-                r = measure(model, log2, K_OTHER, 2, depth_o)
+                # (eight untimed steps in front of the timed ones -- every call slot's lane once: with two, the first configuration of this
+                # section had ONE submission of ~ 7 ms inside its 24 timed steps on some runs, r06v / r06w: + 0.2 - 0.3 ms per step,
+                # "four in flight slower than one"; nothing in the kernels -- tools/sessions/gpu_r06p.sh)
+                W_OTHER = 8 if K_OTHER > 8 else 2
+                r = measure(model, log2, K_OTHER, W_OTHER, depth_o)
+                r0_spans, r0_dev = list(r['spans']), list(r['dev_ms'])
                 used, by_depth = depth_o, None
                 iso_mesh = iso_pre = None        # the kernels' own durations: from the run with ONE call in flight (launches that share the CUs stretch)
                 if world == 1 and depth_o > 1:
@@ -670,10 +679,13 @@ def main():
                     if one['dt'] < r['dt']:
                         r, used = one, 1
                     del one
+                # (how the timed steps of the run with calls in flight lay on the device's clock: start-to-start gaps and each k_mesh span)
+                po = pipelined_overlap(r0_spans, r0_dev) if world == 1 else None
                 s2, t2 = r['state']['stats'], int(r['state']['tris'])
                 o = {'workload': '%s @ samples=2**%d -> %dx%dx%d grid' % (model, log2, len(r['X']), len(r['Y']), len(r['Z'])),
                      'n_gpus': world, 'steps': K_OTHER,
                      'steps_in_flight': used, 'ms_per_step_by_depth': by_depth,
+                     'in_flight_run_on_the_device_clock': ({k: v for k, v in po.items() if k != 'steps'} if po else None),
                      'ms_per_step': round(1e3 * r['dt'] / K_OTHER, 4),
                      'value': round(r['grid_voxels'] * K_OTHER / r['dt'], 1), 'unit': 'voxels/s', 'triangles': t2,
                      'triangles_per_sec': round(t2 * K_OTHER / r['dt'], 1), 'batches': int(s2['batches']), 'skipped': int(s2['skipped']),
