@@ -152,7 +152,9 @@ def generate(
         step=None, bounds=None, samples=SAMPLES,
         workers=WORKERS, batch_size=BATCH_SIZE,
         verbose=True, sparse=True, _stl=False, _weld=False):
-    """reference sdf/core.py:84-150.  (`_stl=True` is what `save` uses for .stl files: the soup
+    """reference sdf/core.py:84-150.  `batch_size` up to 512 (the reference takes any: a larger one is refused with a message; up
+    to 32 runs the fused kernels, above that the batches go through device memory -- a model with user closures then hands its
+    callback one whole tile at a time, (batch_size + 1)^3 points: 4.3 GB of pinned host memory at 512).  (`_stl=True` is what `save` uses for .stl files: the soup
     stays on the device and the 50-byte STL records come back instead of the points; `_weld=True` is
     what `save` uses for every other format: the soup is welded on the device and the indexed mesh
     (unique points, cells) comes back.)"""

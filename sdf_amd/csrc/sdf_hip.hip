@@ -1832,7 +1832,7 @@ int sdf_generate_field(sdf_ctx *c, sdf_field_fn field, void *user, const double 
     };
     const size_t tile_max = (size_t)(bs + 1) * (bs + 1) * (bs + 1);
     const int slots = bs <= 32 ? 1024 : ((bs * bs + 255) & ~255);                      // row slots per tile (k_field_rows)
-    const int CH = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)64 << 20) / tile_max));   // batches per submission (<= 2 GB of pinned points)
+    const int CH = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)64 << 20) / tile_max));   // batches per submission: <= 64 M points = 2 GB of pinned points + values -- except that ONE tile is always taken whole: (512 + 1)^3 points = 4.3 GB at the largest batch size
     const size_t pts_cap = std::max<size_t>((size_t)CH * tile_max, (size_t)9 << 12);   // points per callback
     if (sdf_host_alloc(pts_cap * 24, &h_pts) || sdf_host_alloc(pts_cap * 8, &h_vals)) return 1;
     double *pts = (double *)h_pts, *vals = (double *)h_vals;
