@@ -877,6 +877,10 @@ def main():
                    'parallelism': 'work-list shards x%d + one RCCL all-gather of the slabs per step' % world if world > 1 else 'single GPU'},
         'triangles_per_sec': round(tris * args.steps / dt, 1),
         'eval_voxels_per_sec': round(int(st['n_eval_voxels']) * args.steps / dt, 1),
+        # (`value` counts every voxel of the grid -- the reference's unit of work; of those the skip test and the interval passes decide
+        # all but these, which are the ones that go through the tape interpreter)
+        'interpreted_voxels_per_sec': round(int(st.get('n_sampled_voxels', 0)) * args.steps / dt, 1),
+        'interpreted_share_of_grid': round(int(st.get('n_sampled_voxels', 0)) / max(grid_voxels, 1), 5),
         'value_incl_d2h': round(incl, 1) if incl else None,
         'generate_e2e': e2e,
         'sustained': sustained,
@@ -907,6 +911,8 @@ def main():
         'cpu_baseline': cpu_ref if (cpu_ref is not None and cpu_ref.get('kind') == 'reference') else (cpu if cpu is not None else cpu_ref),
         'cpu_reference_recorded': cpu_ref if (cpu_ref is not None and cpu_ref.get('kind') != 'reference') else None,
         'cpu_port': cpu,
+        'cpu_baseline_note': "kind 'port' on a GPU box is by the task's rules, not an omission: the reference is Python and may not travel in any form "
+                             "(source, bytecode or otherwise), so oracle/_ref cannot hold it; where /root/reference exists (the build container) this object is the live reference",
         'other_configs': None,
     }
     if want_others:

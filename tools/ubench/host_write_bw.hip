@@ -10,14 +10,37 @@
 #include <thread>
 #include <vector>
 #include <sys/mman.h>
+#include <sched.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+#include <fstream>
+#include <string>
 
+static std::vector<int> node_cpus(int node) {   // /sys/devices/system/node/nodeN/cpulist: "0-63,128-191"
+    std::vector<int> v;
+    std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+    std::string s; std::getline(f, s);
+    size_t i = 0;
+    while (i < s.size()) {
+        size_t j = s.find(',', i); if (j == std::string::npos) j = s.size();
+        std::string part = s.substr(i, j - i);
+        size_t d = part.find('-');
+        int a = std::stoi(part.substr(0, d)), b = d == std::string::npos ? a : std::stoi(part.substr(d + 1));
+        for (int c = a; c <= b; c++) v.push_back(c);
+        i = j + 1;
+    }
+    return v;
+}
+static int g_pin_node = -1;
 static double run(char *p, size_t n, int threads, bool nt, int reps) {
+    std::vector<int> cpus = g_pin_node >= 0 ? node_cpus(g_pin_node) : std::vector<int>();
     double best = 1e30;
     for (int r = 0; r < reps; r++) {
         auto t0 = std::chrono::steady_clock::now();
         std::vector<std::thread> th;
         for (int i = 0; i < threads; i++)
             th.emplace_back([=] {
+                if (!cpus.empty()) { cpu_set_t cs; CPU_ZERO(&cs); CPU_SET(cpus[i % cpus.size()], &cs); sched_setaffinity(0, sizeof cs, &cs); }
                 // interleaved blocks of 576 KB like the expansion's (8192 triangles x 72 B)
                 const size_t blk = 8192 * 72, nblk = (n + blk - 1) / blk;
                 for (size_t b = i; b < nblk; b += threads) {
@@ -51,6 +74,15 @@ int main() {
                run(pinned, n, threads, false, 4), run(pinned, n, threads, true, 4), run(plain, n, threads, false, 4), run(plain, n, threads, true, 4),
                run(huge, n, threads, false, 4), run(huge, n, threads, true, 4), numa_pinned ? run(numa_pinned, n, threads, false, 4) : -1.0, numa_pinned ? run(numa_pinned, n, threads, true, 4) : -1.0);
     }
+    // which node does the pinned block lie on, and what do threads bound to either node achieve on it?
+    { int node = -1; long rc = syscall(SYS_get_mempolicy, &node, nullptr, 0, pinned, 3 /* MPOL_F_NODE | MPOL_F_ADDR */); printf("get_mempolicy(pinned): rc %ld node %d\n", rc, node); }
+    for (int node : {0, 1}) {
+        g_pin_node = node;
+        for (int threads : {8, 16, 32})
+            printf("threads bound to node %d, %2d threads: pinned %.2f / nt %.2f ms | ordinary %.2f / nt %.2f\n", node, threads, run(pinned, n, threads, false, 4), run(pinned, n, threads, true, 4),
+                   run(plain, n, threads, false, 4), run(plain, n, threads, true, 4));
+    }
+    g_pin_node = -1;
     // the D2H side: 47 MB of records into pinned memory while nothing else runs
     char *d = nullptr; (void)hipMalloc((void **)&d, 48 << 20);
     for (int r = 0; r < 3; r++) {
