@@ -2139,6 +2139,8 @@ int sdf_mesh_emit_host_workers(sdf_mesh *m, double *h_out, int workers) {
     job.n_items = ni; job.n_tris = nt; job.out = h_out;
     std::vector<float> blk_trace;
     if (rec_trace) { blk_trace.assign((size_t)2 * nblk, 0.0f); job.trace = blk_trace.data(); job.t_origin = tr0; }
+    static std::mutex expand_mu;                         // (ONE expansion at a time per process: the pool serves one job)
+    std::lock_guard<std::mutex> expand_lock(expand_mu);
     sdfhost::Pool &pool = sdfhost::Pool::get();
     // (from here on the helpers hold the job: an error lets them go before it returns)
 #define RECCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { job.abort.store(1); pool.wait(job); return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)

@@ -1,9 +1,8 @@
 #!/bin/bash
-# r06ac: the three profile passes of r06ab again without the drop-in sections of the bench line (their k_mesh launches write 16-byte records and
-# had pulled the averaged WRITE_SIZE of the dominant kernel below the soup's bytes), + the compiler's resource table of this build
+# r06ae: kernel statistics + counters (pipelined, one call at a time, weave 2^33) and the default bench line of the source handed in (the drop-in sections are left out of the profile passes: their k_mesh launches write 16-byte records)
 set -u
 cd "$(dirname "$0")/../.."
-TAG=${1:-r06ac}
+TAG=${1:-r06ae}
 O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
