@@ -16,17 +16,20 @@ from .ir import Node, unwrap
 PIXELS = 2 ** 22
 
 
-def _load_image(thing):
-    """reference sdf/text.py:11-16"""
+def _as_pil(source):
+    """a PIL image from a file name, an array or anything `np.array` accepts (reference sdf/text.py:11-16)"""
     from PIL import Image
-    if isinstance(thing, str):
-        return Image.open(thing)
-    elif isinstance(thing, (np.ndarray, np.generic)):
-        return Image.fromarray(thing)
-    return Image.fromarray(np.array(thing))
+    if isinstance(source, str):
+        return Image.open(source)
+    pixels = source if isinstance(source, (np.ndarray, np.generic)) else np.array(source)
+    return Image.fromarray(pixels)
+
+
+_load_image = _as_pil          # (the reference's name for it)
 
 
 def _fit(aspect, width, height):
+    """the reference's sizing rule: a missing side follows from the other and the aspect ratio; neither given: height 1"""
     if width is None and height is None:
         height = 1
     if width is None:
@@ -36,43 +39,45 @@ def _fit(aspect, width, height):
     return (width, height)
 
 
+def _glyph_box(font_file, string, size):
+    """(font, left, top, columns, rows) of `string` set in `font_file` at `size` points"""
+    from PIL import ImageFont
+    font = ImageFont.truetype(font_file, size)
+    left, top, right, bottom = font.getbbox(string)
+    return font, left, top, right - left, bottom - top
+
+
 def measure_text(name, text, width=None, height=None):
     """reference sdf/text.py:18-28"""
-    from PIL import ImageFont
-    font = ImageFont.truetype(name, 96)
-    x0, y0, x1, y1 = font.getbbox(text)
-    return _fit((x1 - x0) / (y1 - y0), width, height)
+    _, _, _, cols, rows = _glyph_box(name, text, 96)
+    return _fit(cols / rows, width, height)
 
 
 def measure_image(thing, width=None, height=None):
     """reference sdf/text.py:30-40"""
-    im = _load_image(thing)
-    w, h = im.size
-    return _fit(w / h, width, height)
+    cols, rows = _as_pil(thing).size
+    return _fit(cols / rows, width, height)
+
+
+MARGIN = 0.2        # of the glyph box, on every side (reference sdf/text.py:48)
 
 
 @d2.sdf2
 def text(font_name, text, width=None, height=None, pixels=PIXELS, points=512):
-    """reference sdf/text.py:42-63"""
-    from PIL import Image, ImageFont, ImageDraw
-    font = ImageFont.truetype(font_name, points)
-    p = 0.2
-    x0, y0, x1, y1 = font.getbbox(text)
-    px = int((x1 - x0) * p)
-    py = int((y1 - y0) * p)
-    tw = x1 - x0 + 1 + px * 2
-    th = y1 - y0 + 1 + py * 2
-    im = Image.new('L', (tw, th))
-    draw = ImageDraw.Draw(im)
-    draw.text((px - x0, py - y0), text, font=font, fill=255)
-    return _sdf(width, height, pixels, px, py, im)
+    """reference sdf/text.py:42-63: the string rendered white on black into an 8-bit canvas one pixel larger than its glyph box
+    plus the margin on every side, then the distance texture of that canvas"""
+    from PIL import Image, ImageDraw
+    font, left, top, cols, rows = _glyph_box(font_name, text, points)
+    pad = (int(cols * MARGIN), int(rows * MARGIN))
+    canvas = Image.new('L', (cols + 1 + 2 * pad[0], rows + 1 + 2 * pad[1]))
+    ImageDraw.Draw(canvas).text((pad[0] - left, pad[1] - top), text, font=font, fill=255)
+    return _sdf(width, height, pixels, pad[0], pad[1], canvas)
 
 
 @d2.sdf2
 def image(thing, width=None, height=None, pixels=PIXELS):
-    """reference sdf/text.py:65-68"""
-    im = _load_image(thing).convert('L')
-    return _sdf(width, height, pixels, 0, 0, im)
+    """reference sdf/text.py:65-68: any picture, as 8-bit grey, without padding"""
+    return _sdf(width, height, pixels, 0, 0, _as_pil(thing).convert('L'))
 
 
 def distance_texture(mask):
