@@ -2,6 +2,7 @@
 # r06p: VERDICT r05 item 3 "explain C3": gearlike 2^30 per step on the driver's boxes went 1.349 (r03) -> 1.404 (r04) -> 1.510 (r05) and four calls in
 # flight were slower than one.  The trees of round 3 and round 5 as handed in (git archive into ablibs/tree_r03, tree_r05, built with their own
 # build.sh) against HEAD on ONE box, alternating: bench.py --model gearlike --samples-log2 30 with 4 in flight and with --sync, and blobby 2^30 the same.
+# (the trees: for c in r03:382e653 r05:88f9b02; do mkdir -p ablibs/tree_${c%%:*}; git archive ${c##*:} | tar -x -C ablibs/tree_${c%%:*}; (cd ablibs/tree_${c%%:*}/sdf_amd/csrc && sh build.sh); done -- ablibs/ is git-ignored and travels with gpurun)
 set -u
 cd "$(dirname "$0")/../.."
 ROOT=$PWD
