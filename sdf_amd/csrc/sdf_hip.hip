@@ -2085,7 +2085,7 @@ static int copy_to_host(sdf_ctx *c, void *h_dst, const void *d_src, size_t bytes
 }
 
 // The soup on the host.  A mesh of sdf_generate_records sends its RECORDS (16 bytes per triangle + a transform per work item) and the
-// float64 soup is made where it is wanted, by `workers` host threads (<= 0: as many as the machine has, at most 64; the reference's
+// float64 soup is made where it is wanted, by `workers` host threads (<= 0: as many as the machine has, at most 32 -- a caller's number: at most 64; the reference's
 // `workers=` argument, sdf/core.py:87) -- block by block while the later records are still on the link: the pieces of the copy are
 // followed by events, the calling thread publishes how far the records have arrived and takes blocks itself in between.  The
 // arithmetic is k_expand's (`double(local) * scale + offset` on the same operands): the soup is the one the device would write.
