@@ -22,27 +22,34 @@ static int launch_one(int grid, size_t lds, hipStream_t stream, const uint32_t *
 
 // Register-file variants (NP point slots, ND distance slots).  Fewer slots = fewer live VGPRs around the interpreter: the host
 // picks the SMALLEST variant that holds the tape's slots (exact fits for the models at hand: example / gearlike (1,1), blobby /
-// knurling (2,2), weave (4,2), pawn (2,4)).  ONE launch shape per register file -- 1024 threads x 2 samples per lane, the
-// measured optimum wherever it exists (profiles/r02b_shapes.txt: weave 2^33 47.5 ms vs 59.5 ms at 1024 x 1 and 64.7 ms at
-// 512 x 2, although the 4-slot variants spill at 128 VGPRs); the 8-slot file does not fit two samples per lane at 1024 threads
-// and runs 1024 x 1.  (The other shapes were instantiated for tuning until round 5: 12 kernels nothing selected.)
+// knurling (2,2), weave (4,2), pawn (2,4)).  ONE launch shape per register file and scheme, 1024 threads x NS samples per lane:
+//   * one pass, files (1,1), (2,2), (2,4): THREE samples per lane since r06ah -- a third less of the interpreter's scalar stream (fetch,
+//     decode, dispatch: as many scalar as vector instructions per tape instruction at two samples) and 48 instead of 32 tasks per
+//     sampling pass; 54 - 112 spilled vector registers instead of 5 - 26 do not matter (as r06ad had shown for weave).  One box,
+//     alternating, three repeats (profiles/r06ai_three_samples.json): example 2^27 k_mesh 0.186 -> 0.180 ms, 0.2201 -> 0.2149 ms per
+//     sustained step; gearlike 2^30 1.126 -> 1.083; knurling 2^27 1.368 -> 1.322; blobby 2^30 0.572 -> 0.560; pawn 2^27 0.261 -> 0.255.
+//     FOUR samples per lane (204 spills): - 1.6 % only;
+//   * the long tapes' two-pass scheme and the (4,2), (4,4) files: two samples per lane (weave 2^33 with three: + 6.5 %, r06aj; with four
+//     at 512 threads the same as two, r06ad; with one 43 % slower, r06f; profiles/r02b_shapes.txt: 47.5 ms at 1024 x 2 against 59.5 at
+//     1024 x 1 and 64.7 at 512 x 2);
+//   * the 8-slot file does not fit two samples per lane at 1024 threads and runs 1024 x 1.
 SDF_DECLARE_MESH_LAUNCH(MESH_NAME, MESH_T) {
-    if (twopass) {   // sample + classify only (k_scan_items and k_emit2 follow): the default shape of each register file
+    (void)shape;
+    if (twopass) {   // sample + classify only (k_scan_items and k_emit2 follow)
         switch (slots) {
         case 0: return launch_one<1, 1, 2, 1024, true>(grid, lds, stream, code, consts, a);
         case 1: return launch_one<2, 2, 2, 1024, true>(grid, lds, stream, code, consts, a);
-        case 2: return launch_one<4, 2, 2, 1024, true>(grid, lds, stream, code, consts, a);   // (one sample per lane: 8 spilled registers instead of 184 and 43 % slower, profiles/r06f_weave_ns1.json)
+        case 2: return launch_one<4, 2, 2, 1024, true>(grid, lds, stream, code, consts, a);
         case 3: return launch_one<2, 4, 2, 1024, true>(grid, lds, stream, code, consts, a);
         case 4: return launch_one<4, 4, 2, 1024, true>(grid, lds, stream, code, consts, a);
         default: return launch_one<8, 8, 1, 1024, true>(grid, lds, stream, code, consts, a);
         }
     }
-    (void)shape;
     switch (slots) {
-    case 0: return launch_one<1, 1, 2, 1024>(grid, lds, stream, code, consts, a);
-    case 1: return launch_one<2, 2, 2, 1024>(grid, lds, stream, code, consts, a);
+    case 0: return launch_one<1, 1, 3, 1024>(grid, lds, stream, code, consts, a);
+    case 1: return launch_one<2, 2, 3, 1024>(grid, lds, stream, code, consts, a);
     case 2: return launch_one<4, 2, 2, 1024>(grid, lds, stream, code, consts, a);
-    case 3: return launch_one<2, 4, 2, 1024>(grid, lds, stream, code, consts, a);
+    case 3: return launch_one<2, 4, 3, 1024>(grid, lds, stream, code, consts, a);
     case 4: return launch_one<4, 4, 2, 1024>(grid, lds, stream, code, consts, a);
     default: return launch_one<8, 8, 1, 1024>(grid, lds, stream, code, consts, a);
     }

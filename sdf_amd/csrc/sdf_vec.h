@@ -104,6 +104,12 @@ template <typename T> SDF_DEV void late_bind(Vec<T, 2> &a, Vec<T, 2> &b, Vec<T, 
     asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(c.v[0]), "+v"(c.v[1]));
 }
 
+template <typename T> SDF_DEV void late_bind(Vec<T, 3> &a, Vec<T, 3> &b) {
+    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]));
+}
+template <typename T> SDF_DEV void late_bind(Vec<T, 3> &a, Vec<T, 3> &b, Vec<T, 3> &c) {
+    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(c.v[0]), "+v"(c.v[1]), "+v"(c.v[2]));
+}
 // A copy the register coalescer cannot see through (an explicit v_mov): used where a value moves
 // from one piece of machine state to another and the two must keep their own home registers.
 SDF_DEV double real_move(double x) { double r; asm volatile("v_mov_b64 %0, %1" : "=v"(r) : "v"(x)); return r; }

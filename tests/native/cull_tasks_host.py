@@ -132,7 +132,7 @@ extern "C" int cull_sample_loop_host(const unsigned char *record, int lx, int ly
                                      int sparse_tile, float *smp) {
     typedef double T;
     const bool sparse = sparse_tile != 0;
-    constexpr int NS = 2, BLOCK = 1024, NWAVE = BLOCK / 64;
+    constexpr int NS = 3, BLOCK = 1024, NWAVE = BLOCK / 64;
     struct V { T v[NS]; };
     auto host_field = [](const V &x, const V &y, const V &z) { V r; for (int k = 0; k < NS; k++) r.v[k] = x.v[k] + 64.0 * y.v[k] + 4096.0 * z.v[k] - 70000.0; return r; };
     struct { int lz; bool sample(int, int, int &, int &, int &) const { return false; } } tt{lz};

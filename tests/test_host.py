@@ -286,7 +286,7 @@ def test_build_self_check_and_build_info():
     engine.load_library()
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_check.py'), engine.LIB_PATH], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert 'k_mesh<double, false, 1, 1, 2, 1024, false>' in r.stdout and 'ISA CHECK FAILED' not in r.stdout
+    assert 'k_mesh<double, false, 1, 1, 3, 1024, false>' in r.stdout and 'ISA CHECK FAILED' not in r.stdout
     info = engine.build_info()
     assert 'HIP version' in info and 'structurizecfg-skip-uniform-regions' in info, info
 
