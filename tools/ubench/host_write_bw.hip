@@ -31,7 +31,7 @@ static std::vector<int> node_cpus(int node) {   // /sys/devices/system/node/node
     }
     return v;
 }
-static int g_pin_node = -1;
+static int g_pin_node = -1, g_spread = 0;   // g_spread: thread i -> cpu (i * 8) % n + (i * 8) / n of the node's list (one CCD after the other gets a thread)
 static double run(char *p, size_t n, int threads, bool nt, int reps) {
     std::vector<int> cpus = g_pin_node >= 0 ? node_cpus(g_pin_node) : std::vector<int>();
     double best = 1e30;
@@ -40,7 +40,7 @@ static double run(char *p, size_t n, int threads, bool nt, int reps) {
         std::vector<std::thread> th;
         for (int i = 0; i < threads; i++)
             th.emplace_back([=] {
-                if (!cpus.empty()) { cpu_set_t cs; CPU_ZERO(&cs); CPU_SET(cpus[i % cpus.size()], &cs); sched_setaffinity(0, sizeof cs, &cs); }
+                if (!cpus.empty()) { const size_t nc = cpus.size() > 64 ? 64 : cpus.size(); const size_t k = g_spread ? ((size_t)i * 8) % nc + ((size_t)i * 8) / nc : (size_t)i % cpus.size(); cpu_set_t cs; CPU_ZERO(&cs); CPU_SET(cpus[k % cpus.size()], &cs); sched_setaffinity(0, sizeof cs, &cs); }
                 // interleaved blocks of 576 KB like the expansion's (8192 triangles x 72 B)
                 const size_t blk = 8192 * 72, nblk = (n + blk - 1) / blk;
                 for (size_t b = i; b < nblk; b += threads) {
@@ -82,6 +82,14 @@ int main() {
             printf("threads bound to node %d, %2d threads: pinned %.2f / nt %.2f ms | ordinary %.2f / nt %.2f\n", node, threads, run(pinned, n, threads, false, 4), run(pinned, n, threads, true, 4),
                    run(plain, n, threads, false, 4), run(plain, n, threads, true, 4));
     }
+    g_spread = 1;
+    for (int node : {0, 1}) {
+        g_pin_node = node;
+        for (int threads : {8, 16, 32})
+            printf("threads bound to node %d ONE PER CCD FIRST, %2d threads: pinned %.2f / nt %.2f ms | ordinary %.2f / nt %.2f\n", node, threads, run(pinned, n, threads, false, 4), run(pinned, n, threads, true, 4),
+                   run(plain, n, threads, false, 4), run(plain, n, threads, true, 4));
+    }
+    g_spread = 0;
     g_pin_node = -1;
     // the D2H side: 47 MB of records into pinned memory while nothing else runs
     char *d = nullptr; (void)hipMalloc((void **)&d, 48 << 20);
