@@ -2,8 +2,8 @@
 //
 //   k_mesh   THE hot kernel: persistent workgroups (one per CU) pull surviving batches from the ordered work list.
 //            Per round, for batch k:
-//              1. sample   the units of 2^3 samples k_cull listed (cull_tasks) through the tape interpreter (two tasks of
-//                          64 samples per wave and pass, float64 or float32), cast to float32 like skimage's volume cast,
+//              1. sample   the units of 2^3 samples k_cull listed (cull_tasks) through the tape interpreter (NS tasks of
+//                          64 samples per wave and pass -- three in the one-pass kernels, sdf_mesh_inst.hip --, float64), cast to float32 like skimage's volume cast,
 //                          into a SPARSE tile in LDS (TileView: only the listed units; a tile that is not culled stays
 //                          dense) -- the field never touches HBM (reference `_worker`, sdf/core.py:50-52); the sign bits
 //                          of everything else come from the interval pass's sub-group states

@@ -1082,7 +1082,7 @@ static int launch_mesh(sdf_tape *t, const void *code, int precision, MeshArgs &a
     for (int k = 5; k >= 0; k--) if (np <= kFile[k][0] && nd <= kFile[k][1]) slots = k;
     if (c->mesh_slots >= 0 && c->mesh_slots <= 5 && np <= kFile[c->mesh_slots][0] && nd <= kFile[c->mesh_slots][1])
         slots = c->mesh_slots;                                                        // (tuning: another file that fits)
-    // (one shape per register file: 1024 threads x 2 samples per lane, the 8-slot file 1024 x 1 -- sdf_mesh_inst.hip)
+    // (one shape per register file and scheme: 1024 threads x 3 or 2 samples per lane, the 8-slot file 1024 x 1 -- sdf_mesh_inst.hip)
     if (precision != SDF_PRECISION_F64) return fail("k_mesh: float64 only");
     const int rc = t->full ? sdf_launch_mesh_f64_full(slots, 0, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a)
                            : sdf_launch_mesh_f64(slots, 0, a.twopass, grid, lds, st, (const uint32_t *)code, t->d_c64, a);
